@@ -1,0 +1,12 @@
+"""MI355X-native differentiable Gaussian-splat rasterizer for DreamGaussian's stage-1 path.
+
+Public surface (mirrors what gs_renderer.py imports, gs_renderer.py:10-14):
+    GaussianRasterizationSettings, GaussianRasterizer   (package `diff_gaussian_rasterization`)
+    distCUDA2                                           (package `simple_knn._C`)
+"""
+from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer,
+                         rasterize_gaussians, last_stats)
+from .knn import distCUDA2
+
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians",
+           "last_stats", "distCUDA2"]

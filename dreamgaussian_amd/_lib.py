@@ -1,0 +1,103 @@
+"""ctypes binding of libgsr.so (include/gsr.h). No CPU fallback: if the HIP library is
+missing this module raises, loudly, at first use."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import torch  # imported first so that libgsr.so binds to the HIP runtime torch already loaded
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgsr.so")
+
+EXPORTS = ("gsr_forward", "gsr_backward", "gsr_mark_visible", "gsr_dist2",
+           "gsr_geom_bytes", "gsr_img_bytes", "gsr_last_error", "gsr_version")
+
+
+class GsrView(C.Structure):
+    _fields_ = [("image_height", C.c_int32), ("image_width", C.c_int32),
+                ("tanfovx", C.c_float), ("tanfovy", C.c_float),
+                ("scale_modifier", C.c_float), ("sh_degree", C.c_int32),
+                ("prefiltered", C.c_int32), ("debug", C.c_int32),
+                ("bg", C.c_void_p), ("viewmatrix", C.c_void_p),
+                ("projmatrix", C.c_void_p), ("campos", C.c_void_p)]
+
+
+RESIZE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+
+
+class GsrAlloc(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("resize", RESIZE_FN)]
+
+
+class GsrStats(C.Structure):
+    _fields_ = [("num_instances", C.c_int64), ("num_instances_ref", C.c_int64),
+                ("num_visible", C.c_int64), ("max_tile_count", C.c_int64)]
+
+
+_lock = threading.Lock()
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load (once) and type the library. Raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built. Run "
+                "`python -m dreamgaussian_amd.build` (or __graft_entry__.build()); there is no "
+                "CPU fallback for the rasterizer.")
+        lib = C.CDLL(LIB_PATH)
+        p, i32, vp = C.c_void_p, C.c_int32, C.c_void_p
+        lib.gsr_forward.restype = C.c_int
+        lib.gsr_forward.argtypes = [C.POINTER(GsrView), i32, i32] + [p] * 7 + [p] * 4 + \
+            [GsrAlloc, GsrAlloc, GsrAlloc, C.POINTER(GsrStats), vp]
+        lib.gsr_backward.restype = C.c_int
+        lib.gsr_backward.argtypes = [C.POINTER(GsrView), i32, i32] + [p] * 7 + [p] + [p] * 3 + \
+            [p] * 3 + [p] * 8 + [GsrAlloc, vp]
+        lib.gsr_mark_visible.restype = C.c_int
+        lib.gsr_mark_visible.argtypes = [C.POINTER(GsrView), i32, p, p, vp]
+        lib.gsr_dist2.restype = C.c_int
+        lib.gsr_dist2.argtypes = [i32, p, p, GsrAlloc, vp]
+        lib.gsr_geom_bytes.restype = C.c_size_t
+        lib.gsr_geom_bytes.argtypes = [i32, i32, i32]
+        lib.gsr_img_bytes.restype = C.c_size_t
+        lib.gsr_img_bytes.argtypes = [i32, i32]
+        lib.gsr_last_error.restype = C.c_char_p
+        lib.gsr_version.restype = C.c_char_p
+        _lib = lib
+        return lib
+
+
+class Scratch:
+    """GsrAlloc backed by the torch caching allocator; keeps the tensor it handed out."""
+
+    def __init__(self, device):
+        self.device = device
+        self.tensor = None
+        self._cb = RESIZE_FN(self._resize)
+        self.alloc = GsrAlloc(None, self._cb)
+
+    def _resize(self, _ctx, nbytes):
+        try:
+            self.tensor = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=self.device)
+            return self.tensor.data_ptr()
+        except Exception:  # surfaces as "scratch allocation failed" on the C side
+            self.tensor = None
+            return 0
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().gsr_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")

@@ -1,0 +1,72 @@
+"""Build libgsr.so (the C-ABI library of include/gsr.h) for gfx950 with hipcc.
+
+One translation unit (csrc/gsr_api.hip includes the kernel files); cross-compiles without a
+GPU. The .so is written next to this package so that it travels with the source tree.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libgsr.so")
+STAMP = os.path.join(HERE, ".libgsr.stamp")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-shared",
+         "-Wall", "-Wno-unused-function"]
+
+
+def _sources():
+    root = os.path.dirname(HERE)
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))
+             if f.endswith((".hip", ".h"))]
+    files.append(os.path.join(root, "include", "gsr.h"))
+    return files
+
+
+def _digest() -> str:
+    h = hashlib.sha256()
+    h.update(" ".join(FLAGS + [ARCH]).encode())
+    for f in _sources():
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def hipcc_path() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm's hipcc to build libgsr.so)")
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    dig = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(STAMP):
+        with open(STAMP) as fh:
+            if fh.read().strip() == dig:
+                return LIB
+    cmd = [hipcc_path(), f"--offload-arch={ARCH}", *FLAGS,
+           os.path.join(CSRC, "gsr_api.hip"), "-o", LIB]
+    if verbose:
+        print("[dreamgaussian_amd.build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    with open(STAMP, "w") as fh:
+        fh.write(dig)
+    return LIB
+
+
+def is_current() -> bool:
+    if not (os.path.exists(LIB) and os.path.exists(STAMP)):
+        return False
+    with open(STAMP) as fh:
+        return fh.read().strip() == _digest()
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

@@ -1,0 +1,319 @@
+// gsr_api.hip -- host side of the C ABI declared in include/gsr.h (single translation unit:
+// the kernel files are included so that one hipcc invocation builds libgsr.so for gfx950).
+#include "../../include/gsr.h"
+#include "gsr_device.h"
+
+#include "gsr_preprocess.hip"
+#include "gsr_binning.hip"
+#include "gsr_render.hip"
+#include "gsr_knn.hip"
+
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+
+namespace {
+
+thread_local char g_err[512] = "";
+thread_local unsigned long long* g_pinned = nullptr;   // 8 x u64 host-pinned scratch
+
+int fail(int code, const char* fmt, const char* a = "", long long b = 0) {
+    snprintf(g_err, sizeof(g_err), fmt, a, b);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) return fail(-2, "HIP error '%s' at line %lld: " #expr, hipGetErrorString(e_), __LINE__); \
+    } while (0)
+
+int launch_status(bool debug, hipStream_t stream, const char* name) {
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && debug) e = hipStreamSynchronize(stream);
+    if (e == hipSuccess) return 0;
+    snprintf(g_err, sizeof(g_err), "kernel %s failed: %s", name, hipGetErrorString(e));
+    return -3;
+}
+#define LAUNCH_CHECK(view, stream, name)                                                    \
+    do { if (int rc_ = launch_status((view)->debug != 0, stream, name)) return rc_; } while (0)
+
+inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+struct GeomLayout {
+    size_t recs, emit, tile_count, cursor, tile_off, counters, total;
+    int nTiles;
+};
+GeomLayout geom_layout(int N, int H, int W) {
+    GeomLayout L;
+    const int gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE;
+    L.nTiles = gx * gy;
+    size_t o = 0;
+    L.recs = o; o += align_up((size_t)N * sizeof(SplatRec));
+    L.emit = o; o += align_up((size_t)N * sizeof(EmitRec));
+    L.tile_count = o; o += align_up((size_t)L.nTiles * 4);
+    L.cursor = o; o += align_up((size_t)L.nTiles * 4);
+    L.counters = o; o += align_up(8 * 8);
+    L.tile_off = o; o += align_up((size_t)(L.nTiles + 1) * 4);
+    L.total = o;
+    return L;
+}
+struct BinLayout { size_t entries, recs, total; };
+BinLayout bin_layout(size_t M) {
+    BinLayout L;
+    size_t o = 0;
+    L.recs = o; o += align_up(M * sizeof(SplatRec));      // first: the backward needs no M to find it
+    L.entries = o; o += align_up(M * 8);
+    L.total = o < 256 ? 256 : o;
+    return L;
+}
+
+ViewConst make_view(const GsrView* v) {
+    ViewConst c;
+    c.W = v->image_width; c.H = v->image_height;
+    c.gx = (c.W + GSR_TILE - 1) / GSR_TILE; c.gy = (c.H + GSR_TILE - 1) / GSR_TILE;
+    c.tanfovx = v->tanfovx; c.tanfovy = v->tanfovy;
+    c.focal_x = c.W / (2.0f * v->tanfovx); c.focal_y = c.H / (2.0f * v->tanfovy);
+    c.scale_modifier = v->scale_modifier; c.sh_degree = v->sh_degree;
+    c.bg = v->bg; c.view = v->viewmatrix; c.proj = v->projmatrix; c.campos = v->campos;
+    return c;
+}
+
+int check_view(const GsrView* v) {
+    if (!v) return fail(-1, "view is NULL%s", "");
+    if (v->image_width <= 0 || v->image_height <= 0) return fail(-1, "image size must be positive%s", "");
+    if (v->image_width > 32767 || v->image_height > 32767) return fail(-1, "image size above 32767 is not supported%s", "");
+    if (!v->bg || !v->viewmatrix || !v->projmatrix || !v->campos) return fail(-1, "bg/viewmatrix/projmatrix/campos must be device pointers%s", "");
+    if (v->sh_degree < 0 || v->sh_degree > 3) return fail(-1, "sh_degree must be in 0..3%s", "");
+    return 0;
+}
+
+int check_inputs(int N, int K, const GsrView* v, const float* means3D, const float* shs,
+                 const float* colors, const float* opac, const float* scales, const float* rots,
+                 const float* cov3D) {
+    if (N < 0) return fail(-1, "N must be >= 0%s", "");
+    if (N == 0) return 0;
+    if (!means3D || !opac) return fail(-1, "means3D and opacities are required%s", "");
+    if ((shs != nullptr) == (colors != nullptr)) return fail(-1, "Please provide excatly one of either SHs or precomputed colors!%s", "");
+    const bool sr = scales != nullptr && rots != nullptr;
+    if (sr == (cov3D != nullptr) || ((scales != nullptr) != (rots != nullptr)))
+        return fail(-1, "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!%s", "");
+    if (shs && K < (v->sh_degree + 1) * (v->sh_degree + 1)) return fail(-1, "shs has fewer coefficients than sh_degree needs%s", "");
+    return 0;
+}
+
+constexpr int kHistLdsMaxTiles = 16384;   // 64 KiB of LDS histogram
+
+}  // namespace
+
+extern "C" const char* gsr_last_error(void) { return g_err; }
+extern "C" const char* gsr_version(void) { return "gsr 0.1 (gfx950, wave64, 16x16 bins / 8x8 wave blocks)"; }
+
+extern "C" size_t gsr_geom_bytes(int32_t N, int32_t H, int32_t W) { return geom_layout(N, H, W).total; }
+extern "C" size_t gsr_img_bytes(int32_t H, int32_t W) { return align_up((size_t)H * W * 4) * 2; }
+
+extern "C" int gsr_forward(const GsrView* view, int32_t N, int32_t K,
+                           const float* means3D, const float* shs, const float* colors_precomp,
+                           const float* opacities, const float* scales, const float* rotations,
+                           const float* cov3D_precomp,
+                           float* out_color, float* out_depth, float* out_alpha, int32_t* radii,
+                           GsrAlloc geom, GsrAlloc bin, GsrAlloc img,
+                           GsrStats* stats, gsr_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (int rc = check_view(view)) return rc;
+    if (int rc = check_inputs(N, K, view, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp)) return rc;
+    if (!out_color || !out_depth || !out_alpha || (N > 0 && !radii)) return fail(-1, "output pointers are required%s", "");
+    if (!geom.resize || !bin.resize || !img.resize) return fail(-1, "scratch allocators are required%s", "");
+    const ViewConst vc = make_view(view);
+    const int H = vc.H, W = vc.W;
+    const GeomLayout GL = geom_layout(N, H, W);
+    const int T = GL.nTiles;
+
+    char* gbuf = (char*)geom.resize(geom.ctx, GL.total);
+    char* ibuf = (char*)img.resize(img.ctx, gsr_img_bytes(H, W));
+    if (!gbuf || !ibuf) return fail(-4, "scratch allocation failed%s", "");
+    SplatRec* recs = (SplatRec*)(gbuf + GL.recs);
+    EmitRec* emit = (EmitRec*)(gbuf + GL.emit);
+    uint32_t* tile_count = (uint32_t*)(gbuf + GL.tile_count);
+    uint32_t* cursor = (uint32_t*)(gbuf + GL.cursor);
+    uint32_t* tile_off = (uint32_t*)(gbuf + GL.tile_off);
+    unsigned long long* counters = (unsigned long long*)(gbuf + GL.counters);
+    float* final_T = (float*)ibuf;
+    uint32_t* n_contrib = (uint32_t*)(ibuf + align_up((size_t)H * W * 4));
+
+    // tile_count | cursor | counters are contiguous: one memset
+    HIP_TRY(hipMemsetAsync(gbuf + GL.tile_count, 0, GL.tile_off - GL.tile_count, stream));
+
+    const int hist_in_lds = T <= kHistLdsMaxTiles;
+    const int grid_n = N > 0 ? (int)fmin((double)((N + 255) / 256), 512.0) : 0;
+    if (N > 0) {
+        const size_t hist_bytes = hist_in_lds ? (((size_t)T * 4 + 15) & ~(size_t)15) : 0;
+        const size_t sh_bytes = (shs && K > 1) ? (size_t)256 * (3 * K + 1) * 4 : 0;
+        const size_t lds = hist_bytes + sh_bytes;
+        if (lds > 160 * 1024) return fail(-1, "preprocess needs more than 160 KiB of LDS%s", "");
+        if (lds > 48 * 1024)
+            HIP_TRY(hipFuncSetAttribute((const void*)gsr_preprocess_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(gsr_preprocess_fwd, dim3(grid_n), dim3(256), lds, stream, vc, N, K, means3D, shs,
+                           colors_precomp, opacities, scales, rotations, cov3D_precomp, recs, emit, radii,
+                           tile_count, counters, hist_in_lds);
+        LAUNCH_CHECK(view, stream, "preprocess_fwd");
+    }
+    hipLaunchKernelGGL(gsr_tile_scan, dim3(1), dim3(1024), 0, stream, tile_count, tile_off, T, counters);
+    LAUNCH_CHECK(view, stream, "tile_scan");
+
+    // the one host round trip of the forward: how many (tile,Gaussian) instances to allocate
+    if (!g_pinned) HIP_TRY(hipHostMalloc((void**)&g_pinned, 8 * sizeof(unsigned long long), hipHostMallocDefault));
+    HIP_TRY(hipMemcpyAsync(g_pinned, counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    const unsigned long long M_ref = g_pinned[0], V = g_pinned[1], M = g_pinned[2], maxc = g_pinned[3];
+    if (stats) { stats->num_instances = (int64_t)M; stats->num_instances_ref = (int64_t)M_ref; stats->num_visible = (int64_t)V; stats->max_tile_count = (int64_t)maxc; }
+    if (M >= 0xfffffff0ull) return fail(-5, "too many tile instances (%s%lld)", "", (long long)M);
+
+    const BinLayout BL = bin_layout((size_t)M);
+    char* bbuf = (char*)bin.resize(bin.ctx, BL.total);
+    if (!bbuf) return fail(-4, "bin scratch allocation failed%s", "");
+    unsigned long long* entries = (unsigned long long*)(bbuf + BL.entries);
+    SplatRec* srecs = (SplatRec*)(bbuf + BL.recs);
+
+    if (M > 0) {
+        const size_t lds = hist_in_lds ? (size_t)T * 4 : 0;
+        if (lds > 48 * 1024)
+            HIP_TRY(hipFuncSetAttribute((const void*)gsr_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(gsr_scatter, dim3(grid_n), dim3(256), lds, stream, N, emit, tile_off, cursor, entries,
+                           vc.gx, T, hist_in_lds, (uint32_t)M);
+        LAUNCH_CHECK(view, stream, "scatter");
+        // per-tile sort, three size classes
+        hipLaunchKernelGGL((gsr_tile_sort_lds<2048, 256>), dim3(T), dim3(256), 2048 * 8, stream, tile_off, entries, recs, srecs, 0u, 2048u);
+        LAUNCH_CHECK(view, stream, "tile_sort_small");
+        if (maxc > 2048) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                HIP_TRY(hipFuncSetAttribute((const void*)gsr_tile_sort_lds<16384, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL((gsr_tile_sort_lds<16384, 1024>), dim3(T), dim3(1024), 16384 * 8, stream, tile_off, entries, recs, srecs, 2048u, 16384u);
+            LAUNCH_CHECK(view, stream, "tile_sort_large");
+        }
+        if (maxc > 16384) {
+            hipLaunchKernelGGL(gsr_tile_sort_global, dim3(T), dim3(1024), 0, stream, tile_off, entries, recs, srecs, 16384u);
+            LAUNCH_CHECK(view, stream, "tile_sort_global");
+        }
+    }
+    hipLaunchKernelGGL(gsr_render_fwd, dim3(T), dim3(256), 0, stream, tile_off, srecs, view->bg, W, H, vc.gx,
+                       out_color, out_depth, out_alpha, final_T, n_contrib);
+    LAUNCH_CHECK(view, stream, "render_fwd");
+    return 0;
+}
+
+extern "C" int gsr_backward(const GsrView* view, int32_t N, int32_t K,
+                            const float* means3D, const float* shs, const float* colors_precomp,
+                            const float* opacities, const float* scales, const float* rotations,
+                            const float* cov3D_precomp, const int32_t* radii,
+                            const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
+                            const void* geom, const void* bin, const void* img,
+                            float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs, float* dL_dcolors,
+                            float* dL_dopacities, float* dL_dscales, float* dL_drotations,
+                            float* dL_dcov3D, GsrAlloc tmp, gsr_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (int rc = check_view(view)) return rc;
+    if (int rc = check_inputs(N, K, view, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp)) return rc;
+    if (N == 0) return 0;
+    if (!geom || !bin || !img || !radii) return fail(-1, "forward state (geom/bin/img/radii) is required%s", "");
+    if (!dL_dcolor || !dL_ddepth || !dL_dalpha) return fail(-1, "incoming gradients are required%s", "");
+    if (!dL_dmeans3D || !dL_dmeans2D || !dL_dopacities) return fail(-1, "dL_dmeans3D/dL_dmeans2D/dL_dopacities are required%s", "");
+    if (shs && !dL_dshs) return fail(-1, "dL_dshs is required with shs%s", "");
+    if (!tmp.resize) return fail(-1, "tmp allocator is required%s", "");
+    const ViewConst vc = make_view(view);
+    const int H = vc.H, W = vc.W;
+    const GeomLayout GL = geom_layout(N, H, W);
+    const int T = GL.nTiles;
+    const char* gbuf = (const char*)geom;
+    const char* ibuf = (const char*)img;
+    const SplatRec* recs = (const SplatRec*)(gbuf + GL.recs);
+    const uint32_t* tile_off = (const uint32_t*)(gbuf + GL.tile_off);
+    const unsigned long long* counters = (const unsigned long long*)(gbuf + GL.counters);
+    const float* final_T = (const float*)ibuf;
+    const uint32_t* n_contrib = (const uint32_t*)(ibuf + align_up((size_t)H * W * 4));
+    (void)counters;
+    const SplatRec* srecs = (const SplatRec*)bin;          // BinLayout.recs == 0
+
+    float* g2d = (float*)tmp.resize(tmp.ctx, align_up((size_t)N * GSR_G2D_STRIDE * 4));
+    if (!g2d) return fail(-4, "tmp scratch allocation failed%s", "");
+    HIP_TRY(hipMemsetAsync(g2d, 0, (size_t)N * GSR_G2D_STRIDE * 4, stream));
+
+    hipLaunchKernelGGL(gsr_render_bwd, dim3(T), dim3(256), 0, stream, tile_off, srecs, view->bg, W, H, vc.gx,
+                       final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, g2d);
+    LAUNCH_CHECK(view, stream, "render_bwd");
+
+    const int grid_n = (int)fmin((double)((N + 255) / 256), 2048.0);
+    const size_t lds = (shs && K > 1) ? (size_t)256 * (3 * K + 1) * 4 : 0;
+    if (lds > 160 * 1024) return fail(-1, "preprocess_bwd needs more than 160 KiB of LDS%s", "");
+    if (lds > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)gsr_preprocess_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(gsr_preprocess_bwd, dim3(grid_n), dim3(256), lds, stream, vc, N, K, means3D, shs,
+                       colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, recs, g2d,
+                       dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacities, dL_dscales,
+                       dL_drotations, dL_dcov3D);
+    LAUNCH_CHECK(view, stream, "preprocess_bwd");
+    return 0;
+}
+
+extern "C" int gsr_mark_visible(const GsrView* view, int32_t N, const float* means3D,
+                                uint8_t* visible, gsr_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!view || !view->viewmatrix) return fail(-1, "viewmatrix is required%s", "");
+    if (N < 0) return fail(-1, "N must be >= 0%s", "");
+    if (N == 0) return 0;
+    if (!means3D || !visible) return fail(-1, "means3D and visible are required%s", "");
+    hipLaunchKernelGGL(gsr_mark_visible_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, view->viewmatrix, N, means3D, visible);
+    LAUNCH_CHECK(view, stream, "mark_visible");
+    return 0;
+}
+
+extern "C" int gsr_dist2(int32_t P, const float* points, float* out, GsrAlloc tmp, gsr_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (P < 0) return fail(-1, "P must be >= 0%s", "");
+    if (P == 0) return 0;
+    if (!points || !out) return fail(-1, "points and out are required%s", "");
+    if (!tmp.resize) return fail(-1, "tmp allocator is required%s", "");
+    // grid resolution from P alone (no host round trip): ~4 points per cell on a filled box
+    int G = (int)floor(cbrt((double)P / 4.0));
+    if (G < 1) G = 1;
+    if (G > 128) G = 128;
+    const size_t nCells = (size_t)G * G * G;
+    size_t o = 0;
+    const size_t o_bbox = o; o += align_up(6 * 4);
+    const size_t o_grid = o; o += align_up(sizeof(KnnGrid));
+    const size_t o_cnt = o; o += align_up(nCells * 4);
+    const size_t o_cur = o; o += align_up(nCells * 4);
+    const size_t o_off = o; o += align_up((nCells + 1) * 4);
+    const size_t o_cell = o; o += align_up((size_t)P * 4);
+    const size_t o_sorted = o; o += align_up((size_t)P * 16);
+    char* buf = (char*)tmp.resize(tmp.ctx, o);
+    if (!buf) return fail(-4, "tmp scratch allocation failed%s", "");
+    uint32_t* bbox = (uint32_t*)(buf + o_bbox);
+    KnnGrid* grid = (KnnGrid*)(buf + o_grid);
+    uint32_t* cnt = (uint32_t*)(buf + o_cnt);
+    uint32_t* cur = (uint32_t*)(buf + o_cur);
+    uint32_t* off = (uint32_t*)(buf + o_off);
+    uint32_t* cell_of = (uint32_t*)(buf + o_cell);
+    float4* sorted = (float4*)(buf + o_sorted);
+    HIP_TRY(hipMemsetAsync(bbox, 0xff, 3 * 4, stream));
+    HIP_TRY(hipMemsetAsync(bbox + 3, 0, 3 * 4, stream));
+    HIP_TRY(hipMemsetAsync(cnt, 0, o_off - o_cnt, stream));   // cnt | cur
+    const int grid_p = (int)fmin((double)((P + 255) / 256), 2048.0);
+    GsrView dbg; memset(&dbg, 0, sizeof(dbg));
+    hipLaunchKernelGGL(gsr_knn_bbox, dim3(grid_p), dim3(256), 0, stream, P, points, bbox);
+    LAUNCH_CHECK(&dbg, stream, "knn_bbox");
+    hipLaunchKernelGGL(gsr_knn_grid_setup, dim3(1), dim3(64), 0, stream, bbox, G, grid);
+    LAUNCH_CHECK(&dbg, stream, "knn_grid_setup");
+    hipLaunchKernelGGL(gsr_knn_count, dim3(grid_p), dim3(256), 0, stream, P, points, grid, cell_of, cnt);
+    LAUNCH_CHECK(&dbg, stream, "knn_count");
+    hipLaunchKernelGGL(gsr_knn_scan, dim3(1), dim3(1024), 0, stream, cnt, off, (int)nCells);
+    LAUNCH_CHECK(&dbg, stream, "knn_scan");
+    hipLaunchKernelGGL(gsr_knn_scatter, dim3(grid_p), dim3(256), 0, stream, P, points, cell_of, off, cur, sorted);
+    LAUNCH_CHECK(&dbg, stream, "knn_scatter");
+    hipLaunchKernelGGL(gsr_knn_search, dim3(grid_p), dim3(256), 0, stream, P, sorted, off, grid, out);
+    LAUNCH_CHECK(&dbg, stream, "knn_search");
+    return 0;
+}

@@ -1,0 +1,173 @@
+// gsr_binning.hip -- tile binning and per-tile depth sort (K2, K3, K4).
+//
+// Replaces (behaviour, not code) the duplicate-with-keys / global radix sort / range
+// identification stage of the external rasterizer: order inside a
+// tile = ascending fp32 depth bits, ties in ascending Gaussian index.
+//
+// MI355X design: no global M-element sort. Per-tile instance counts come out of K1's LDS
+// histograms; K2 scans them into segment offsets; K3 scatters 8-byte (depth,id) keys into the
+// tile segments through an LDS-privatised cursor reservation (one returning global atomic per
+// (workgroup,tile) instead of one per instance); K4 sorts each segment inside LDS (bitonic,
+// 64-bit keys, up to 16384 entries = 128 KiB of the CU's 160 KiB) and writes the tile's
+// 64-byte SplatRec stream in final order so the render kernels read it with scalar loads.
+#include "gsr_device.h"
+
+// ---------------------------------------------------------------------------------------
+// K2: exclusive scan of the per-tile counts (single workgroup; T is a few thousand).
+// counters[2] = M_emit, counters[3] = max per-tile count.
+// ---------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(1024)
+gsr_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_off, int T,
+              unsigned long long* __restrict__ counters) {
+    __shared__ unsigned long long wsum[16];
+    __shared__ uint32_t wmax[16];
+    const int per = (T + 1023) / 1024;
+    const int beg = threadIdx.x * per, end = min(beg + per, T);
+    unsigned long long local = 0;
+    uint32_t lmax = 0;
+    for (int i = beg; i < end; ++i) { const uint32_t c = tile_count[i]; local += c; lmax = max(lmax, c); }
+    // inclusive scan inside the wave
+    unsigned long long incl = local;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    lmax = wave_max_u32(lmax);
+    if (lane == 63) wsum[wave] = incl;
+    if (lane == 0) wmax[wave] = lmax;
+    __syncthreads();
+    unsigned long long wave_base = 0;
+    for (int w = 0; w < wave; ++w) wave_base += wsum[w];
+    unsigned long long run = wave_base + incl - local;
+    for (int i = beg; i < end; ++i) { tile_off[i] = (uint32_t)run; run += tile_count[i]; }
+    if (threadIdx.x == 1023) {
+        tile_off[T] = (uint32_t)(wave_base + incl);
+        counters[2] = wave_base + incl;
+        uint32_t m = 0;
+        for (int w = 0; w < 16; ++w) m = max(m, wmax[w]);
+        counters[3] = m;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// K3: scatter (depth bits, id) keys into the tile segments.
+// dynamic LDS: nTiles uint32 when hist_in_lds.
+// ---------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(256)
+gsr_scatter(int N, const EmitRec* __restrict__ emit, const uint32_t* __restrict__ tile_off,
+            uint32_t* __restrict__ cursor, unsigned long long* __restrict__ entries,
+            int gx, int nTiles, int hist_in_lds, uint32_t capacity) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint32_t* hist = reinterpret_cast<uint32_t*>(smem_raw);
+    if (hist_in_lds) {
+        for (int t = threadIdx.x; t < nTiles; t += blockDim.x) hist[t] = 0;
+        __syncthreads();
+        for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < N; idx += gridDim.x * blockDim.x) {
+            const uint4 em = reinterpret_cast<const uint4*>(emit)[idx];
+            const int x0 = em.x & 0xffff, x1 = em.x >> 16, y0 = em.y & 0xffff, y1 = em.y >> 16;
+            for (int ty = y0; ty < y1; ++ty)
+                for (int tx = x0; tx < x1; ++tx) atomicAdd(&hist[ty * gx + tx], 1u);
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < nTiles; t += blockDim.x) {
+            const uint32_t c = hist[t];
+            hist[t] = c ? (tile_off[t] + atomicAdd(&cursor[t], c)) : 0u;
+        }
+        __syncthreads();
+    }
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < N; idx += gridDim.x * blockDim.x) {
+        const uint4 em = reinterpret_cast<const uint4*>(emit)[idx];
+        const int x0 = em.x & 0xffff, x1 = em.x >> 16, y0 = em.y & 0xffff, y1 = em.y >> 16;
+        const unsigned long long key = ((unsigned long long)em.z << 32) | (uint32_t)idx;
+        for (int ty = y0; ty < y1; ++ty)
+            for (int tx = x0; tx < x1; ++tx) {
+                const int t = ty * gx + tx;
+                uint32_t pos;
+                if (hist_in_lds) pos = atomicAdd(&hist[t], 1u);
+                else pos = tile_off[t] + atomicAdd(&cursor[t], 1u);
+                if (pos < capacity) entries[pos] = key;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// K4: per-tile sort + record gather.
+// Bitonic network in the "all ascending" form (first step of each merge mirrors, the rest
+// are half-cleaners) so that indices >= n act as +infinity keys and are simply skipped.
+// ---------------------------------------------------------------------------------------
+template <typename KeyPtr>
+__device__ __forceinline__ void bitonic_sort(KeyPtr keys, uint32_t n, int nthreads) {
+    uint32_t n2 = 1;
+    while (n2 < n) n2 <<= 1;
+    const uint32_t pairs = n2 >> 1;
+    for (uint32_t k = 2, lk = 1; k <= n2; k <<= 1, ++lk) {
+        // mirror step: lo = blk*k + w, hi = blk*k + k-1-w, w < k/2
+        for (uint32_t t = threadIdx.x; t < pairs; t += nthreads) {
+            const uint32_t w = t & ((k >> 1) - 1), blk = t >> (lk - 1);
+            const uint32_t lo = blk * k + w, hi = blk * k + (k - 1 - w);
+            if (hi < n) {
+                const unsigned long long a = keys[lo], b = keys[hi];
+                if (a > b) { keys[lo] = b; keys[hi] = a; }
+            }
+        }
+        __syncthreads();
+        for (uint32_t j = k >> 2, lj = lk - 2; j >= 1; j >>= 1, --lj) {
+            for (uint32_t t = threadIdx.x; t < pairs; t += nthreads) {
+                const uint32_t lo = ((t >> lj) << (lj + 1)) | (t & (j - 1));
+                const uint32_t hi = lo + j;
+                if (hi < n) {
+                    const unsigned long long a = keys[lo], b = keys[hi];
+                    if (a > b) { keys[lo] = b; keys[hi] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// write the tile's records in sorted order: 4 lanes move one 64-byte record
+__device__ __forceinline__ void gather_records(const unsigned long long* keys, uint32_t n,
+                                               const SplatRec* __restrict__ geom,
+                                               SplatRec* __restrict__ out, int nthreads) {
+    const uint32_t part = threadIdx.x & 3;
+    for (uint32_t i = threadIdx.x >> 2; i < n; i += (nthreads >> 2)) {
+        const uint32_t id = (uint32_t)keys[i];
+        const uint4 v = reinterpret_cast<const uint4*>(geom + id)[part];
+        reinterpret_cast<uint4*>(out + i)[part] = v;
+    }
+}
+
+template <int CAP, int NT>
+__global__ void __launch_bounds__(NT)
+gsr_tile_sort_lds(const uint32_t* __restrict__ tile_off, const unsigned long long* __restrict__ entries,
+                  const SplatRec* __restrict__ geom, SplatRec* __restrict__ out,
+                  uint32_t lo_excl, uint32_t hi_incl) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem_raw);
+    const uint32_t s = tile_off[blockIdx.x];
+    const uint32_t n = tile_off[blockIdx.x + 1] - s;
+    if (n <= lo_excl || n > hi_incl) return;
+    for (uint32_t i = threadIdx.x; i < n; i += NT) keys[i] = entries[s + i];
+    __syncthreads();
+    bitonic_sort(keys, n, NT);
+    gather_records(keys, n, geom, out + s, NT);
+}
+
+// fallback for lists longer than the LDS capacity: same network, in place in HBM
+extern "C" __global__ void __launch_bounds__(1024)
+gsr_tile_sort_global(const uint32_t* __restrict__ tile_off, unsigned long long* __restrict__ entries,
+                     const SplatRec* __restrict__ geom, SplatRec* __restrict__ out,
+                     uint32_t lo_excl) {
+    const uint32_t s = tile_off[blockIdx.x];
+    const uint32_t n = tile_off[blockIdx.x + 1] - s;
+    if (n <= lo_excl) return;
+    bitonic_sort(entries + s, n, 1024);
+    gather_records(entries + s, n, geom, out + s, 1024);
+}
+
+template __global__ void gsr_tile_sort_lds<2048, 256>(const uint32_t*, const unsigned long long*,
+                                                      const SplatRec*, SplatRec*, uint32_t, uint32_t);
+template __global__ void gsr_tile_sort_lds<16384, 1024>(const uint32_t*, const unsigned long long*,
+                                                        const SplatRec*, SplatRec*, uint32_t, uint32_t);

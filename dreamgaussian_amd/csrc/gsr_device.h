@@ -1,0 +1,98 @@
+// gsr_device.h -- shared device-side definitions for the gfx950 splat rasterizer.
+// wave = 64 lanes everywhere; no portability shims.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define GSR_TILE 16          // binning granularity in pixels (numerics: SURVEY 7, hard part 2)
+#define GSR_LOG2E 1.4426950408889634f
+#define GSR_LN2 0.6931471805599453f
+
+// One 64-byte record per Gaussian (geom stage) and per (tile,Gaussian) instance (sorted
+// stage). 64 B = one s_load_dwordx16: the render kernels read records with SCALAR loads
+// because every lane of a wave consumes the same Gaussian.
+struct __attribute__((aligned(16))) SplatRec {
+    float x, y;        // projected mean, pixel coordinates
+    float qa, qb;      // -0.5*A*log2e, -B*log2e      (conic A,B,C; G = exp2(qa dx^2 + qb dx dy + qc dy^2))
+    float qc, opac;    // -0.5*C*log2e, opacity
+    float r, g;        // colour (after +0.5 and clamp at 0)
+    float b, depth;    // view-space z
+    uint32_t id;       // Gaussian index
+    uint32_t bbx;      // int16 xmin | int16 xmax << 16 : pixel columns where alpha can reach 1/255
+    uint32_t bby;      // same for rows
+    uint32_t rectx;    // emission tile rect  x0 | x1 << 16   (x1 exclusive)
+    uint32_t recty;    //                     y0 | y1 << 16
+    uint32_t flags;    // bit0..2 colour channel clamped at 0; bit3 emits instances
+};
+static_assert(sizeof(SplatRec) == 64, "SplatRec must be 64 bytes");
+
+#define GSR_FLAG_EMIT 8u
+
+// per-Gaussian streaming side array for the scatter kernel (coalesced 16 B / lane)
+struct __attribute__((aligned(16))) EmitRec {
+    uint32_t rectx, recty, depth_bits, pad;
+};
+
+// screen-space gradient accumulators written by render_bwd (atomics), read by preprocess_bwd
+// [0] sum dL/dG*G*(2qa dx + qb dy)   -> mean2D.x   (times ln2 * 0.5 W later)
+// [1] sum dL/dG*G*(2qc dy + qb dx)   -> mean2D.y
+// [2] dL/dA  [3] dL/dB  [4] dL/dC  (true conic)   [5] dL/dopacity
+// [6..8] dL/drgb  [9] dL/ddepth  [10..11] pad
+#define GSR_G2D_STRIDE 12
+
+struct ViewConst {           // by-value kernel argument (scalar registers)
+    int W, H, gx, gy;
+    float tanfovx, tanfovy, focal_x, focal_y;
+    float scale_modifier;
+    int sh_degree;
+    const float* bg;
+    const float* view;
+    const float* proj;
+    const float* campos;
+};
+
+// ---------------------------------------------------------------------------------------
+// wave-level helpers (DPP; gfx9 encodings)
+// ---------------------------------------------------------------------------------------
+#define DPP_ROW_SHR(n) (0x110 + (n))
+#define DPP_ROW_BCAST15 0x142
+#define DPP_ROW_BCAST31 0x143
+
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_add(float v) {
+    // v + (v moved by CTRL), lanes without a source add 0
+    int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true);
+    return v + __int_as_float(moved);
+}
+
+// sum over the 64 lanes; the total is valid in lane 63 only
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+    v = dpp_add<DPP_ROW_SHR(1)>(v);
+    v = dpp_add<DPP_ROW_SHR(2)>(v);
+    v = dpp_add<DPP_ROW_SHR(4)>(v);
+    v = dpp_add<DPP_ROW_SHR(8)>(v);
+    {   // row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3
+        int m = __builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_ROW_BCAST15, 0xa, 0xf, false);
+        v = v + __int_as_float(m);
+    }
+    {
+        int m = __builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_ROW_BCAST31, 0xc, 0xf, false);
+        v = v + __int_as_float(m);
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64);
+        v = v > o ? v : o;
+    }
+    return v;
+}
+
+__device__ __forceinline__ int32_t unpack_lo16(uint32_t v) { return (int32_t)(int16_t)(v & 0xffffu); }
+__device__ __forceinline__ int32_t unpack_hi16(uint32_t v) { return (int32_t)v >> 16; }
+__device__ __forceinline__ uint32_t pack16(int32_t lo, int32_t hi) {
+    return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16);
+}

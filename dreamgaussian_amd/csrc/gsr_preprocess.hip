@@ -1,0 +1,576 @@
+// gsr_preprocess.hip -- per-Gaussian stage, forward (K1) and backward (K6).
+//
+// Replaces (behaviour, not code) the preprocess half of the external rasterizer that
+// gs_renderer.py:800-809 calls; in-tree Python twins of the math: gs_renderer.py:85-132
+// (rotation/covariance), sh_utils.py:57-112 + gs_renderer.py:793 (SH -> RGB),
+// gs_renderer.py:629-671 (projection conventions). Spec: SURVEY.md Appendix A.3 / A.7.
+//
+// Both kernels are HBM-streaming: one lane per Gaussian, SH rows staged through LDS with
+// coalesced loads/stores (row pitch 3K+1 dwords: odd => conflict-free per-lane row walks),
+// per-tile instance counts privatised in an LDS histogram and flushed once per workgroup.
+#include "gsr_device.h"
+
+namespace {
+
+constexpr float SH_C0 = 0.28209479177387814f;
+constexpr float SH_C1 = 0.4886025119029199f;
+constexpr float SH_C2_0 = 1.0925484305920792f, SH_C2_1 = -1.0925484305920792f,
+                SH_C2_2 = 0.31539156525252005f, SH_C2_3 = -1.0925484305920792f,
+                SH_C2_4 = 0.5462742152960396f;
+constexpr float SH_C3_0 = -0.5900435899266435f, SH_C3_1 = 2.890611442640554f,
+                SH_C3_2 = -0.4570457994644658f, SH_C3_3 = 0.3731763325901154f,
+                SH_C3_4 = -0.4570457994644658f, SH_C3_5 = 1.445305721320277f,
+                SH_C3_6 = -0.5900435899266435f;
+
+struct Cov3 { float c0, c1, c2, c3, c4, c5; };   // S00 S01 S02 S11 S12 S22
+
+__device__ __forceinline__ void quat_to_R(const float4 q, float R[9]) {
+    const float r = q.x, x = q.y, y = q.z, z = q.w;   // (r,x,y,z), gs_renderer.py:92-105
+    R[0] = 1.f - 2.f * (y * y + z * z); R[1] = 2.f * (x * y - r * z); R[2] = 2.f * (x * z + r * y);
+    R[3] = 2.f * (x * y + r * z); R[4] = 1.f - 2.f * (x * x + z * z); R[5] = 2.f * (y * z - r * x);
+    R[6] = 2.f * (x * z - r * y); R[7] = 2.f * (y * z + r * x); R[8] = 1.f - 2.f * (x * x + y * y);
+}
+
+// Sigma = (R diag(s)) (R diag(s))^T
+__device__ __forceinline__ Cov3 cov3d_from_scale_rot(const float3 s, const float R[9]) {
+    float M[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { M[3 * i] = R[3 * i] * s.x; M[3 * i + 1] = R[3 * i + 1] * s.y; M[3 * i + 2] = R[3 * i + 2] * s.z; }
+    Cov3 c;
+    c.c0 = M[0] * M[0] + M[1] * M[1] + M[2] * M[2];
+    c.c1 = M[0] * M[3] + M[1] * M[4] + M[2] * M[5];
+    c.c2 = M[0] * M[6] + M[1] * M[7] + M[2] * M[8];
+    c.c3 = M[3] * M[3] + M[4] * M[4] + M[5] * M[5];
+    c.c4 = M[3] * M[6] + M[4] * M[7] + M[5] * M[8];
+    c.c5 = M[6] * M[6] + M[7] * M[7] + M[8] * M[8];
+    return c;
+}
+
+struct Proj2D {
+    float tx, ty, tz;       // view-space mean with the 1.3*tanfov clamp applied to x,y
+    bool clampx, clampy;
+    float T0[3], T1[3];     // rows of J * Wr
+    float a, b, c;          // 2D covariance incl. the +0.3 dilation
+};
+
+__device__ __forceinline__ Proj2D project_cov(const ViewConst& vc, const float* __restrict__ V,
+                                              float3 pv, const Cov3& S) {
+    Proj2D o;
+    const float limx = 1.3f * vc.tanfovx, limy = 1.3f * vc.tanfovy;
+    const float txtz = pv.x / pv.z, tytz = pv.y / pv.z;
+    o.clampx = (txtz < -limx) || (txtz > limx);
+    o.clampy = (tytz < -limy) || (tytz > limy);
+    o.tx = fminf(limx, fmaxf(-limx, txtz)) * pv.z;
+    o.ty = fminf(limy, fmaxf(-limy, tytz)) * pv.z;
+    o.tz = pv.z;
+    const float iz = 1.f / pv.z;
+    const float j00 = vc.focal_x * iz, j02 = -(vc.focal_x * o.tx) * iz * iz;
+    const float j11 = vc.focal_y * iz, j12 = -(vc.focal_y * o.ty) * iz * iz;
+    // Wr[i][k] = V[k][i] = V[4k+i]  (view = p @ V, row-vector convention)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        o.T0[k] = j00 * V[4 * k + 0] + j02 * V[4 * k + 2];
+        o.T1[k] = j11 * V[4 * k + 1] + j12 * V[4 * k + 2];
+    }
+    // u = Sigma * T0^T, w = Sigma * T1^T
+    const float u0 = S.c0 * o.T0[0] + S.c1 * o.T0[1] + S.c2 * o.T0[2];
+    const float u1 = S.c1 * o.T0[0] + S.c3 * o.T0[1] + S.c4 * o.T0[2];
+    const float u2 = S.c2 * o.T0[0] + S.c4 * o.T0[1] + S.c5 * o.T0[2];
+    const float w0 = S.c0 * o.T1[0] + S.c1 * o.T1[1] + S.c2 * o.T1[2];
+    const float w1 = S.c1 * o.T1[0] + S.c3 * o.T1[1] + S.c4 * o.T1[2];
+    const float w2 = S.c2 * o.T1[0] + S.c4 * o.T1[1] + S.c5 * o.T1[2];
+    o.a = o.T0[0] * u0 + o.T0[1] * u1 + o.T0[2] * u2 + 0.3f;
+    o.b = o.T1[0] * u0 + o.T1[1] * u1 + o.T1[2] * u2;
+    o.c = o.T1[0] * w0 + o.T1[1] * w1 + o.T1[2] * w2 + 0.3f;
+    return o;
+}
+
+// SH basis values for unit direction d (sh_utils.py:74-100); nb = (deg+1)^2 entries filled
+__device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, float B[16]) {
+    B[0] = SH_C0;
+    if (deg > 0) {
+        B[1] = -SH_C1 * y; B[2] = SH_C1 * z; B[3] = -SH_C1 * x;
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            B[4] = SH_C2_0 * xy; B[5] = SH_C2_1 * yz; B[6] = SH_C2_2 * (2.f * zz - xx - yy);
+            B[7] = SH_C2_3 * xz; B[8] = SH_C2_4 * (xx - yy);
+            if (deg > 2) {
+                B[9] = SH_C3_0 * y * (3.f * xx - yy); B[10] = SH_C3_1 * xy * z;
+                B[11] = SH_C3_2 * y * (4.f * zz - xx - yy);
+                B[12] = SH_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy);
+                B[13] = SH_C3_4 * x * (4.f * zz - xx - yy); B[14] = SH_C3_5 * z * (xx - yy);
+                B[15] = SH_C3_6 * x * (xx - 3.f * yy);
+            }
+        }
+    }
+}
+
+// Stage `cnt` SH rows (each 3K floats, contiguous in HBM) into LDS with pitch 3K+1.
+__device__ __forceinline__ void stage_rows_in(const float* __restrict__ src, float* lds,
+                                              int cnt, int rowlen) {
+    const int total = cnt * rowlen;
+    const int pitch = rowlen + 1;
+    if ((rowlen & 3) == 0) {
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        for (int i = threadIdx.x; i < total / 4; i += blockDim.x) {
+            const float4 v = s4[i];
+            const int e = 4 * i, row = e / rowlen, col = e - row * rowlen;  // rowlen%4==0: no row straddle
+            float* d = lds + row * pitch + col;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+    } else {
+        for (int e = threadIdx.x; e < total; e += blockDim.x) {
+            const int row = e / rowlen, col = e - row * rowlen;
+            lds[row * pitch + col] = src[e];
+        }
+    }
+}
+
+__device__ __forceinline__ void stage_rows_out(float* __restrict__ dst, const float* lds,
+                                               int cnt, int rowlen) {
+    const int total = cnt * rowlen;
+    const int pitch = rowlen + 1;
+    if ((rowlen & 3) == 0) {
+        float4* d4 = reinterpret_cast<float4*>(dst);
+        for (int i = threadIdx.x; i < total / 4; i += blockDim.x) {
+            const int e = 4 * i, row = e / rowlen, col = e - row * rowlen;
+            const float* s = lds + row * pitch + col;
+            d4[i] = make_float4(s[0], s[1], s[2], s[3]);
+        }
+    } else {
+        for (int e = threadIdx.x; e < total; e += blockDim.x) {
+            const int row = e / rowlen, col = e - row * rowlen;
+            dst[e] = lds[row * pitch + col];
+        }
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+// K1: preprocess forward.  grid-stride over batches of blockDim.x Gaussians.
+// dynamic LDS: [hist: nTilesLds ints][sh stage: blockDim.x * (3K+1) floats if shs]
+// ---------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(256)
+gsr_preprocess_fwd(ViewConst vc, int N, int K,
+                   const float* __restrict__ means3D, const float* __restrict__ shs,
+                   const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
+                   const float* __restrict__ scales, const float* __restrict__ rotations,
+                   const float* __restrict__ cov3D_precomp,
+                   SplatRec* __restrict__ recs, EmitRec* __restrict__ emit,
+                   int32_t* __restrict__ radii, uint32_t* __restrict__ tile_count,
+                   unsigned long long* __restrict__ counters /*[0]=M_ref [1]=V*/,
+                   int hist_in_lds) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int nTiles = vc.gx * vc.gy;
+    uint32_t* hist = reinterpret_cast<uint32_t*>(smem_raw);
+    float* shbuf = reinterpret_cast<float*>(smem_raw + (hist_in_lds ? ((nTiles * 4 + 15) & ~15) : 0));
+    const int rowlen = 3 * K;
+    const bool stage = (shs != nullptr) && (K > 1);
+
+    if (hist_in_lds) {
+        for (int t = threadIdx.x; t < nTiles; t += blockDim.x) hist[t] = 0;
+    }
+    __syncthreads();
+
+    const float* __restrict__ V = vc.view;
+    const float* __restrict__ P = vc.proj;
+    unsigned long long my_ref = 0, my_vis = 0;
+
+    for (int base = blockIdx.x * blockDim.x; base < N; base += gridDim.x * blockDim.x) {
+        const int cnt = min((int)blockDim.x, N - base);
+        if (stage) {
+            __syncthreads();   // previous batch's readers are done
+            stage_rows_in(shs + (size_t)base * rowlen, shbuf, cnt, rowlen);
+            __syncthreads();
+        }
+        const int idx = base + threadIdx.x;
+        if (idx >= N) continue;
+
+        SplatRec rec;
+        rec.x = rec.y = rec.qa = rec.qb = rec.qc = rec.opac = rec.r = rec.g = rec.b = rec.depth = 0.f;
+        rec.id = (uint32_t)idx; rec.bbx = pack16(1, 0); rec.bby = pack16(1, 0);
+        rec.rectx = 0; rec.recty = 0; rec.flags = 0;
+        EmitRec em; em.rectx = 0; em.recty = 0; em.depth_bits = 0; em.pad = 0;
+        int32_t radius_out = 0;
+
+        const float mx = means3D[3 * idx], my = means3D[3 * idx + 1], mz = means3D[3 * idx + 2];
+        float3 pv;
+        pv.x = V[0] * mx + V[4] * my + V[8] * mz + V[12];
+        pv.y = V[1] * mx + V[5] * my + V[9] * mz + V[13];
+        pv.z = V[2] * mx + V[6] * my + V[10] * mz + V[14];
+        if (pv.z > 0.2f) {
+            const float hx = P[0] * mx + P[4] * my + P[8] * mz + P[12];
+            const float hy = P[1] * mx + P[5] * my + P[9] * mz + P[13];
+            const float hw = P[3] * mx + P[7] * my + P[11] * mz + P[15];
+            const float p_w = 1.0f / (hw + 0.0000001f);
+            const float ndcx = hx * p_w, ndcy = hy * p_w;
+
+            Cov3 S;
+            if (cov3D_precomp) {
+                const float* c = cov3D_precomp + 6 * (size_t)idx;
+                S.c0 = c[0]; S.c1 = c[1]; S.c2 = c[2]; S.c3 = c[3]; S.c4 = c[4]; S.c5 = c[5];
+            } else {
+                const float4 q = reinterpret_cast<const float4*>(rotations)[idx];
+                float3 s;
+                s.x = vc.scale_modifier * scales[3 * idx];
+                s.y = vc.scale_modifier * scales[3 * idx + 1];
+                s.z = vc.scale_modifier * scales[3 * idx + 2];
+                float R[9];
+                quat_to_R(q, R);
+                S = cov3d_from_scale_rot(s, R);
+            }
+            const Proj2D pj = project_cov(vc, V, pv, S);
+            const float det = pj.a * pj.c - pj.b * pj.b;
+            if (det != 0.f) {
+                const float det_inv = 1.f / det;
+                const float cA = pj.c * det_inv, cB = -pj.b * det_inv, cC = pj.a * det_inv;
+                const float mid = 0.5f * (pj.a + pj.c);
+                const float lam = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+                const float radius = ceilf(3.f * sqrtf(lam));
+                const float px = ((ndcx + 1.0f) * vc.W - 1.0f) * 0.5f;
+                const float py = ((ndcy + 1.0f) * vc.H - 1.0f) * 0.5f;
+                // reference tile rect (A.3)
+                const float fgx = (float)vc.gx, fgy = (float)vc.gy;
+                const int rx0 = (int)fminf(fgx, fmaxf(0.f, truncf((px - radius) / GSR_TILE)));
+                const int rx1 = (int)fminf(fgx, fmaxf(0.f, truncf((px + radius + (GSR_TILE - 1)) / GSR_TILE)));
+                const int ry0 = (int)fminf(fgy, fmaxf(0.f, truncf((py - radius) / GSR_TILE)));
+                const int ry1 = (int)fminf(fgy, fmaxf(0.f, truncf((py + radius + (GSR_TILE - 1)) / GSR_TILE)));
+                const int area_ref = (rx1 - rx0) * (ry1 - ry0);
+                if (area_ref > 0) {
+                    radius_out = (int32_t)radius;
+                    my_ref += (unsigned long long)area_ref;
+                    my_vis += 1;
+                    // colour
+                    float cr, cg, cb;
+                    uint32_t flags = 0;
+                    if (colors_precomp) {
+                        cr = colors_precomp[3 * idx]; cg = colors_precomp[3 * idx + 1]; cb = colors_precomp[3 * idx + 2];
+                    } else {
+                        float dx = mx - vc.campos[0], dy = my - vc.campos[1], dz = mz - vc.campos[2];
+                        const float inv = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
+                        dx *= inv; dy *= inv; dz *= inv;
+                        float B[16];
+                        sh_basis(vc.sh_degree, dx, dy, dz, B);
+                        const int nb = (vc.sh_degree + 1) * (vc.sh_degree + 1);
+                        const float* row = stage ? (shbuf + threadIdx.x * (rowlen + 1)) : (shs + (size_t)idx * rowlen);
+                        cr = cg = cb = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) {   // static indices: B[] stays in registers
+                            if (k < nb) { cr += B[k] * row[3 * k]; cg += B[k] * row[3 * k + 1]; cb += B[k] * row[3 * k + 2]; }
+                        }
+                        cr += 0.5f; cg += 0.5f; cb += 0.5f;
+                        if (cr < 0.f) { flags |= 1u; cr = 0.f; }
+                        if (cg < 0.f) { flags |= 2u; cg = 0.f; }
+                        if (cb < 0.f) { flags |= 4u; cb = 0.f; }
+                    }
+                    const float op = opacities[idx];
+                    rec.x = px; rec.y = py;
+                    rec.qa = -0.5f * cA * GSR_LOG2E; rec.qb = -cB * GSR_LOG2E; rec.qc = -0.5f * cC * GSR_LOG2E;
+                    rec.opac = op; rec.r = cr; rec.g = cg; rec.b = cb; rec.depth = pv.z;
+                    // Exact no-op culling: a pixel can only pass the alpha >= 1/255 test inside the
+                    // axis-aligned box |dx| <= sqrt(2 tau a), |dy| <= sqrt(2 tau c), tau = ln(255 o)
+                    // (a 0.2% safety margin dominates fp32 rounding of the in-kernel alpha).
+                    int ex0 = 0, ex1 = 0, ey0 = 0, ey1 = 0;
+                    const float tau = __logf(255.f * op);
+                    if (tau > 0.f) {
+                        const float hxw = sqrtf(2.f * tau * pj.a) * 1.002f + 0.01f;
+                        const float hyw = sqrtf(2.f * tau * pj.c) * 1.002f + 0.01f;
+                        const float bx0 = fminf(fmaxf(ceilf(px - hxw), -32768.f), 32767.f);
+                        const float bx1 = fminf(fmaxf(floorf(px + hxw), -32768.f), 32767.f);
+                        const float by0 = fminf(fmaxf(ceilf(py - hyw), -32768.f), 32767.f);
+                        const float by1 = fminf(fmaxf(floorf(py + hyw), -32768.f), 32767.f);
+                        const int ibx0 = (int)bx0, ibx1 = (int)bx1, iby0 = (int)by0, iby1 = (int)by1;
+                        rec.bbx = pack16(ibx0, ibx1); rec.bby = pack16(iby0, iby1);
+                        if (ibx1 >= 0 && iby1 >= 0 && ibx0 < vc.W && iby0 < vc.H && ibx0 <= ibx1 && iby0 <= iby1) {
+                            ex0 = max(rx0, max(ibx0, 0) / GSR_TILE);
+                            ex1 = min(rx1, min(ibx1, vc.W - 1) / GSR_TILE + 1);
+                            ey0 = max(ry0, max(iby0, 0) / GSR_TILE);
+                            ey1 = min(ry1, min(iby1, vc.H - 1) / GSR_TILE + 1);
+                        }
+                    }
+                    if (ex1 > ex0 && ey1 > ey0) {
+                        flags |= GSR_FLAG_EMIT;
+                        rec.rectx = pack16(ex0, ex1); rec.recty = pack16(ey0, ey1);
+                        em.rectx = rec.rectx; em.recty = rec.recty; em.depth_bits = __float_as_uint(pv.z);
+                        for (int ty = ey0; ty < ey1; ++ty)
+                            for (int tx = ex0; tx < ex1; ++tx) {
+                                const int t = ty * vc.gx + tx;
+                                if (hist_in_lds) atomicAdd(&hist[t], 1u);
+                                else atomicAdd(&tile_count[t], 1u);
+                            }
+                    }
+                    rec.flags = flags;
+                }
+            }
+        }
+        radii[idx] = radius_out;
+        reinterpret_cast<uint4*>(recs + idx)[0] = reinterpret_cast<uint4*>(&rec)[0];
+        reinterpret_cast<uint4*>(recs + idx)[1] = reinterpret_cast<uint4*>(&rec)[1];
+        reinterpret_cast<uint4*>(recs + idx)[2] = reinterpret_cast<uint4*>(&rec)[2];
+        reinterpret_cast<uint4*>(recs + idx)[3] = reinterpret_cast<uint4*>(&rec)[3];
+        reinterpret_cast<uint4*>(emit)[idx] = *reinterpret_cast<uint4*>(&em);
+    }
+
+    // statistics (wave-aggregated)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        my_ref += __shfl_xor(my_ref, off, 64);
+        my_vis += __shfl_xor(my_vis, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (my_ref) atomicAdd(&counters[0], my_ref);
+        if (my_vis) atomicAdd(&counters[1], my_vis);
+    }
+    if (hist_in_lds) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < nTiles; t += blockDim.x) {
+            const uint32_t c = hist[t];
+            if (c) atomicAdd(&tile_count[t], c);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// K6: preprocess backward.  Exact analytic gradient of K1; recomputes the
+// forward intermediates from the inputs instead of re-reading saved state.
+// dynamic LDS: blockDim.x * (3K+1) floats when shs (used for SH in, then dSH out).
+// ---------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(256)
+gsr_preprocess_bwd(ViewConst vc, int N, int K,
+                   const float* __restrict__ means3D, const float* __restrict__ shs,
+                   const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
+                   const float* __restrict__ scales, const float* __restrict__ rotations,
+                   const float* __restrict__ cov3D_precomp, const int32_t* __restrict__ radii,
+                   const SplatRec* __restrict__ recs, const float* __restrict__ g2d,
+                   float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
+                   float* __restrict__ dL_dshs, float* __restrict__ dL_dcolors,
+                   float* __restrict__ dL_dopac, float* __restrict__ dL_dscales,
+                   float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* shbuf = reinterpret_cast<float*>(smem_raw);
+    const int rowlen = 3 * K;
+    const bool use_sh = (shs != nullptr);
+    const bool stage = use_sh && (K > 1);
+    const float* __restrict__ V = vc.view;
+    const float* __restrict__ P = vc.proj;
+
+    for (int base = blockIdx.x * blockDim.x; base < N; base += gridDim.x * blockDim.x) {
+        const int cnt = min((int)blockDim.x, N - base);
+        if (stage) {
+            __syncthreads();
+            stage_rows_in(shs + (size_t)base * rowlen, shbuf, cnt, rowlen);
+            __syncthreads();
+        }
+        const int idx = base + threadIdx.x;
+        float dm[3] = {0.f, 0.f, 0.f};
+        float dm2[2] = {0.f, 0.f};
+        float dop = 0.f, dsc[3] = {0.f, 0.f, 0.f}, dq[4] = {0.f, 0.f, 0.f, 0.f};
+        float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float dcol[3] = {0.f, 0.f, 0.f};
+        float* myrow = shbuf + threadIdx.x * (rowlen + 1);
+        const bool live = (idx < N) && (radii[idx] > 0);
+
+        if (live) {
+            const float* g = g2d + (size_t)idx * GSR_G2D_STRIDE;
+            const uint32_t flags = recs[idx].flags;
+            const float mx = means3D[3 * idx], my = means3D[3 * idx + 1], mz = means3D[3 * idx + 2];
+            float3 pv;
+            pv.x = V[0] * mx + V[4] * my + V[8] * mz + V[12];
+            pv.y = V[1] * mx + V[5] * my + V[9] * mz + V[13];
+            pv.z = V[2] * mx + V[6] * my + V[10] * mz + V[14];
+            const float hx = P[0] * mx + P[4] * my + P[8] * mz + P[12];
+            const float hy = P[1] * mx + P[5] * my + P[9] * mz + P[13];
+            const float hw = P[3] * mx + P[7] * my + P[11] * mz + P[15];
+            const float m_w = 1.0f / (hw + 0.0000001f);
+
+            // ---- screen-space mean ------------------------------------------------------
+            const float gmx = g[0] * (GSR_LN2 * 0.5f * vc.W);   // dL/d ndc.x
+            const float gmy = g[1] * (GSR_LN2 * 0.5f * vc.H);
+            dm2[0] = gmx; dm2[1] = gmy;
+            const float mul1 = hx * m_w * m_w, mul2 = hy * m_w * m_w;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                dm[k] = (P[4 * k] * m_w - P[4 * k + 3] * mul1) * gmx + (P[4 * k + 1] * m_w - P[4 * k + 3] * mul2) * gmy;
+            // ---- depth ------------------------------------------------------------------
+            const float gdepth = g[9];
+            dm[0] += V[2] * gdepth; dm[1] += V[6] * gdepth; dm[2] += V[10] * gdepth;
+            // ---- opacity ----------------------------------------------------------------
+            dop = g[5];
+
+            // ---- colour -----------------------------------------------------------------
+            float gr = g[6], gg = g[7], gb = g[8];
+            if (!use_sh) {
+                dcol[0] = gr; dcol[1] = gg; dcol[2] = gb;
+            } else {
+                if (flags & 1u) gr = 0.f;
+                if (flags & 2u) gg = 0.f;
+                if (flags & 4u) gb = 0.f;
+                float dx = mx - vc.campos[0], dy = my - vc.campos[1], dz = mz - vc.campos[2];
+                const float len2 = dx * dx + dy * dy + dz * dz;
+                const float inv = 1.f / sqrtf(len2);
+                const float x = dx * inv, y = dy * inv, z = dz * inv;
+                const int deg = vc.sh_degree;
+                const int nb = (deg + 1) * (deg + 1);
+                float B[16];
+                sh_basis(deg, x, y, z, B);
+                const float* row = stage ? myrow : (shs + (size_t)idx * rowlen);
+                // direction derivative: dRGB/d(x,y,z) contracted with (gr,gg,gb)
+                float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+                if (deg > 0) {
+                    float s[16];   // s[k] = sh[k] . grad_rgb
+#pragma unroll
+                    for (int k = 1; k < 16; ++k)
+                        s[k] = (k < nb) ? (row[3 * k] * gr + row[3 * k + 1] * gg + row[3 * k + 2] * gb) : 0.f;
+                    ddx = -SH_C1 * s[3]; ddy = -SH_C1 * s[1]; ddz = SH_C1 * s[2];
+                    if (deg > 1) {
+                        const float xx = x * x, yy = y * y, zz = z * z;
+                        ddx += SH_C2_0 * y * s[4] + SH_C2_2 * (-2.f * x) * s[6] + SH_C2_3 * z * s[7] + SH_C2_4 * (2.f * x) * s[8];
+                        ddy += SH_C2_0 * x * s[4] + SH_C2_1 * z * s[5] + SH_C2_2 * (-2.f * y) * s[6] + SH_C2_4 * (-2.f * y) * s[8];
+                        ddz += SH_C2_1 * y * s[5] + SH_C2_2 * (4.f * z) * s[6] + SH_C2_3 * x * s[7];
+                        if (deg > 2) {
+                            ddx += SH_C3_0 * (6.f * x * y) * s[9] + SH_C3_1 * (y * z) * s[10] + SH_C3_2 * (-2.f * x * y) * s[11]
+                                 + SH_C3_3 * (-6.f * x * z) * s[12] + SH_C3_4 * (4.f * zz - 3.f * xx - yy) * s[13]
+                                 + SH_C3_5 * (2.f * x * z) * s[14] + SH_C3_6 * (3.f * xx - 3.f * yy) * s[15];
+                            ddy += SH_C3_0 * (3.f * xx - 3.f * yy) * s[9] + SH_C3_1 * (x * z) * s[10]
+                                 + SH_C3_2 * (4.f * zz - xx - 3.f * yy) * s[11] + SH_C3_3 * (-6.f * y * z) * s[12]
+                                 + SH_C3_4 * (-2.f * x * y) * s[13] + SH_C3_5 * (-2.f * y * z) * s[14]
+                                 + SH_C3_6 * (-6.f * x * y) * s[15];
+                            ddz += SH_C3_1 * (x * y) * s[10] + SH_C3_2 * (8.f * y * z) * s[11]
+                                 + SH_C3_3 * (6.f * zz - 3.f * xx - 3.f * yy) * s[12] + SH_C3_4 * (8.f * x * z) * s[13]
+                                 + SH_C3_5 * (xx - yy) * s[14];
+                        }
+                    }
+                    // through the normalisation: (I - d d^T)/|p| applied to (ddx,ddy,ddz)
+                    const float dot = x * ddx + y * ddy + z * ddz;
+                    dm[0] += (ddx - x * dot) * inv; dm[1] += (ddy - y * dot) * inv; dm[2] += (ddz - z * dot) * inv;
+                }
+                // dL/dSH: write this lane's row (the staged input row is dead now)
+                float* o = stage ? myrow : (dL_dshs + (size_t)idx * rowlen);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    if (k < K) {
+                        const float bk = (k < nb) ? B[k] : 0.f;
+                        o[3 * k] = bk * gr; o[3 * k + 1] = bk * gg; o[3 * k + 2] = bk * gb;
+                    }
+                }
+                for (int e = 48; e < rowlen; ++e) o[e] = 0.f;   // K > 16: inactive coefficients
+            }
+
+            // ---- conic -> cov2D -> (Sigma, t) -------------------------------------------
+            Cov3 S;
+            float R[9];
+            float3 s = make_float3(0.f, 0.f, 0.f);
+            float4 q = make_float4(1.f, 0.f, 0.f, 0.f);
+            if (cov3D_precomp) {
+                const float* c = cov3D_precomp + 6 * (size_t)idx;
+                S.c0 = c[0]; S.c1 = c[1]; S.c2 = c[2]; S.c3 = c[3]; S.c4 = c[4]; S.c5 = c[5];
+            } else {
+                q = reinterpret_cast<const float4*>(rotations)[idx];
+                s.x = vc.scale_modifier * scales[3 * idx];
+                s.y = vc.scale_modifier * scales[3 * idx + 1];
+                s.z = vc.scale_modifier * scales[3 * idx + 2];
+                quat_to_R(q, R);
+                S = cov3d_from_scale_rot(s, R);
+            }
+            const Proj2D pj = project_cov(vc, V, pv, S);
+            const float a = pj.a, b = pj.b, c = pj.c;
+            const float det = a * c - b * b;
+            const float d2i = 1.f / (det * det);
+            const float gA = g[2], gB = g[3], gC = g[4];
+            const float dLa = d2i * (-c * c * gA + b * c * gB - b * b * gC);
+            const float dLb = d2i * (2.f * b * c * gA - (a * c + b * b) * gB + 2.f * a * b * gC);
+            const float dLc = d2i * (-b * b * gA + a * b * gB - a * a * gC);
+
+            // G = dLa T0^T T0 + dLb sym(T0^T T1) + dLc T1^T T1   (gradient w.r.t. Sigma entries)
+            const float* T0 = pj.T0; const float* T1 = pj.T1;
+            float Gm[9];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    Gm[3 * i + j] = dLa * T0[i] * T0[j] + 0.5f * dLb * (T0[i] * T1[j] + T1[i] * T0[j]) + dLc * T1[i] * T1[j];
+            if (cov3D_precomp) {
+                dcov[0] = Gm[0]; dcov[1] = 2.f * Gm[1]; dcov[2] = 2.f * Gm[2];
+                dcov[3] = Gm[4]; dcov[4] = 2.f * Gm[5]; dcov[5] = Gm[8];
+            } else {
+                // Sigma = M M^T, M = R diag(s): dL/dM = 2 G M
+                float M[9], dM[9];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { M[3 * i] = R[3 * i] * s.x; M[3 * i + 1] = R[3 * i + 1] * s.y; M[3 * i + 2] = R[3 * i + 2] * s.z; }
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        dM[3 * i + j] = 2.f * (Gm[3 * i] * M[j] + Gm[3 * i + 1] * M[3 + j] + Gm[3 * i + 2] * M[6 + j]);
+                const float sv[3] = {s.x, s.y, s.z};
+                float dR[9];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    dsc[j] = vc.scale_modifier * (dM[j] * R[j] + dM[3 + j] * R[3 + j] + dM[6 + j] * R[6 + j]);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) dR[3 * i + j] = dM[3 * i + j] * sv[j];
+                }
+                const float r = q.x, x = q.y, y = q.z, z = q.w;
+                dq[0] = 2.f * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
+                dq[1] = 2.f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.f * x * dR[8]);
+                dq[2] = 2.f * (-2.f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.f * y * dR[8]);
+                dq[3] = 2.f * (-2.f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
+            }
+            // dL/dT rows: dT0 = 2 dLa Sigma T0 + dLb Sigma T1 ; dT1 = 2 dLc Sigma T1 + dLb Sigma T0
+            const float u0 = S.c0 * T0[0] + S.c1 * T0[1] + S.c2 * T0[2];
+            const float u1 = S.c1 * T0[0] + S.c3 * T0[1] + S.c4 * T0[2];
+            const float u2 = S.c2 * T0[0] + S.c4 * T0[1] + S.c5 * T0[2];
+            const float w0 = S.c0 * T1[0] + S.c1 * T1[1] + S.c2 * T1[2];
+            const float w1 = S.c1 * T1[0] + S.c3 * T1[1] + S.c4 * T1[2];
+            const float w2 = S.c2 * T1[0] + S.c4 * T1[1] + S.c5 * T1[2];
+            const float dT0[3] = {2.f * dLa * u0 + dLb * w0, 2.f * dLa * u1 + dLb * w1, 2.f * dLa * u2 + dLb * w2};
+            const float dT1[3] = {2.f * dLc * w0 + dLb * u0, 2.f * dLc * w1 + dLb * u1, 2.f * dLc * w2 + dLb * u2};
+            // T = J Wr, Wr[i][k] = V[4k+i]:  dJ[r][i] = sum_k dT[r][k] * V[4k+i]
+            float dJ00 = 0.f, dJ02 = 0.f, dJ11 = 0.f, dJ12 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                dJ00 += dT0[k] * V[4 * k + 0]; dJ02 += dT0[k] * V[4 * k + 2];
+                dJ11 += dT1[k] * V[4 * k + 1]; dJ12 += dT1[k] * V[4 * k + 2];
+            }
+            const float tz = 1.f / pj.tz, tz2 = tz * tz, tz3 = tz2 * tz;
+            const float dtx = pj.clampx ? 0.f : -vc.focal_x * tz2 * dJ02;
+            const float dty = pj.clampy ? 0.f : -vc.focal_y * tz2 * dJ12;
+            const float dtz = -vc.focal_x * tz2 * dJ00 - vc.focal_y * tz2 * dJ11
+                            + (2.f * vc.focal_x * pj.tx) * tz3 * dJ02 + (2.f * vc.focal_y * pj.ty) * tz3 * dJ12;
+            // t_i = sum_k m_k V[4k+i]
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dm[k] += V[4 * k] * dtx + V[4 * k + 1] * dty + V[4 * k + 2] * dtz;
+        } else if (idx < N && use_sh) {
+            if (stage) { for (int e = 0; e < rowlen; ++e) myrow[e] = 0.f; }
+            else { float* o = dL_dshs + (size_t)idx * rowlen; for (int e = 0; e < rowlen; ++e) o[e] = 0.f; }
+        }
+
+        if (idx < N) {
+            dL_dmeans3D[3 * idx] = dm[0]; dL_dmeans3D[3 * idx + 1] = dm[1]; dL_dmeans3D[3 * idx + 2] = dm[2];
+            dL_dmeans2D[3 * idx] = dm2[0]; dL_dmeans2D[3 * idx + 1] = dm2[1]; dL_dmeans2D[3 * idx + 2] = 0.f;
+            dL_dopac[idx] = dop;
+            if (dL_dcolors) { dL_dcolors[3 * idx] = dcol[0]; dL_dcolors[3 * idx + 1] = dcol[1]; dL_dcolors[3 * idx + 2] = dcol[2]; }
+            if (dL_dcov3D) {
+#pragma unroll
+                for (int e = 0; e < 6; ++e) dL_dcov3D[6 * (size_t)idx + e] = dcov[e];
+            }
+            if (dL_dscales) { dL_dscales[3 * idx] = dsc[0]; dL_dscales[3 * idx + 1] = dsc[1]; dL_dscales[3 * idx + 2] = dsc[2]; }
+            if (dL_drots) reinterpret_cast<float4*>(dL_drots)[idx] = make_float4(dq[0], dq[1], dq[2], dq[3]);
+        }
+        if (stage) {
+            __syncthreads();
+            stage_rows_out(dL_dshs + (size_t)base * rowlen, shbuf, cnt, rowlen);
+        }
+    }
+}
+
+// visible[i] = view-space z > 0.2  (frustum rule of A.3)
+extern "C" __global__ void __launch_bounds__(256)
+gsr_mark_visible_kernel(const float* __restrict__ V, int N, const float* __restrict__ means3D,
+                        uint8_t* __restrict__ visible) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N) return;
+    const float z = V[2] * means3D[3 * idx] + V[6] * means3D[3 * idx + 1] + V[10] * means3D[3 * idx + 2] + V[14];
+    visible[idx] = z > 0.2f ? 1 : 0;
+}

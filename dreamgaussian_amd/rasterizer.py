@@ -1,0 +1,215 @@
+"""Host-side mirror of the `diff_gaussian_rasterization` surface DreamGaussian uses.
+
+Same names, argument meaning and error behaviour as the external package the reference
+imports at gs_renderer.py:10-13 and calls at gs_renderer.py:745-760, 800-809:
+`GaussianRasterizationSettings` (12-field NamedTuple), `GaussianRasterizer(raster_settings=)`
+whose call returns `(color[3,H,W], radii[N] int32, depth[1,H,W], alpha[1,H,W])`, and an
+autograd.Function whose backward returns gradients positionally for
+`means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp`.
+
+All arithmetic runs in the hand-written HIP kernels of libgsr.so (include/gsr.h) on the
+tensors' device and torch's current stream; torch is used for memory, streams and autograd
+plumbing only. There is no CPU path: CPU tensors raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import torch
+from torch import nn
+
+from . import _lib
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+_last_stats = {}
+
+
+def last_stats() -> dict:
+    """Scene statistics of the most recent forward (V, M of SURVEY 8(d))."""
+    return dict(_last_stats)
+
+
+def _f32c(t: Optional[torch.Tensor], device) -> Optional[torch.Tensor]:
+    if t is None or t.numel() == 0:
+        return None
+    if t.device != device:
+        raise RuntimeError(f"all rasterizer inputs must be on {device}, got {t.device}")
+    return t.detach().to(torch.float32).contiguous()
+
+
+def _view_struct(rs: GaussianRasterizationSettings, device):
+    keep = [torch.as_tensor(x).to(device=device, dtype=torch.float32).contiguous().reshape(-1)
+            for x in (rs.bg, rs.viewmatrix, rs.projmatrix, rs.campos)]
+    if keep[0].numel() != 3 or keep[1].numel() != 16 or keep[2].numel() != 16 or keep[3].numel() != 3:
+        raise RuntimeError("bg/campos must have 3 elements and viewmatrix/projmatrix 16")
+    v = _lib.GsrView(int(rs.image_height), int(rs.image_width), float(rs.tanfovx),
+                     float(rs.tanfovy), float(rs.scale_modifier), int(rs.sh_degree),
+                     int(bool(rs.prefiltered)), int(bool(rs.debug)),
+                     keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(), keep[3].data_ptr())
+    return v, keep
+
+
+def _require_gpu(t: torch.Tensor):
+    if t.device.type != "cuda":
+        raise RuntimeError(
+            "dreamgaussian_amd rasterizer runs on an MI355X (torch device 'cuda' on ROCm) only; "
+            f"got a tensor on '{t.device}'. There is no CPU fallback.")
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                cov3Ds_precomp, raster_settings):
+        _require_gpu(means3D)
+        lib = _lib.load()
+        dev = means3D.device
+        rs = raster_settings
+        H, W = int(rs.image_height), int(rs.image_width)
+        m3 = _f32c(means3D, dev)
+        N = int(means3D.shape[0])
+        if N > 0 and (means3D.dim() != 2 or means3D.shape[1] != 3):
+            raise RuntimeError("means3D must have dimensions (num_points, 3)")
+        shc = _f32c(sh, dev)
+        col = _f32c(colors_precomp, dev)
+        op = _f32c(opacities, dev)
+        sc = _f32c(scales, dev)
+        rot = _f32c(rotations, dev)
+        cov = _f32c(cov3Ds_precomp, dev)
+        K = int(shc.shape[1]) if shc is not None else 0
+        if shc is not None and (shc.dim() != 3 or shc.shape[0] != N or shc.shape[2] != 3):
+            raise RuntimeError("shs must have dimensions (num_points, num_coeffs, 3)")
+
+        color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+        depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+        alpha = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+        radii = torch.zeros(N, dtype=torch.int32, device=dev)
+        geom, binb, img = _lib.Scratch(dev), _lib.Scratch(dev), _lib.Scratch(dev)
+        stats = _lib.GsrStats()
+        with torch.cuda.device(dev):
+            view, keep = _view_struct(rs, dev)
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            rc = lib.gsr_forward(C.byref(view), N, K, _lib.ptr(m3), _lib.ptr(shc), _lib.ptr(col),
+                                 _lib.ptr(op), _lib.ptr(sc), _lib.ptr(rot), _lib.ptr(cov),
+                                 _lib.ptr(color), _lib.ptr(depth), _lib.ptr(alpha), _lib.ptr(radii),
+                                 geom.alloc, binb.alloc, img.alloc, C.byref(stats), stream)
+        _lib.check(rc, "gsr_forward")
+        _last_stats.update(M=stats.num_instances, M_ref=stats.num_instances_ref,
+                           V=stats.num_visible, max_tile=stats.max_tile_count, N=N, H=H, W=W, K=K)
+        ctx.raster_settings = rs
+        ctx.dims = (N, K)
+        ctx.present = (shc is not None, col is not None, sc is not None, cov is not None)
+        empty = torch.empty(0, device=dev)
+        ctx.save_for_backward(m3, shc if shc is not None else empty, col if col is not None else empty,
+                              op if op is not None else empty, sc if sc is not None else empty,
+                              rot if rot is not None else empty, cov if cov is not None else empty,
+                              radii, geom.tensor, binb.tensor, img.tensor)
+        ctx.shapes = (means3D.shape, means2D.shape, None if sh is None else sh.shape,
+                      None if colors_precomp is None else colors_precomp.shape, opacities.shape,
+                      None if scales is None else scales.shape,
+                      None if rotations is None else rotations.shape,
+                      None if cov3Ds_precomp is None else cov3Ds_precomp.shape)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, depth, alpha
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
+        lib = _lib.load()
+        (m3, shc, col, op, sc, rot, cov, radii, geom, binb, img) = ctx.saved_tensors
+        has_sh, has_col, has_sr, has_cov = ctx.present
+        N, K = ctx.dims
+        rs = ctx.raster_settings
+        dev = m3.device
+        H, W = int(rs.image_height), int(rs.image_width)
+        z = lambda g, shape: (torch.zeros(shape, dtype=torch.float32, device=dev) if g is None
+                              else g.to(torch.float32).contiguous())
+        gc, gd, ga = z(grad_color, (3, H, W)), z(grad_depth, (1, H, W)), z(grad_alpha, (1, H, W))
+        f = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        d_m3, d_m2, d_op = f(N, 3), f(N, 3), f(N, 1)
+        d_sh = f(N, K, 3) if has_sh else None
+        d_col = f(N, 3) if has_col else None
+        d_sc = f(N, 3) if has_sr else None
+        d_rot = f(N, 4) if has_sr else None
+        d_cov = f(N, 6) if has_cov else None
+        if N > 0:
+            tmp = _lib.Scratch(dev)
+            with torch.cuda.device(dev):
+                view, keep = _view_struct(rs, dev)
+                stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+                P = _lib.ptr
+                rc = lib.gsr_backward(
+                    C.byref(view), N, K, P(m3), P(shc) if has_sh else None, P(col) if has_col else None,
+                    P(op), P(sc) if has_sr else None, P(rot) if has_sr else None,
+                    P(cov) if has_cov else None, P(radii), P(gc), P(gd), P(ga),
+                    P(geom), P(binb), P(img), P(d_m3), P(d_m2), P(d_sh), P(d_col), P(d_op),
+                    P(d_sc), P(d_rot), P(d_cov), tmp.alloc, stream)
+            _lib.check(rc, "gsr_backward")
+        s = ctx.shapes
+        rs_ = lambda g, shape: None if g is None or shape is None else g.reshape(shape)
+        return (rs_(d_m3, s[0]), rs_(d_m2, s[1]) if tuple(s[1]) == (N, 3) else None, rs_(d_sh, s[2]),
+                rs_(d_col, s[3]), rs_(d_op, s[4]), rs_(d_sc, s[5]), rs_(d_rot, s[6]), rs_(d_cov, s[7]),
+                None)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                        cov3Ds_precomp, raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales,
+                                     rotations, cov3Ds_precomp, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """Boolean [N]: passes the frustum rule (view-space z > 0.2)."""
+        _require_gpu(positions)
+        lib = _lib.load()
+        dev = positions.device
+        pos = _f32c(positions, dev)
+        N = int(positions.shape[0])
+        vis = torch.zeros(N, dtype=torch.uint8, device=dev)
+        with torch.no_grad(), torch.cuda.device(dev):
+            view, keep = _view_struct(self.raster_settings, dev)
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            rc = lib.gsr_mark_visible(C.byref(view), N, _lib.ptr(pos), _lib.ptr(vis), stream)
+        _lib.check(rc, "gsr_mark_visible")
+        return vis.bool()
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None,
+                rotations=None, cov3D_precomp=None):
+        raster_settings = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        empty = torch.Tensor([]).to(means3D.device)
+        if shs is None:
+            shs = empty
+        if colors_precomp is None:
+            colors_precomp = empty
+        if scales is None:
+            scales = empty
+        if rotations is None:
+            rotations = empty
+        if cov3D_precomp is None:
+            cov3D_precomp = empty
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales,
+                                   rotations, cov3D_precomp, raster_settings)

@@ -1,0 +1,123 @@
+/* gsr.h -- C ABI of libgsr.so, the MI355X (gfx950) Gaussian-splat rasterizer.
+ *
+ * This is the drop-in boundary for the one hot path of DreamGaussian that this repository
+ * replaces: the differentiable rasterizer behind gs_renderer.Renderer.render and the
+ * simple-knn distCUDA2 initialiser.  Plain pointers and sizes only -- no torch types.
+ * All pointers are DEVICE pointers to contiguous fp32 / int32 data unless marked [host].
+ * Every call is asynchronous on `stream` except where stated; nothing here calls
+ * hipMalloc: scratch memory is obtained from the caller through GsrAlloc callbacks
+ * (the torch caching allocator in the Python host side), the same ownership model as the
+ * reference extension's resize lambdas.
+ *
+ * Reference interfaces each entry point replaces (file:line in /root/reference):
+ *   gsr_forward       <- GaussianRasterizer(raster_settings)(means3D, means2D, shs, ...)
+ *                        gs_renderer.py:760,800-809  (ext: _C.rasterize_gaussians)
+ *   gsr_backward      <- loss.backward() through that call, main.py:273
+ *                        (ext: _C.rasterize_gaussians_backward)
+ *   gsr_mark_visible  <- GaussianRasterizer.markVisible (ext: _C.mark_visible; never called
+ *                        by DreamGaussian, kept for surface completeness)
+ *   gsr_dist2         <- simple_knn._C.distCUDA2(points), gs_renderer.py:341;
+ *                        simple-knn/spatial.cu:15-26, simple_knn.cu:185-221
+ */
+#ifndef GSR_H
+#define GSR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* hipStream_t without dragging hip headers into C callers */
+typedef void* gsr_stream_t;
+
+/* Per-view constants: the 12 fields of GaussianRasterizationSettings
+ * (gs_renderer.py:745-758). Matrices are in the reference's transposed/row-vector layout:
+ * x' = m[0]*x + m[4]*y + m[8]*z + m[12]  (gs_renderer.py:662-670). */
+typedef struct GsrView {
+    int32_t image_height;
+    int32_t image_width;
+    float tanfovx;
+    float tanfovy;
+    float scale_modifier;
+    int32_t sh_degree;       /* ACTIVE degree, 0..3 */
+    int32_t prefiltered;     /* accepted, ignored (reference passes False) */
+    int32_t debug;           /* !=0: synchronise + check after every launch */
+    const float* bg;         /* [3]  device */
+    const float* viewmatrix; /* [16] device */
+    const float* projmatrix; /* [16] device */
+    const float* campos;     /* [3]  device */
+} GsrView;
+
+/* Scratch allocator: resize(ctx, bytes) must return a device pointer, 256-byte aligned, to
+ * at least `bytes` bytes that stay alive until the matching backward has run. */
+typedef void* (*GsrResizeFn)(void* ctx, size_t bytes);
+typedef struct GsrAlloc {
+    void* ctx;
+    GsrResizeFn resize;
+} GsrAlloc;
+
+/* Statistics of the last forward on this thread (scene statistics V and M of SURVEY 8(d)). */
+typedef struct GsrStats {
+    int64_t num_instances;      /* M_emit: (tile,Gaussian) pairs actually binned */
+    int64_t num_instances_ref;  /* M: pairs under the reference's 3-sigma rect rule */
+    int64_t num_visible;        /* V: Gaussians with radii > 0 */
+    int64_t max_tile_count;     /* longest per-tile list */
+} GsrStats;
+
+/* Forward.
+ *   N                number of Gaussians; K = shs.shape[1] (max coefficients per Gaussian)
+ *   means3D [N,3]    shs [N,K,3] or NULL    colors_precomp [N,3] or NULL (exactly one)
+ *   opacities [N]    scales [N,3] + rotations [N,4] (r,x,y,z) or cov3D_precomp [N,6]
+ *   out_color [3,H,W] out_depth [H,W] out_alpha [H,W] radii [N] int32
+ *   geom/bin/img     scratch; the three buffers must be kept and handed to gsr_backward
+ *   stats            [host] optional
+ * Blocks the host once (until the per-tile counts are known) like the reference ext does.
+ * Returns 0, or a negative code with gsr_last_error() set. N==0 renders the background. */
+int gsr_forward(const GsrView* view, int32_t N, int32_t K,
+                const float* means3D, const float* shs, const float* colors_precomp,
+                const float* opacities, const float* scales, const float* rotations,
+                const float* cov3D_precomp,
+                float* out_color, float* out_depth, float* out_alpha, int32_t* radii,
+                GsrAlloc geom, GsrAlloc bin, GsrAlloc img,
+                GsrStats* stats, gsr_stream_t stream);
+
+/* Backward. Same inputs as the forward plus the incoming gradients
+ *   dL_dcolor [3,H,W]  dL_ddepth [H,W]  dL_dalpha [H,W]
+ * and the three scratch buffers of the matching forward. Outputs (dense, exact zeros for
+ * culled Gaussians; a NULL output is skipped where that is meaningful):
+ *   dL_dmeans3D [N,3]  dL_dmeans2D [N,3] (x,y in NDC units = pixel grad * 0.5*(W,H); z=0)
+ *   dL_dshs [N,K,3] | dL_dcolors [N,3]   dL_dopacities [N]
+ *   dL_dscales [N,3] + dL_drotations [N,4] | dL_dcov3D [N,6]
+ *   tmp               scratch for the per-Gaussian screen-space gradient accumulators */
+int gsr_backward(const GsrView* view, int32_t N, int32_t K,
+                 const float* means3D, const float* shs, const float* colors_precomp,
+                 const float* opacities, const float* scales, const float* rotations,
+                 const float* cov3D_precomp, const int32_t* radii,
+                 const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
+                 const void* geom, const void* bin, const void* img,
+                 float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs, float* dL_dcolors,
+                 float* dL_dopacities, float* dL_dscales, float* dL_drotations,
+                 float* dL_dcov3D, GsrAlloc tmp, gsr_stream_t stream);
+
+/* Frustum test only: visible[i] = (view-space z of means3D[i] > 0.2). */
+int gsr_mark_visible(const GsrView* view, int32_t N, const float* means3D,
+                     uint8_t* visible, gsr_stream_t stream);
+
+/* distCUDA2: out[i] = mean of the squared distances from point i to its 3 nearest
+ * neighbours (self excluded by index; fewer than 3 neighbours count as FLT_MAX each,
+ * as in simple_knn.cu:142-182). points [P,3], out [P]. No host synchronisation. */
+int gsr_dist2(int32_t P, const float* points, float* out, GsrAlloc tmp, gsr_stream_t stream);
+
+/* Bytes of scratch the forward will request for geom / img (bin is data dependent). */
+size_t gsr_geom_bytes(int32_t N, int32_t image_height, int32_t image_width);
+size_t gsr_img_bytes(int32_t image_height, int32_t image_width);
+
+const char* gsr_last_error(void);
+const char* gsr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSR_H */
