@@ -1,0 +1,270 @@
+#!/usr/bin/env python
+"""bench.py -- Mrays/s (fwd+bwd) of the MI355X splat rasterizer on BASELINE.json's workloads.
+
+  python bench.py [--gpus N --steps K --warmup W] [--workload 1M-800-sh3] [--kind blob]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one forward + one backward of the rasterizer (through the drop-in
+`GaussianRasterizer` autograd surface, i.e. the path gs_renderer.py:800-809 / main.py:273
+take) for ONE camera over the synthetic scene, inputs and dL/d{color,depth,alpha} already
+resident in HBM. With N>1 every rank renders its own orbit camera of the same (replicated)
+scene -- the view-parallel mode of SURVEY 8(e) -- and rank 0 gathers the N images with RCCL
+inside the timed region; per-GPU work is fixed ("weak" scaling), value = total rays / time.
+
+One JSON line on stdout (rank 0). Besides the driver's contract it carries
+  roofline      the dominant kernel's algorithmic bytes / its hipEvent-measured duration
+  path_roofline the same for the whole fwd+bwd (B_alg of SURVEY 8(d) / step time)
+  cpu_baseline  the CPU oracle (oracle/gs_oracle.py, a port: the reference has no CPU render
+                path and its CUDA ext is absent) timed on a bounded sample on the host cores
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level table)
+
+WORKLOADS = {                  # BASELINE.json configs (index): N, sh degree, W, H
+    "5k-256-sh0": dict(cfg=0, N=5_000, deg=0, W=256, H=256),
+    "100k-800-sh3": dict(cfg=1, N=100_000, deg=3, W=800, H=800),
+    "1M-800-sh3": dict(cfg=2, N=1_000_000, deg=3, W=800, H=800),
+    "250k-512-sh0": dict(cfg=3, N=250_000, deg=0, W=512, H=512),
+}
+
+
+def alg_bytes(N, K, V, M, P):
+    """Algorithmic (compulsory) HBM bytes of SURVEY 8(d), split per kernel so that the parts
+    add up to B_alg(fwd+bwd) = N(3 A_in + 16) + 212 V + 24 M + 56 P."""
+    A_in = 44 + 12 * K
+    per = {
+        "preprocess_fwd": N * (A_in + 4) + 44 * V,      # inputs read, radii + 44 B state written
+        "scatter": 8 * M,                               # (depth,id) entries written
+        "tile_sort": 8 * M,                             # ... read back by the sort
+        "render_fwd": 44 * V + 28 * P,                  # state read, 20 B out + 8 B aux per pixel
+        "render_bwd": 84 * V + 8 * M + 28 * P,          # state read, 40 B 2D grads, lists, pixel grads
+        "preprocess_bwd": N * (2 * A_in + 12) + 40 * V, # inputs re-read, grads written, 2D grads read
+    }
+    per["total"] = sum(per.values())
+    assert per["total"] == N * (3 * A_in + 16) + 212 * V + 24 * M + 56 * P
+    return per
+
+
+def kernel_family(name: str) -> str:
+    return "tile_sort" if name.startswith("tile_sort") else name
+
+
+def build_inputs(wl, kind, dev, azimuth):
+    from dreamgaussian_amd import synthetic as syn
+    import dreamgaussian_amd as D
+    sc = syn.make_scene(wl["N"], wl["deg"], 0, kind)
+    rs_cpu = syn.make_settings(syn.orbit_pose(0.0, azimuth, 2.0), wl["W"], wl["H"], sh_degree=wl["deg"])
+    rs = D.GaussianRasterizationSettings(*[x.to(dev) if torch.is_tensor(x) else x for x in rs_cpu])
+    g = torch.Generator().manual_seed(1)
+    H, W = wl["H"], wl["W"]
+    grads = [torch.rand(3, H, W, generator=g), torch.rand(1, H, W, generator=g), torch.rand(1, H, W, generator=g)]
+    return sc, rs_cpu, rs, grads
+
+
+def cpu_baseline(sc, rs_cpu, grads, budget_s=15.0):
+    """CPU oracle on a bounded sample of the SAME scene/camera/loss: per-Gaussian stage and
+    binning in full, compositing fwd+bwd on a strided subset of the non-empty 16x16 tiles
+    sized to ~budget_s; whole-frame time estimated by scaling the composite time with the
+    (instance x pixel) pair count. kind 'port': the reference has no CPU path."""
+    from oracle import gs_oracle as O
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    S = O.Settings(*rs_cpu)
+    H, W = int(S.image_height), int(S.image_width)
+
+    def leaves():
+        t = {k: v.detach().clone().requires_grad_(True) for k, v in sc.items()}
+        return t
+
+    def run(tiles):
+        t = leaves()
+        t0 = time.perf_counter()
+        c, r, d, a, aux = O.rasterize(t["means3D"], None, t["opacities"], S, shs=t["shs"],
+                                      scales=t["scales"], rotations=t["rotations"],
+                                      return_aux=True, tiles=tiles)
+        torch.autograd.backward([c, d, a], grads)
+        return time.perf_counter() - t0, aux
+
+    # pass 0: no tiles -> cost of the per-Gaussian stage + binning (+ their backward)
+    t_pg, aux = run([])
+    ranges = aux["ranges"]
+    cnt = ranges[1:] - ranges[:-1]
+    nonempty = [int(t) for t in range(len(cnt)) if cnt[t] > 0]
+    total_pairs = float(cnt.sum()) * 256.0
+    if not nonempty:
+        return dict(value=H * W / t_pg / 1e6, unit="Mrays/s", cores=ncores, kind="port",
+                    sample="empty scene")
+    # calibrate on 2 tiles, then pick the stride that fits the budget
+    probe = nonempty[:: max(1, len(nonempty) // 2)][:2]
+    t_probe, _ = run(probe)
+    per_pair = max(t_probe - t_pg, 1e-4) / (float(sum(cnt[t] for t in probe)) * 256.0)
+    want_pairs = budget_s / per_pair
+    stride = max(1, int(round(total_pairs / want_pairs)))
+    tiles = nonempty[::stride]
+    t_s, _ = run(tiles)
+    pairs_s = float(sum(cnt[t] for t in tiles)) * 256.0
+    t_comp = max(t_s - t_pg, 1e-6)
+    t_full = t_pg + t_comp * total_pairs / pairs_s
+    return dict(value=H * W / t_full / 1e6, unit="Mrays/s", cores=ncores, kind="port",
+                sample=(f"oracle fwd+bwd, same scene/camera/loss: per-Gaussian stage + binning in full "
+                        f"({t_pg:.1f} s), compositing on {len(tiles)} of {len(nonempty)} non-empty tiles "
+                        f"({100.0 * pairs_s / total_pairs:.1f}% of instance-pixel pairs, {t_comp:.1f} s), "
+                        f"frame time scaled by pair count to {t_full:.0f} s"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="1M-800-sh3", choices=sorted(WORKLOADS))
+    ap.add_argument("--kind", default="blob", choices=["blob", "trained"])
+    ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-oracle compositing; 0 disables")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import dreamgaussian_amd as D
+    from dreamgaussian_amd import _lib, views
+
+    wl = WORKLOADS[a.workload]
+    K = (wl["deg"] + 1) ** 2
+    azimuth = 360.0 * rank / max(world, 1)          # rank r renders orbit view r
+    sc, rs_cpu, rs, grads_cpu = build_inputs(wl, a.kind, dev, azimuth)
+    t = {k: v.to(dev).requires_grad_(True) for k, v in sc.items()}
+    m2d = torch.zeros(wl["N"], 3, device=dev, requires_grad=True)
+    gout = [g.to(dev) for g in grads_cpu]
+    rast = D.GaussianRasterizer(raster_settings=rs)
+    gather_buf = views.make_gather_buffer(world, 5, wl["H"], wl["W"], dev) if world > 1 else None
+
+    def step():
+        for v in t.values():
+            v.grad = None
+        m2d.grad = None
+        color, radii, depth, alpha = rast(means3D=t["means3D"], means2D=m2d, shs=t["shs"],
+                                          colors_precomp=None, opacities=t["opacities"],
+                                          scales=t["scales"], rotations=t["rotations"],
+                                          cov3D_precomp=None)
+        work = None
+        if world > 1:                                # RCCL gather of the rendered views to rank 0
+            work = views.gather_views_async(color, depth, alpha, gather_buf, dst=0)
+        torch.autograd.backward([color, depth, alpha], gout)
+        if work is not None:
+            work.wait()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        td = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(td, op=dist.ReduceOp.MAX)
+        dt = float(td.item())
+    st = D.last_stats()
+
+    # ---- per-kernel durations: hipEvents around every launch, same workload, K more steps ----
+    kern, roof, path_roof, dt_prof = {}, None, None, None
+    if not a.no_roofline and rank == 0:
+        _lib.profile_reset()
+        _lib.profile_enable(True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        torch.cuda.synchronize()
+        dt_prof = time.perf_counter() - t1
+        _lib.profile_enable(False)
+        raw = _lib.profile_read()
+        for name, (ms, n) in raw.items():
+            fam = kernel_family(name)
+            e = kern.setdefault(fam, [0.0, 0])
+            e[0] += ms
+            e[1] = max(e[1], n)
+        P = wl["H"] * wl["W"]
+        ab = alg_bytes(wl["N"], K, st["V"], st["M_ref"], P)
+        per_step = {k: v[0] / a.steps for k, v in kern.items()}
+        dom = max(per_step, key=per_step.get)
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get(f"{a.workload}/{a.kind}", {}).get(dom)
+            except Exception:
+                traffic = None
+        if dom in ab:
+            ach = ab[dom] / (per_step[dom] * 1e-3) / 1e9
+            roof = dict(bound="hbm", kernel=dom, achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(ach / HBM_PEAK_GBS, 5), traffic=traffic,
+                        alg_bytes_per_launch=ab[dom], avg_launch_ms=round(per_step[dom], 4),
+                        launches_per_step=1)
+        ach_p = ab["total"] / (dt / a.steps) / 1e9
+        path_roof = dict(bound="hbm", achieved=round(ach_p, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                         frac=round(ach_p / HBM_PEAK_GBS, 5), alg_bytes_per_step=ab["total"],
+                         gpu_kernel_ms_per_step=round(sum(per_step.values()), 4))
+    if world > 1:
+        dist.barrier()
+
+    cpu = None
+    if rank == 0 and world == 1 and a.cpu_budget > 0:
+        cpu = cpu_baseline(sc, rs_cpu, grads_cpu, a.cpu_budget)
+        cpu["value"] = round(cpu["value"], 5)
+
+    if rank == 0:
+        rays = wl["H"] * wl["W"] * world * a.steps
+        out = {
+            "metric": "Mrays/s (fwd+bwd)", "value": round(rays / dt / 1e6, 3), "unit": "Mrays/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[{wl['cfg']}]: {wl['N']} Gaussians, SH degree "
+                                   f"{wl['deg']}, {wl['W']}x{wl['H']}, fwd+bwd, scene '{a.kind}' seed 0, "
+                                   f"orbit camera r=2 fovy=49.1",
+                       "views_per_step": world, "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU",
+                       "N": wl["N"], "K": K, "V": st["V"], "M": st["M_ref"], "M_emitted": st["M"],
+                       "max_tile_list": st["max_tile"]},
+            "roofline": roof, "path_roofline": path_roof, "cpu_baseline": cpu,
+            "kernels_ms_per_step": {k: round(v[0] / a.steps, 4) for k, v in sorted(kern.items())},
+            "ms_per_step_with_events": None if dt_prof is None else round(dt_prof / a.steps * 1e3, 4),
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgsr.so")
 
 EXPORTS = ("gsr_forward", "gsr_backward", "gsr_mark_visible", "gsr_dist2",
+           "gsr_profile_enable", "gsr_profile_read", "gsr_profile_reset",
            "gsr_geom_bytes", "gsr_img_bytes", "gsr_last_error", "gsr_version")
 
 
@@ -69,6 +70,13 @@ def load() -> C.CDLL:
         lib.gsr_geom_bytes.argtypes = [i32, i32, i32]
         lib.gsr_img_bytes.restype = C.c_size_t
         lib.gsr_img_bytes.argtypes = [i32, i32]
+        lib.gsr_profile_enable.restype = C.c_int
+        lib.gsr_profile_enable.argtypes = [C.c_int]
+        lib.gsr_profile_reset.restype = C.c_int
+        lib.gsr_profile_reset.argtypes = []
+        lib.gsr_profile_read.restype = C.c_int
+        lib.gsr_profile_read.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float),
+                                         C.POINTER(C.c_int)]
         lib.gsr_last_error.restype = C.c_char_p
         lib.gsr_version.restype = C.c_char_p
         _lib = lib
@@ -101,3 +109,21 @@ def check(rc: int, what: str):
     if rc != 0:
         msg = load().gsr_last_error().decode(errors="replace")
         raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def profile_enable(on: bool):
+    """Bracket every kernel of the calling thread's gsr_* calls with hipEvents (bench.py)."""
+    load().gsr_profile_enable(1 if on else 0)
+
+
+def profile_reset():
+    load().gsr_profile_reset()
+
+
+def profile_read(cap: int = 64) -> dict:
+    """{kernel name: (total ms, launches)} since the last reset; waits for the events."""
+    names = (C.c_char_p * cap)()
+    ms = (C.c_float * cap)()
+    cnt = (C.c_int * cap)()
+    n = load().gsr_profile_read(cap, names, ms, cnt)
+    return {names[i].decode(): (float(ms[i]), int(cnt[i])) for i in range(n)}

@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <math.h>
+#include <vector>
 
 namespace {
 
@@ -28,7 +29,39 @@ int fail(int code, const char* fmt, const char* a = "", long long b = 0) {
         if (e_ != hipSuccess) return fail(-2, "HIP error '%s' at line %lld: " #expr, hipGetErrorString(e_), __LINE__); \
     } while (0)
 
+// ---- per-kernel timing (gsr_profile_*): hipEvent pairs on the caller's stream ------------
+struct ProfPending { const char* name; hipEvent_t start, stop; };
+struct ProfRow { const char* name; double ms; int launches; };
+struct ProfState {
+    bool on = false;
+    hipEvent_t cur = nullptr;
+    std::vector<hipEvent_t> pool;
+    std::vector<ProfPending> pending;
+    std::vector<ProfRow> rows;
+    hipEvent_t get() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        return e;
+    }
+};
+thread_local ProfState g_prof;
+
+inline void prof_begin(hipStream_t stream) {
+    if (!g_prof.on) return;
+    g_prof.cur = g_prof.get();
+    if (g_prof.cur) (void)hipEventRecord(g_prof.cur, stream);
+}
+inline void prof_end(hipStream_t stream, const char* name) {
+    if (!g_prof.on || !g_prof.cur) return;
+    hipEvent_t stop = g_prof.get();
+    if (stop) { (void)hipEventRecord(stop, stream); g_prof.pending.push_back({name, g_prof.cur, stop}); }
+    else g_prof.pool.push_back(g_prof.cur);
+    g_prof.cur = nullptr;
+}
+
 int launch_status(bool debug, hipStream_t stream, const char* name) {
+    prof_end(stream, name);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && debug) e = hipStreamSynchronize(stream);
     if (e == hipSuccess) return 0;
@@ -107,6 +140,35 @@ constexpr int kHistLdsMaxTiles = 16384;   // 64 KiB of LDS histogram
 }  // namespace
 
 extern "C" const char* gsr_last_error(void) { return g_err; }
+
+extern "C" int gsr_profile_enable(int on) { g_prof.on = on != 0; return 0; }
+extern "C" int gsr_profile_reset(void) {
+    for (auto& p : g_prof.pending) { g_prof.pool.push_back(p.start); g_prof.pool.push_back(p.stop); }
+    g_prof.pending.clear(); g_prof.rows.clear();
+    return 0;
+}
+extern "C" int gsr_profile_read(int cap, const char** names, float* total_ms, int* launches) {
+    for (auto& p : g_prof.pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(p.stop) == hipSuccess && hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) {
+            ProfRow* row = nullptr;
+            for (auto& r : g_prof.rows) if (r.name == p.name || strcmp(r.name, p.name) == 0) { row = &r; break; }
+            if (!row) { g_prof.rows.push_back({p.name, 0.0, 0}); row = &g_prof.rows.back(); }
+            row->ms += ms; row->launches += 1;
+        }
+        g_prof.pool.push_back(p.start); g_prof.pool.push_back(p.stop);
+    }
+    g_prof.pending.clear();
+    int n = 0;
+    for (auto& r : g_prof.rows) {
+        if (n >= cap) break;
+        if (names) names[n] = r.name;
+        if (total_ms) total_ms[n] = (float)r.ms;
+        if (launches) launches[n] = r.launches;
+        ++n;
+    }
+    return n;
+}
 extern "C" const char* gsr_version(void) { return "gsr 0.1 (gfx950, wave64, 16x16 bins / 8x8 wave blocks)"; }
 
 extern "C" size_t gsr_geom_bytes(int32_t N, int32_t H, int32_t W) { return geom_layout(N, H, W).total; }
@@ -142,7 +204,9 @@ extern "C" int gsr_forward(const GsrView* view, int32_t N, int32_t K,
     uint32_t* n_contrib = (uint32_t*)(ibuf + align_up((size_t)H * W * 4));
 
     // tile_count | cursor | counters are contiguous: one memset
+    prof_begin(stream);
     HIP_TRY(hipMemsetAsync(gbuf + GL.tile_count, 0, GL.tile_off - GL.tile_count, stream));
+    prof_end(stream, "memset_fwd");
 
     const int hist_in_lds = T <= kHistLdsMaxTiles;
     const int grid_n = N > 0 ? (int)fmin((double)((N + 255) / 256), 512.0) : 0;
@@ -153,12 +217,12 @@ extern "C" int gsr_forward(const GsrView* view, int32_t N, int32_t K,
         if (lds > 160 * 1024) return fail(-1, "preprocess needs more than 160 KiB of LDS%s", "");
         if (lds > 48 * 1024)
             HIP_TRY(hipFuncSetAttribute((const void*)gsr_preprocess_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(gsr_preprocess_fwd, dim3(grid_n), dim3(256), lds, stream, vc, N, K, means3D, shs,
+        prof_begin(stream); hipLaunchKernelGGL(gsr_preprocess_fwd, dim3(grid_n), dim3(256), lds, stream, vc, N, K, means3D, shs,
                            colors_precomp, opacities, scales, rotations, cov3D_precomp, recs, emit, radii,
                            tile_count, counters, hist_in_lds);
         LAUNCH_CHECK(view, stream, "preprocess_fwd");
     }
-    hipLaunchKernelGGL(gsr_tile_scan, dim3(1), dim3(1024), 0, stream, tile_count, tile_off, T, counters);
+    prof_begin(stream); hipLaunchKernelGGL(gsr_tile_scan, dim3(1), dim3(1024), 0, stream, tile_count, tile_off, T, counters);
     LAUNCH_CHECK(view, stream, "tile_scan");
 
     // the one host round trip of the forward: how many (tile,Gaussian) instances to allocate
@@ -179,11 +243,11 @@ extern "C" int gsr_forward(const GsrView* view, int32_t N, int32_t K,
         const size_t lds = hist_in_lds ? (size_t)T * 4 : 0;
         if (lds > 48 * 1024)
             HIP_TRY(hipFuncSetAttribute((const void*)gsr_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(gsr_scatter, dim3(grid_n), dim3(256), lds, stream, N, emit, tile_off, cursor, entries,
+        prof_begin(stream); hipLaunchKernelGGL(gsr_scatter, dim3(grid_n), dim3(256), lds, stream, N, emit, tile_off, cursor, entries,
                            vc.gx, T, hist_in_lds, (uint32_t)M);
         LAUNCH_CHECK(view, stream, "scatter");
         // per-tile sort, three size classes
-        hipLaunchKernelGGL((gsr_tile_sort_lds<2048, 256>), dim3(T), dim3(256), 2048 * 8, stream, tile_off, entries, recs, srecs, 0u, 2048u);
+        prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_lds<2048, 256>), dim3(T), dim3(256), 2048 * 8, stream, tile_off, entries, recs, srecs, 0u, 2048u);
         LAUNCH_CHECK(view, stream, "tile_sort_small");
         if (maxc > 2048) {
             static bool attr_set = false;
@@ -191,15 +255,15 @@ extern "C" int gsr_forward(const GsrView* view, int32_t N, int32_t K,
                 HIP_TRY(hipFuncSetAttribute((const void*)gsr_tile_sort_lds<16384, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8));
                 attr_set = true;
             }
-            hipLaunchKernelGGL((gsr_tile_sort_lds<16384, 1024>), dim3(T), dim3(1024), 16384 * 8, stream, tile_off, entries, recs, srecs, 2048u, 16384u);
+            prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_lds<16384, 1024>), dim3(T), dim3(1024), 16384 * 8, stream, tile_off, entries, recs, srecs, 2048u, 16384u);
             LAUNCH_CHECK(view, stream, "tile_sort_large");
         }
         if (maxc > 16384) {
-            hipLaunchKernelGGL(gsr_tile_sort_global, dim3(T), dim3(1024), 0, stream, tile_off, entries, recs, srecs, 16384u);
+            prof_begin(stream); hipLaunchKernelGGL(gsr_tile_sort_global, dim3(T), dim3(1024), 0, stream, tile_off, entries, recs, srecs, 16384u);
             LAUNCH_CHECK(view, stream, "tile_sort_global");
         }
     }
-    hipLaunchKernelGGL(gsr_render_fwd, dim3(T), dim3(256), 0, stream, tile_off, srecs, view->bg, W, H, vc.gx,
+    prof_begin(stream); hipLaunchKernelGGL(gsr_render_fwd, dim3(T), dim3(256), 0, stream, tile_off, srecs, view->bg, W, H, vc.gx,
                        out_color, out_depth, out_alpha, final_T, n_contrib);
     LAUNCH_CHECK(view, stream, "render_fwd");
     return 0;
@@ -239,9 +303,11 @@ extern "C" int gsr_backward(const GsrView* view, int32_t N, int32_t K,
 
     float* g2d = (float*)tmp.resize(tmp.ctx, align_up((size_t)N * GSR_G2D_STRIDE * 4));
     if (!g2d) return fail(-4, "tmp scratch allocation failed%s", "");
+    prof_begin(stream);
     HIP_TRY(hipMemsetAsync(g2d, 0, (size_t)N * GSR_G2D_STRIDE * 4, stream));
+    prof_end(stream, "memset_bwd");
 
-    hipLaunchKernelGGL(gsr_render_bwd, dim3(T), dim3(256), 0, stream, tile_off, srecs, view->bg, W, H, vc.gx,
+    prof_begin(stream); hipLaunchKernelGGL(gsr_render_bwd, dim3(T), dim3(256), 0, stream, tile_off, srecs, view->bg, W, H, vc.gx,
                        final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, g2d);
     LAUNCH_CHECK(view, stream, "render_bwd");
 
@@ -250,7 +316,7 @@ extern "C" int gsr_backward(const GsrView* view, int32_t N, int32_t K,
     if (lds > 160 * 1024) return fail(-1, "preprocess_bwd needs more than 160 KiB of LDS%s", "");
     if (lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void*)gsr_preprocess_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(gsr_preprocess_bwd, dim3(grid_n), dim3(256), lds, stream, vc, N, K, means3D, shs,
+    prof_begin(stream); hipLaunchKernelGGL(gsr_preprocess_bwd, dim3(grid_n), dim3(256), lds, stream, vc, N, K, means3D, shs,
                        colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, recs, g2d,
                        dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacities, dL_dscales,
                        dL_drotations, dL_dcov3D);
@@ -265,7 +331,7 @@ extern "C" int gsr_mark_visible(const GsrView* view, int32_t N, const float* mea
     if (N < 0) return fail(-1, "N must be >= 0%s", "");
     if (N == 0) return 0;
     if (!means3D || !visible) return fail(-1, "means3D and visible are required%s", "");
-    hipLaunchKernelGGL(gsr_mark_visible_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, view->viewmatrix, N, means3D, visible);
+    prof_begin(stream); hipLaunchKernelGGL(gsr_mark_visible_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, view->viewmatrix, N, means3D, visible);
     LAUNCH_CHECK(view, stream, "mark_visible");
     return 0;
 }
@@ -303,17 +369,17 @@ extern "C" int gsr_dist2(int32_t P, const float* points, float* out, GsrAlloc tm
     HIP_TRY(hipMemsetAsync(cnt, 0, o_off - o_cnt, stream));   // cnt | cur
     const int grid_p = (int)fmin((double)((P + 255) / 256), 2048.0);
     GsrView dbg; memset(&dbg, 0, sizeof(dbg));
-    hipLaunchKernelGGL(gsr_knn_bbox, dim3(grid_p), dim3(256), 0, stream, P, points, bbox);
+    prof_begin(stream); hipLaunchKernelGGL(gsr_knn_bbox, dim3(grid_p), dim3(256), 0, stream, P, points, bbox);
     LAUNCH_CHECK(&dbg, stream, "knn_bbox");
-    hipLaunchKernelGGL(gsr_knn_grid_setup, dim3(1), dim3(64), 0, stream, bbox, G, grid);
+    prof_begin(stream); hipLaunchKernelGGL(gsr_knn_grid_setup, dim3(1), dim3(64), 0, stream, bbox, G, grid);
     LAUNCH_CHECK(&dbg, stream, "knn_grid_setup");
-    hipLaunchKernelGGL(gsr_knn_count, dim3(grid_p), dim3(256), 0, stream, P, points, grid, cell_of, cnt);
+    prof_begin(stream); hipLaunchKernelGGL(gsr_knn_count, dim3(grid_p), dim3(256), 0, stream, P, points, grid, cell_of, cnt);
     LAUNCH_CHECK(&dbg, stream, "knn_count");
-    hipLaunchKernelGGL(gsr_knn_scan, dim3(1), dim3(1024), 0, stream, cnt, off, (int)nCells);
+    prof_begin(stream); hipLaunchKernelGGL(gsr_knn_scan, dim3(1), dim3(1024), 0, stream, cnt, off, (int)nCells);
     LAUNCH_CHECK(&dbg, stream, "knn_scan");
-    hipLaunchKernelGGL(gsr_knn_scatter, dim3(grid_p), dim3(256), 0, stream, P, points, cell_of, off, cur, sorted);
+    prof_begin(stream); hipLaunchKernelGGL(gsr_knn_scatter, dim3(grid_p), dim3(256), 0, stream, P, points, cell_of, off, cur, sorted);
     LAUNCH_CHECK(&dbg, stream, "knn_scatter");
-    hipLaunchKernelGGL(gsr_knn_search, dim3(grid_p), dim3(256), 0, stream, P, sorted, off, grid, out);
+    prof_begin(stream); hipLaunchKernelGGL(gsr_knn_search, dim3(grid_p), dim3(256), 0, stream, P, sorted, off, grid, out);
     LAUNCH_CHECK(&dbg, stream, "knn_search");
     return 0;
 }

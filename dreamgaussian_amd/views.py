@@ -1,0 +1,121 @@
+"""View-parallel rendering over the GPUs of one node.
+
+The B cameras of one DreamGaussian SDS step are independent given the Gaussians: the
+reference renders them in a serial Python loop and `torch.cat`s the images
+(main.py:219-255). Here the Gaussians are replicated, rank r renders views r, r+world, ...
+and the images meet on one rank through an RCCL gather over xGMI (direct peer->root
+transfers: each peer owns a link to the root, so the gather is one hop and per-link bound);
+per-Gaussian gradients are summed with one all-reduce per attribute bucket.
+
+One process per GPU, `torch.distributed` (backend "nccl" = RCCL on ROCm; "gloo" in the CPU
+tests). No rendering arithmetic lives here.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def _world(group=None):
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0, 1
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
+def shard_views(views: Sequence, group=None) -> List:
+    """Round-robin ownership: rank r gets views[r::world] (view i lives on rank i % world)."""
+    rank, world = _world(group)
+    return list(views[rank::world])
+
+
+def owner_of(view_index: int, group=None) -> int:
+    return view_index % _world(group)[1]
+
+
+def make_gather_buffer(world: int, channels: int, H: int, W: int, device) -> torch.Tensor:
+    """[world, channels, H, W] staging buffer; only the destination rank reads it."""
+    return torch.empty(world, channels, H, W, dtype=torch.float32, device=device)
+
+
+def gather_views_async(color: torch.Tensor, depth: torch.Tensor, alpha: torch.Tensor,
+                       buf: torch.Tensor, dst: int = 0, group=None):
+    """Start the gather of this rank's (color[3,H,W], depth[1,H,W], alpha[1,H,W]) into
+    buf[rank] on `dst`; returns the work handle (wait() before reading buf). The images are
+    detached: gradients flow back through `scatter_view_grads`."""
+    rank, world = _world(group)
+    local = torch.cat([color.detach(), depth.detach(), alpha.detach()], dim=0).contiguous()
+    if world == 1:
+        buf[0].copy_(local)
+        return None
+    glist = [buf[i] for i in range(world)] if rank == dst else None
+    return dist.gather(local, glist, dst=dst, group=group, async_op=True)
+
+
+def gather_images(local: torch.Tensor, dst: Optional[int] = 0, group=None) -> Optional[torch.Tensor]:
+    """local [b,C,H,W] (this rank's views, equal b on every rank) -> [b*world,C,H,W] in VIEW
+    order (view i = rank i % world, slot i // world) on `dst` (None = every rank)."""
+    rank, world = _world(group)
+    if world == 1:
+        return local
+    local = local.contiguous()
+    if dst is None:
+        out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+        dist.all_gather([out[i] for i in range(world)], local, group=group)
+    else:
+        out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device) \
+            if rank == dst else None
+        dist.gather(local, [out[i] for i in range(world)] if rank == dst else None, dst=dst, group=group)
+        if rank != dst:
+            return None
+    # [world, b, ...] -> view order: index = slot * world + rank
+    return out.transpose(0, 1).reshape((-1,) + tuple(local.shape[1:]))
+
+
+def scatter_view_grads(grad_all: Optional[torch.Tensor], like: torch.Tensor, src: int = 0,
+                       group=None) -> torch.Tensor:
+    """Inverse of gather_images for the backward: `grad_all` [b*world,C,H,W] in view order on
+    `src` -> this rank's [b,C,H,W] slice."""
+    rank, world = _world(group)
+    if world == 1:
+        return grad_all
+    out = torch.empty_like(like)
+    if rank == src:
+        b = like.shape[0]
+        g = grad_all.reshape((b, world) + tuple(like.shape[1:])).transpose(0, 1).contiguous()
+        dist.scatter(out, [g[i] for i in range(world)], src=src, group=group)
+    else:
+        dist.scatter(out, None, src=src, group=group)
+    return out
+
+
+def allreduce_grads(params: Iterable[torch.Tensor], group=None, bucket_bytes: int = 64 << 20):
+    """Sum `.grad` of the replicated Gaussian parameters over the ranks, in flat buckets of
+    ~bucket_bytes (few, large collectives: xGMI rings are per-link bound, launch latency
+    dominates small ones)."""
+    rank, world = _world(group)
+    if world == 1:
+        return
+    grads = [p.grad for p in params if p.grad is not None]
+    bucket, size = [], 0
+
+    def flush():
+        nonlocal bucket, size
+        if not bucket:
+            return
+        flat = torch.cat([g.reshape(-1) for g in bucket])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        off = 0
+        for g in bucket:
+            n = g.numel()
+            g.copy_(flat[off:off + n].view_as(g))
+            off += n
+        bucket, size = [], 0
+
+    for g in grads:
+        bucket.append(g)
+        size += g.numel() * g.element_size()
+        if size >= bucket_bytes:
+            flush()
+    flush()

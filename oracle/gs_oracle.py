@@ -265,7 +265,7 @@ class _Composite(torch.autograd.Function):
     per-tile gradient is torch's, not hand-derived)."""
 
     @staticmethod
-    def forward(ctx, xy, conic, opac, color, depth, bg, ids, ranges, H, W, gx):
+    def forward(ctx, xy, conic, opac, color, depth, bg, ids, ranges, H, W, gx, tiles=None):
         dt = xy.dtype
         out_c = torch.zeros(H, W, 3, dtype=dt)
         out_d = torch.zeros(H, W, dtype=dt)
@@ -273,7 +273,8 @@ class _Composite(torch.autograd.Function):
         out_T = torch.ones(H, W, dtype=dt)
         out_n = torch.zeros(H, W, dtype=torch.int64)
         out_c[:] = bg
-        for t in range(len(ranges) - 1):
+        tiles = range(len(ranges) - 1) if tiles is None else tiles
+        for t in tiles:
             s, e = int(ranges[t]), int(ranges[t + 1])
             if e == s:
                 continue
@@ -290,17 +291,17 @@ class _Composite(torch.autograd.Function):
             out_T[y0:y1, x0:x1] = T.reshape(y1 - y0, x1 - x0)
             out_n[y0:y1, x0:x1] = n.reshape(y1 - y0, x1 - x0)
         ctx.save_for_backward(xy, conic, opac, color, depth, bg)
-        ctx.misc = (ids, ranges, H, W, gx)
+        ctx.misc = (ids, ranges, H, W, gx, tiles)
         ctx.mark_non_differentiable(out_T, out_n)
         return out_c.permute(2, 0, 1).contiguous(), out_d[None], out_a[None], out_T, out_n
 
     @staticmethod
     def backward(ctx, g_c, g_d, g_a, _gT, _gn):
         xy, conic, opac, color, depth, bg = ctx.saved_tensors
-        ids, ranges, H, W, gx = ctx.misc
+        ids, ranges, H, W, gx, tiles = ctx.misc
         grads = [torch.zeros_like(t) for t in (xy, conic, opac, color, depth)]
         g_c = g_c.permute(1, 2, 0)
-        for t in range(len(ranges) - 1):
+        for t in tiles:
             s, e = int(ranges[t]), int(ranges[t + 1])
             if e == s:
                 continue
@@ -319,13 +320,16 @@ class _Composite(torch.autograd.Function):
             for acc, gi in zip(grads, gl):
                 if gi is not None:
                     acc.index_add_(0, g, gi)
-        return (*grads, None, None, None, None, None, None)
+        return (*grads, None, None, None, None, None, None, None)
 
 
 def rasterize(means3D, means2D, opacities, S: Settings, shs=None, colors_precomp=None,
-              scales=None, rotations=None, cov3D_precomp=None, return_aux: bool = False):
+              scales=None, rotations=None, cov3D_precomp=None, return_aux: bool = False,
+              tiles=None):
     """Full differentiable render. Returns (color[3,H,W], radii[N] i32, depth[1,H,W],
-    alpha[1,H,W]) in the order the reference unpacks (gs_renderer.py:800)."""
+    alpha[1,H,W]) in the order the reference unpacks (gs_renderer.py:800).
+    `tiles` (optional list of tile ids) restricts compositing to those 16x16 tiles (all other
+    pixels keep the background): bench.py's bounded CPU-baseline sample."""
     assert means3D.device.type == "cpu", "the oracle is a CPU checker"
     pre = preprocess(means3D, means2D, opacities, shs, colors_precomp, scales, rotations,
                      cov3D_precomp, S)
@@ -334,7 +338,7 @@ def rasterize(means3D, means2D, opacities, S: Settings, shs=None, colors_precomp
     bg = S.bg.to(means3D.dtype).cpu()
     color, depth, alpha, T_final, n_contrib = _Composite.apply(
         pre["xy"], pre["conic"], pre["opacity"], pre["color"], pre["depth"], bg,
-        ids, ranges, H, W, pre["grid"][0])
+        ids, ranges, H, W, pre["grid"][0], tiles)
     if return_aux:
         aux = dict(pre=pre, ids=ids, ranges=ranges, M=M, V=int(pre["valid"].sum()),
                    T_final=T_final, n_contrib=n_contrib)
@@ -349,89 +353,13 @@ def mark_visible(means3D, S: Settings) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------------------
-# cameras / synthetic scenes shared by tests and bench  
+# cameras / synthetic scenes: shared with bench.py, so they live in the package
+# (dreamgaussian_amd/synthetic.py, host-side input generators only)
 # --------------------------------------------------------------------------------------
-
-def look_at_opengl(campos):
-    """cam_utils.py:21-41 (opengl=True, target=0)."""
-    def nrm(v):
-        return v / np.sqrt(max(float(np.sum(v * v)), 1e-20))
-    fwd = nrm(campos.astype(np.float64))
-    up = np.array([0, 1, 0], dtype=np.float64)
-    right = nrm(np.cross(up, fwd))
-    up = nrm(np.cross(fwd, right))
-    return np.stack([right, up, fwd], axis=1)
+from dreamgaussian_amd.synthetic import (look_at_opengl, orbit_pose, nn3_mean_sqdist,  # noqa: E402,F401
+                                         make_scene)
+from dreamgaussian_amd import synthetic as _syn  # noqa: E402
 
 
-def orbit_pose(elevation, azimuth, radius):
-    """cam_utils.py:44-63."""
-    el, az = np.deg2rad(elevation), np.deg2rad(azimuth)
-    campos = np.array([radius * np.cos(el) * np.sin(az), -radius * np.sin(el),
-                       radius * np.cos(el) * np.cos(az)])
-    T = np.eye(4, dtype=np.float32)
-    T[:3, :3] = look_at_opengl(campos)
-    T[:3, 3] = campos
-    return T
-
-
-def make_settings(c2w, W, H, fovy_deg=49.1, znear=0.01, zfar=100.0, sh_degree=0, bg=(1, 1, 1),
-                  scale_modifier=1.0, dtype=torch.float32) -> Settings:
-    """MiniCam + Renderer.render's settings assembly (gs_renderer.py:645-671, 742-758)."""
-    fovy = np.deg2rad(fovy_deg)
-    fovx = 2 * np.arctan(np.tan(fovy / 2) * W / H)
-    w2c = np.linalg.inv(c2w)
-    w2c[1:3, :3] *= -1
-    w2c[:3, 3] *= -1
-    view = torch.tensor(w2c).transpose(0, 1).to(torch.float32)
-    P = torch.zeros(4, 4)
-    P[0, 0] = 1 / math.tan(fovx / 2)
-    P[1, 1] = 1 / math.tan(fovy / 2)
-    P[3, 2] = 1.0
-    P[2, 2] = zfar / (zfar - znear)
-    P[2, 3] = -(zfar * znear) / (zfar - znear)
-    proj = view @ P.transpose(0, 1)
-    campos = -torch.tensor(c2w[:3, 3]).to(torch.float32)
-    return Settings(H, W, math.tan(fovx * 0.5), math.tan(fovy * 0.5),
-                    torch.tensor(bg, dtype=dtype), scale_modifier, view.to(dtype),
-                    proj.to(dtype), sh_degree, campos.to(dtype), False, False)
-
-
-def nn3_mean_sqdist(xyz: np.ndarray) -> np.ndarray:
-    from scipy.spatial import cKDTree
-    d, _ = cKDTree(xyz).query(xyz, k=4)
-    return (d[:, 1:] ** 2).mean(1)
-
-
-def make_scene(N, sh_degree=0, seed=0, kind="blob"):
-    """Synthetic scenes of SURVEY §8(d). Returns activated tensors exactly as
-    Renderer.render hands them to the rasterizer (gs_renderer.py:762-797)."""
-    rs = np.random.RandomState(seed)
-    phis = rs.random_sample(N) * 2 * np.pi
-    costheta = rs.random_sample(N) * 2 - 1
-    thetas = np.arccos(costheta)
-    mu = rs.random_sample(N)
-    r = 0.5 * np.cbrt(mu)
-    xyz = np.stack([r * np.sin(thetas) * np.cos(phis), r * np.sin(thetas) * np.sin(phis),
-                    r * np.cos(thetas)], 1).astype(np.float32)
-    K = (sh_degree + 1) ** 2
-    sh = np.zeros((N, K, 3), np.float32)
-    sh[:, 0] = rs.random_sample((N, 3)) / 255.0  # SH2RGB->RGB2SH round trip (gs_renderer.py:705-707,334)
-    if K > 1:
-        sh[:, 1:] = rs.normal(0, 0.1, (N, K - 1, 3))
-    d2 = np.maximum(nn3_mean_sqdist(xyz.astype(np.float64)), 1e-7).astype(np.float32)
-    sigma = np.sqrt(d2)
-    if kind == "blob":
-        scales = np.repeat(sigma[:, None], 3, 1)
-        rots = np.zeros((N, 4), np.float32)
-        rots[:, 0] = 1
-        opac = np.full((N, 1), 0.1, np.float32)
-    elif kind == "trained":
-        scales = sigma[:, None] * np.exp(rs.uniform(np.log(0.3), np.log(3.0), (N, 3)))
-        q = rs.normal(size=(N, 4))
-        rots = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
-        opac = rs.uniform(0.05, 0.95, (N, 1)).astype(np.float32)
-        sh[:, 0] = (rs.random_sample((N, 3)) - 0.5) / C0
-    else:
-        raise ValueError(kind)
-    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
-    return dict(means3D=t(xyz), shs=t(sh), opacities=t(opac), scales=t(scales), rotations=t(rots))
+def make_settings(*a, **k) -> Settings:
+    return Settings(*_syn.make_settings(*a, **k))

@@ -1,0 +1,103 @@
+"""View-parallel host logic (dreamgaussian_amd/views.py) on CPU: two gloo processes.
+Each rank renders its own camera (with the oracle standing in for the GPU rasterizer, as the
+checker) and the gathered batch / reduced gradients must equal the serial result."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _render(cam_az, sc, W, H):
+    from oracle import gs_oracle as O
+    S = O.make_settings(O.orbit_pose(0.0, cam_az, 2.0), W, H, sh_degree=0)
+    c, r, d, a = O.rasterize(sc["means3D"], None, sc["opacities"], S, shs=sc["shs"], scales=sc["scales"], rotations=sc["rotations"])
+    return torch.cat([c, d, a], 0)
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import gs_oracle as O
+        from dreamgaussian_amd import views
+        torch.manual_seed(0)
+        W, H = 32, 24
+        azs = [0.0, 90.0, 180.0, 270.0]
+        sc = {k: v.clone().requires_grad_(True) for k, v in O.make_scene(120, 0, 0, "trained").items()}
+        mine = views.shard_views(azs)
+        assert mine == azs[rank::world]
+        assert [views.owner_of(i) for i in range(4)] == [0, 1, 0, 1]
+        local = torch.stack([_render(az, sc, W, H) for az in mine])            # [2,5,H,W]
+        batch = views.gather_images(local.detach(), dst=0)
+        everywhere = views.gather_images(local.detach(), dst=None)
+        # async gather used by bench.py
+        buf = views.make_gather_buffer(world, 5, H, W, "cpu")
+        work = views.gather_views_async(local[0, :3], local[0, 3:4], local[0, 4:5], buf, dst=0)
+        if work is not None:
+            work.wait()
+        # loss on the gathered batch lives on rank 0; its image gradient is scattered back
+        gw = torch.rand(4, 5, H, W, generator=torch.Generator().manual_seed(1))
+        g_local = views.scatter_view_grads(gw if rank == 0 else None, local, src=0)
+        torch.autograd.backward([local], [g_local])
+        params = list(sc.values())
+        views.allreduce_grads(params, bucket_bytes=1 << 10)                    # several buckets
+        if rank == 0:
+            q.put(dict(batch=batch, everywhere=everywhere, buf=buf.clone(),
+                       grads={k: v.grad.clone() for k, v in sc.items()}))
+        else:
+            assert batch is None
+            q.put(dict(everywhere=everywhere, grads={k: v.grad.clone() for k, v in sc.items()}))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_view_parallel_equals_serial():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import gs_oracle as O
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    r0 = next(r for r in res if "batch" in r)
+    r1 = next(r for r in res if "batch" not in r)
+    # serial reference
+    W, H = 32, 24
+    azs = [0.0, 90.0, 180.0, 270.0]
+    sc = {k: v.clone().requires_grad_(True) for k, v in O.make_scene(120, 0, 0, "trained").items()}
+    serial = torch.stack([_render(az, sc, W, H) for az in azs])
+    gw = torch.rand(4, 5, H, W, generator=torch.Generator().manual_seed(1))
+    torch.autograd.backward([serial], [gw])
+    assert torch.allclose(r0["batch"], serial.detach(), atol=1e-6)
+    assert torch.equal(r0["everywhere"], r1["everywhere"]) and torch.allclose(r0["everywhere"], serial.detach(), atol=1e-6)
+    assert torch.allclose(r0["buf"][0], serial[0].detach(), atol=1e-6) and torch.allclose(r0["buf"][1], serial[1].detach(), atol=1e-6)
+    for k, v in sc.items():
+        for r in (r0, r1):
+            assert torch.allclose(r["grads"][k], v.grad, rtol=1e-4, atol=1e-6 * v.grad.abs().max().item()), k
+
+
+def test_single_process_fallthrough():
+    from dreamgaussian_amd import views
+    x = torch.rand(2, 5, 4, 4)
+    assert views.shard_views([1, 2, 3]) == [1, 2, 3]
+    assert views.gather_images(x) is x
+    assert views.scatter_view_grads(x, x) is x
+    views.allreduce_grads([torch.nn.Parameter(torch.zeros(3))])

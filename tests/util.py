@@ -1,0 +1,71 @@
+"""Shared helpers for the parity tests: run the HIP path and the oracle on the same inputs."""
+import torch
+
+from oracle import gs_oracle as O
+import dreamgaussian_amd as D
+
+
+def settings_to(S, dev, dtype=torch.float32):
+    return D.GaussianRasterizationSettings(*[x.to(device=dev, dtype=dtype) if torch.is_tensor(x) else x for x in S])
+
+
+def run_hip(sc, S, dev, weights=None, means2D=True):
+    t = {k: v.detach().to(dev).requires_grad_(True) for k, v in sc.items()}
+    N = t["means3D"].shape[0]
+    m2d = torch.zeros(N, 3, device=dev, requires_grad=True)
+    out = D.GaussianRasterizer(raster_settings=settings_to(S, dev))(
+        means3D=t["means3D"], means2D=m2d, shs=t.get("shs"), colors_precomp=t.get("colors_precomp"),
+        opacities=t["opacities"], scales=t.get("scales"), rotations=t.get("rotations"),
+        cov3D_precomp=t.get("cov3D_precomp"))
+    grads = None
+    if weights is not None:
+        torch.autograd.backward([out[0], out[2], out[3]], [w.to(dev) for w in weights])
+        grads = {k: v.grad.detach().cpu() for k, v in t.items()}
+        grads["means2D"] = m2d.grad.detach().cpu()
+    return [o.detach().cpu() for o in out], grads, D.last_stats()
+
+
+def run_oracle(sc, S, weights=None, dtype=torch.float32):
+    t = {k: v.detach().to(dtype).requires_grad_(True) for k, v in sc.items()}
+    N = t["means3D"].shape[0]
+    m2d = torch.zeros(N, 3, dtype=dtype, requires_grad=True)
+    S2 = O.Settings(*[x.to(dtype) if torch.is_tensor(x) else x for x in S])
+    c, r, d, a, aux = O.rasterize(t["means3D"], m2d, t["opacities"], S2, shs=t.get("shs"),
+                                  colors_precomp=t.get("colors_precomp"), scales=t.get("scales"),
+                                  rotations=t.get("rotations"), cov3D_precomp=t.get("cov3D_precomp"),
+                                  return_aux=True)
+    grads = None
+    if weights is not None:
+        torch.autograd.backward([c, d, a], [w.to(dtype) for w in weights])
+        grads = {k: v.grad.detach() for k, v in t.items()}
+        grads["means2D"] = m2d.grad.detach()
+    return [c.detach(), r, d.detach(), a.detach()], grads, aux
+
+
+def weights_for(H, W, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.rand(3, H, W, generator=g), torch.rand(1, H, W, generator=g), torch.rand(1, H, W, generator=g)]
+
+
+# Stated tolerances (fp32 HIP kernels vs the oracle; BASELINE.json: grads within 1e-4 rel):
+FWD_ATOL = 2e-5          # color / alpha, absolute (values are O(1)); depth relative to its max
+GRAD_RTOL = 1e-4         # per attribute, relative to that attribute's max |grad| (float64 oracle as arbiter)
+
+
+def assert_forward_close(ho, oo, atol=FWD_ATOL):
+    assert bool((ho[1].to(torch.int64) == oo[1].to(torch.int64)).all()), \
+        f"radii mismatch on {int((ho[1] != oo[1]).sum())} Gaussians"
+    for name, i in (("color", 0), ("depth", 2), ("alpha", 3)):
+        ref = oo[i].double()
+        err = (ho[i].double() - ref).abs().max().item()
+        tol = atol * max(1.0, ref.abs().max().item())
+        assert err <= tol, f"{name}: max abs err {err:.3e} > {tol:.3e}"
+
+
+def assert_grads_close(hg, og, rtol=GRAD_RTOL):
+    for k, ref in og.items():
+        ref = ref.double()
+        got = hg[k].double().reshape(ref.shape)
+        scale = ref.abs().max().item()
+        err = (got - ref).abs().max().item()
+        assert err <= rtol * scale + 1e-9, f"d{k}: max abs err {err:.3e} vs {rtol:.0e} * max|ref| {scale:.3e}"
