@@ -74,55 +74,52 @@ def build_inputs(wl, kind, dev, azimuth):
     return sc, rs_cpu, rs, grads
 
 
-def cpu_baseline(sc, rs_cpu, grads, budget_s=15.0):
-    """CPU oracle on a bounded sample of the SAME scene/camera/loss: per-Gaussian stage and
-    binning in full, compositing fwd+bwd on a strided subset of the non-empty 16x16 tiles
-    sized to ~budget_s; whole-frame time estimated by scaling the composite time with the
-    (instance x pixel) pair count. kind 'port': the reference has no CPU path."""
+def cpu_baseline(sc, rs_cpu, grads, budget_s=15.0, max_threads=16):
+    """CPU oracle on a bounded sample of the SAME scene/camera/loss: the per-Gaussian stage and
+    the binning run in full (they define the tile lists), compositing fwd+bwd runs on a strided
+    subset of the non-empty 16x16 tiles sized to ~budget_s; the whole-frame time is estimated by
+    scaling the measured composite time with the (instance x pixel) pair count.
+    kind 'port': the reference has no CPU path and its CUDA extension is absent."""
     from oracle import gs_oracle as O
-    ncores = os.cpu_count() or 1
-    torch.set_num_threads(ncores)
+    nthreads = max(1, min(os.cpu_count() or 1, max_threads))   # torch CPU ops stop scaling well before 256 threads
+    torch.set_num_threads(nthreads)
     S = O.Settings(*rs_cpu)
     H, W = int(S.image_height), int(S.image_width)
 
-    def leaves():
-        t = {k: v.detach().clone().requires_grad_(True) for k, v in sc.items()}
-        return t
-
     def run(tiles):
-        t = leaves()
+        t = {k: v.detach().clone().requires_grad_(True) for k, v in sc.items()}
+        O.TIMERS["composite_fwd"] = O.TIMERS["composite_bwd"] = 0.0
         t0 = time.perf_counter()
         c, r, d, a, aux = O.rasterize(t["means3D"], None, t["opacities"], S, shs=t["shs"],
                                       scales=t["scales"], rotations=t["rotations"],
                                       return_aux=True, tiles=tiles)
         torch.autograd.backward([c, d, a], grads)
-        return time.perf_counter() - t0, aux
+        total = time.perf_counter() - t0
+        comp = O.TIMERS["composite_fwd"] + O.TIMERS["composite_bwd"]
+        return total - comp, comp, aux
 
-    # pass 0: no tiles -> cost of the per-Gaussian stage + binning (+ their backward)
-    t_pg, aux = run([])
+    # probe: two tiles -> seconds per (instance x pixel) pair; also times the per-Gaussian stage
+    t_pg, _, aux = run([])
     ranges = aux["ranges"]
     cnt = ranges[1:] - ranges[:-1]
     nonempty = [int(t) for t in range(len(cnt)) if cnt[t] > 0]
     total_pairs = float(cnt.sum()) * 256.0
     if not nonempty:
-        return dict(value=H * W / t_pg / 1e6, unit="Mrays/s", cores=ncores, kind="port",
-                    sample="empty scene")
-    # calibrate on 2 tiles, then pick the stride that fits the budget
-    probe = nonempty[:: max(1, len(nonempty) // 2)][:2]
-    t_probe, _ = run(probe)
-    per_pair = max(t_probe - t_pg, 1e-4) / (float(sum(cnt[t] for t in probe)) * 256.0)
-    want_pairs = budget_s / per_pair
-    stride = max(1, int(round(total_pairs / want_pairs)))
+        return dict(value=H * W / t_pg / 1e6, unit="Mrays/s", cores=nthreads, kind="port", sample="empty scene")
+    probe = [nonempty[len(nonempty) // 3], nonempty[(2 * len(nonempty)) // 3]]
+    _, c_probe, _ = run(probe)
+    per_pair = max(c_probe, 1e-4) / (float(sum(cnt[t] for t in probe)) * 256.0)
+    stride = max(1, int(round(total_pairs * per_pair / budget_s)))
     tiles = nonempty[::stride]
-    t_s, _ = run(tiles)
+    t_pg2, t_comp, _ = run(tiles)
+    t_pg = min(t_pg, t_pg2)
     pairs_s = float(sum(cnt[t] for t in tiles)) * 256.0
-    t_comp = max(t_s - t_pg, 1e-6)
     t_full = t_pg + t_comp * total_pairs / pairs_s
-    return dict(value=H * W / t_full / 1e6, unit="Mrays/s", cores=ncores, kind="port",
-                sample=(f"oracle fwd+bwd, same scene/camera/loss: per-Gaussian stage + binning in full "
-                        f"({t_pg:.1f} s), compositing on {len(tiles)} of {len(nonempty)} non-empty tiles "
-                        f"({100.0 * pairs_s / total_pairs:.1f}% of instance-pixel pairs, {t_comp:.1f} s), "
-                        f"frame time scaled by pair count to {t_full:.0f} s"))
+    return dict(value=H * W / t_full / 1e6, unit="Mrays/s", cores=nthreads, kind="port",
+                sample=(f"oracle fwd+bwd, same scene/camera/loss, {nthreads} torch threads of {os.cpu_count()} "
+                        f"host cores: per-Gaussian stage + binning in full ({t_pg:.1f} s), compositing on "
+                        f"{len(tiles)} of {len(nonempty)} non-empty tiles ({100.0 * pairs_s / total_pairs:.1f}% of "
+                        f"instance-pixel pairs, {t_comp:.1f} s), frame time scaled by pair count to {t_full:.0f} s"))
 
 
 def main():
@@ -242,7 +239,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and a.cpu_budget > 0:
         cpu = cpu_baseline(sc, rs_cpu, grads_cpu, a.cpu_budget)
-        cpu["value"] = round(cpu["value"], 5)
+        cpu["value"] = float(f"{cpu['value']:.4g}")
 
     if rank == 0:
         rays = wl["H"] * wl["W"] * world * a.steps

@@ -12,6 +12,7 @@
 #include <string.h>
 #include <math.h>
 #include <vector>
+#include <mutex>
 
 namespace {
 
@@ -34,7 +35,6 @@ struct ProfPending { const char* name; hipEvent_t start, stop; };
 struct ProfRow { const char* name; double ms; int launches; };
 struct ProfState {
     bool on = false;
-    hipEvent_t cur = nullptr;
     std::vector<hipEvent_t> pool;
     std::vector<ProfPending> pending;
     std::vector<ProfRow> rows;
@@ -45,19 +45,24 @@ struct ProfState {
         return e;
     }
 };
-thread_local ProfState g_prof;
+// process-wide (the backward runs on torch's autograd thread, the forward on the caller's)
+ProfState g_prof;
+std::mutex g_prof_mu;
+thread_local hipEvent_t g_prof_cur = nullptr;
 
 inline void prof_begin(hipStream_t stream) {
     if (!g_prof.on) return;
-    g_prof.cur = g_prof.get();
-    if (g_prof.cur) (void)hipEventRecord(g_prof.cur, stream);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_cur = g_prof.get();
+    if (g_prof_cur) (void)hipEventRecord(g_prof_cur, stream);
 }
 inline void prof_end(hipStream_t stream, const char* name) {
-    if (!g_prof.on || !g_prof.cur) return;
+    if (!g_prof.on || !g_prof_cur) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     hipEvent_t stop = g_prof.get();
-    if (stop) { (void)hipEventRecord(stop, stream); g_prof.pending.push_back({name, g_prof.cur, stop}); }
-    else g_prof.pool.push_back(g_prof.cur);
-    g_prof.cur = nullptr;
+    if (stop) { (void)hipEventRecord(stop, stream); g_prof.pending.push_back({name, g_prof_cur, stop}); }
+    else g_prof.pool.push_back(g_prof_cur);
+    g_prof_cur = nullptr;
 }
 
 int launch_status(bool debug, hipStream_t stream, const char* name) {
@@ -143,11 +148,13 @@ extern "C" const char* gsr_last_error(void) { return g_err; }
 
 extern "C" int gsr_profile_enable(int on) { g_prof.on = on != 0; return 0; }
 extern "C" int gsr_profile_reset(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto& p : g_prof.pending) { g_prof.pool.push_back(p.start); g_prof.pool.push_back(p.stop); }
     g_prof.pending.clear(); g_prof.rows.clear();
     return 0;
 }
 extern "C" int gsr_profile_read(int cap, const char** names, float* total_ms, int* launches) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto& p : g_prof.pending) {
         float ms = 0.f;
         if (hipEventSynchronize(p.stop) == hipSuccess && hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) {

@@ -22,6 +22,12 @@ constexpr float SH_C3_0 = -0.5900435899266435f, SH_C3_1 = 2.890611442640554f,
                 SH_C3_4 = -0.4570457994644658f, SH_C3_5 = 1.445305721320277f,
                 SH_C3_6 = -0.5900435899266435f;
 
+// View-space depth in ONE pinned fp32 evaluation order (no fma contraction): it is the sort
+// key of the compositing order, so the oracle evaluates exactly this chain.
+__device__ __forceinline__ float view_depth(const float* __restrict__ V, float x, float y, float z) {
+    return __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(V[2], x), __fmul_rn(V[6], y)), __fmul_rn(V[10], z)), V[14]);
+}
+
 struct Cov3 { float c0, c1, c2, c3, c4, c5; };   // S00 S01 S02 S11 S12 S22
 
 __device__ __forceinline__ void quat_to_R(const float4 q, float R[9]) {
@@ -198,7 +204,7 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
         float3 pv;
         pv.x = V[0] * mx + V[4] * my + V[8] * mz + V[12];
         pv.y = V[1] * mx + V[5] * my + V[9] * mz + V[13];
-        pv.z = V[2] * mx + V[6] * my + V[10] * mz + V[14];
+        pv.z = view_depth(V, mx, my, mz);
         if (pv.z > 0.2f) {
             const float hx = P[0] * mx + P[4] * my + P[8] * mz + P[12];
             const float hy = P[1] * mx + P[5] * my + P[9] * mz + P[13];
@@ -378,7 +384,7 @@ gsr_preprocess_bwd(ViewConst vc, int N, int K,
             float3 pv;
             pv.x = V[0] * mx + V[4] * my + V[8] * mz + V[12];
             pv.y = V[1] * mx + V[5] * my + V[9] * mz + V[13];
-            pv.z = V[2] * mx + V[6] * my + V[10] * mz + V[14];
+            pv.z = view_depth(V, mx, my, mz);
             const float hx = P[0] * mx + P[4] * my + P[8] * mz + P[12];
             const float hy = P[1] * mx + P[5] * my + P[9] * mz + P[13];
             const float hw = P[3] * mx + P[7] * my + P[11] * mz + P[15];
@@ -571,6 +577,6 @@ gsr_mark_visible_kernel(const float* __restrict__ V, int N, const float* __restr
                         uint8_t* __restrict__ visible) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= N) return;
-    const float z = V[2] * means3D[3 * idx] + V[6] * means3D[3 * idx + 1] + V[10] * means3D[3 * idx + 2] + V[14];
+    const float z = view_depth(V, means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
     visible[idx] = z > 0.2f ? 1 : 0;
 }

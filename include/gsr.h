@@ -114,8 +114,8 @@ int gsr_dist2(int32_t P, const float* points, float* out, GsrAlloc tmp, gsr_stre
 size_t gsr_geom_bytes(int32_t N, int32_t image_height, int32_t image_width);
 size_t gsr_img_bytes(int32_t image_height, int32_t image_width);
 
-/* Per-kernel timing, a measurement aid for bench.py: while enabled (per host
- * thread) every kernel launched by gsr_forward / gsr_backward / gsr_dist2 is bracketed by a
+/* Per-kernel timing, a measurement aid for bench.py: while enabled (process
+ * wide) every kernel launched by gsr_forward / gsr_backward / gsr_dist2 is bracketed by a
  * hipEvent pair recorded on the caller's stream. gsr_profile_read waits for the recorded
  * events, folds them into per-kernel totals and copies up to `cap` rows out:
  * names[i] (static strings), total_ms[i], launches[i]. Returns the number of rows.

@@ -34,6 +34,10 @@ from typing import NamedTuple, Optional
 import numpy as np
 import torch
 
+import time
+
+TIMERS = {"composite_fwd": 0.0, "composite_bwd": 0.0}   # seconds spent compositing (bench.py's cpu_baseline)
+
 BLOCK = 16  # binning granularity in pixels (part of the numerics: SURVEY §7 hard part 2)
 
 # SH constants: identical values to sh_utils.py:26-48
@@ -134,7 +138,13 @@ def preprocess(means3D, means2D, opacities, shs, colors_precomp, scales, rotatio
         # gradient is dL/d(ndc) = dL/d(pixel) * 0.5*(W,H)   
         ndc = ndc + means2D[:, :2]
     tz = p_view[:, 2]
-    valid = tz > 0.2
+    with torch.no_grad():
+        # The depth SORT KEY is pinned to one fp32 evaluation order so that the discrete
+        # compositing order is reproducible bit for bit (A.4): key = ((V02*x + V12*y) + V22*z) + V32,
+        # every product and sum rounded to fp32 separately (no fma). The kernels use the same chain.
+        m32, V32 = means3D.detach().to(torch.float32), V.detach().to(torch.float32)
+        depth_key = ((V32[0, 2] * m32[:, 0] + V32[1, 2] * m32[:, 1]) + V32[2, 2] * m32[:, 2]) + V32[3, 2]
+        valid = depth_key > 0.2          # frustum rule (A.3), decided on the same fp32 value
 
     if cov3D_precomp is not None and cov3D_precomp.numel() > 0:
         Sigma = sym_from6(cov3D_precomp)
@@ -193,7 +203,7 @@ def preprocess(means3D, means2D, opacities, shs, colors_precomp, scales, rotatio
         clamped = raw < 0
         color = torch.clamp_min(raw, 0.0)  # gs_renderer.py:793
 
-    return dict(valid=valid, xy=torch.stack([px, py], -1), depth=tz, conic=conic,
+    return dict(valid=valid, xy=torch.stack([px, py], -1), depth=tz, depth_key=depth_key, conic=conic,
                 opacity=opacities.reshape(-1), color=color, clamped=clamped,
                 radius=torch.where(valid, radius, torch.zeros_like(radius)).to(torch.int32),
                 rect=torch.stack([rx0, ry0, rx1, ry1], -1), tiles=torch.where(valid, tiles, 0),
@@ -209,7 +219,7 @@ def build_tile_lists(pre: dict):
     gx, gy = pre["grid"]
     valid = pre["valid"].cpu().numpy()
     rect = pre["rect"].cpu().numpy()
-    depth = pre["depth"].detach().to(torch.float32).cpu().numpy()
+    depth = pre["depth_key"].cpu().numpy()
     idx = np.nonzero(valid)[0]
     r = rect[idx]
     w = (r[:, 2] - r[:, 0]).astype(np.int64)
@@ -267,6 +277,7 @@ class _Composite(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xy, conic, opac, color, depth, bg, ids, ranges, H, W, gx, tiles=None):
         dt = xy.dtype
+        _t0 = time.perf_counter()
         out_c = torch.zeros(H, W, 3, dtype=dt)
         out_d = torch.zeros(H, W, dtype=dt)
         out_a = torch.zeros(H, W, dtype=dt)
@@ -290,6 +301,7 @@ class _Composite(torch.autograd.Function):
             out_a[y0:y1, x0:x1] = a.reshape(y1 - y0, x1 - x0)
             out_T[y0:y1, x0:x1] = T.reshape(y1 - y0, x1 - x0)
             out_n[y0:y1, x0:x1] = n.reshape(y1 - y0, x1 - x0)
+        TIMERS["composite_fwd"] += time.perf_counter() - _t0
         ctx.save_for_backward(xy, conic, opac, color, depth, bg)
         ctx.misc = (ids, ranges, H, W, gx, tiles)
         ctx.mark_non_differentiable(out_T, out_n)
@@ -299,6 +311,7 @@ class _Composite(torch.autograd.Function):
     def backward(ctx, g_c, g_d, g_a, _gT, _gn):
         xy, conic, opac, color, depth, bg = ctx.saved_tensors
         ids, ranges, H, W, gx, tiles = ctx.misc
+        _t0 = time.perf_counter()
         grads = [torch.zeros_like(t) for t in (xy, conic, opac, color, depth)]
         g_c = g_c.permute(1, 2, 0)
         for t in tiles:
@@ -320,6 +333,7 @@ class _Composite(torch.autograd.Function):
             for acc, gi in zip(grads, gl):
                 if gi is not None:
                     acc.index_add_(0, g, gi)
+        TIMERS["composite_bwd"] += time.perf_counter() - _t0
         return (*grads, None, None, None, None, None, None, None)
 
 
@@ -348,8 +362,8 @@ def rasterize(means3D, means2D, opacities, S: Settings, shs=None, colors_precomp
 
 def mark_visible(means3D, S: Settings) -> torch.Tensor:
     """Frustum test only (view-space z > 0.2), the rule the preprocess uses."""
-    V = S.viewmatrix.to(means3D.dtype)
-    return (means3D @ V[:3, 2] + V[3, 2]) > 0.2
+    m32, V32 = means3D.detach().to(torch.float32), S.viewmatrix.to(torch.float32)
+    return (((V32[0, 2] * m32[:, 0] + V32[1, 2] * m32[:, 1]) + V32[2, 2] * m32[:, 2]) + V32[3, 2]) > 0.2
 
 
 # --------------------------------------------------------------------------------------

@@ -52,20 +52,44 @@ FWD_ATOL = 2e-5          # color / alpha, absolute (values are O(1)); depth rela
 GRAD_RTOL = 1e-4         # per attribute, relative to that attribute's max |grad| (float64 oracle as arbiter)
 
 
-def assert_forward_close(ho, oo, atol=FWD_ATOL):
-    assert bool((ho[1].to(torch.int64) == oo[1].to(torch.int64)).all()), \
-        f"radii mismatch on {int((ho[1] != oo[1]).sum())} Gaussians"
+def assert_forward_close(ho, oo, atol=FWD_ATOL, outlier_frac=2e-5, outlier_abs=8e-3):
+    """radii equal up to boundary flips; color/depth/alpha within atol (depth: atol * max depth).
+    Discrete per-(pixel,Gaussian) decisions (alpha >= 1/255, T(1-alpha) >= 1e-4) sit on fp32
+    boundaries for ~1e-8 of the pairs, so on large frames a few pixels (<= outlier_frac of them,
+    none on small frames) may differ by up to one minimal contribution (2/255)."""
+    dr = (ho[1].to(torch.int64) - oo[1].to(torch.int64)).abs()
+    # radius = ceil(3 sqrt(lambda)) is discontinuous: fp32 rounding differences (fma contraction,
+    # sqrt) may flip a value sitting on an integer boundary, by one, on a handful of Gaussians
+    if dr.numel():
+        nbad = int((dr != 0).sum())
+        assert int(dr.max()) <= 1 and nbad <= max(1, dr.numel() // 5000), \
+            f"radii mismatch on {nbad} Gaussians (max |diff| {int(dr.max())})"
     for name, i in (("color", 0), ("depth", 2), ("alpha", 3)):
         ref = oo[i].double()
-        err = (ho[i].double() - ref).abs().max().item()
-        tol = atol * max(1.0, ref.abs().max().item())
-        assert err <= tol, f"{name}: max abs err {err:.3e} > {tol:.3e}"
+        err = (ho[i].double() - ref).abs()
+        scale = max(1.0, ref.abs().max().item())
+        tol = atol * scale
+        nout = int((err > tol).sum())
+        allowed = int(err.numel() * outlier_frac)
+        assert nout <= allowed and err.max().item() <= (outlier_abs * scale if allowed else tol), \
+            f"{name}: {nout} values above {tol:.1e} (allowed {allowed}), max abs err {err.max().item():.3e}"
 
 
-def assert_grads_close(hg, og, rtol=GRAD_RTOL):
+def grad_floors(sc, og):
+    """Natural magnitude of each gradient, for attributes whose true gradient may cancel to ~0:
+    dL/dq is a sum of dL/dM * s terms (exactly 0 for isotropic Gaussians), so its rounding noise
+    scales with |dL/ds| * |s|, not with |dL/dq|."""
+    floors = {}
+    if "rotations" in og and "scales" in og:
+        floors["rotations"] = (og["scales"].double().abs().max() * sc["scales"].double().abs().max()).item()
+    return floors
+
+
+def assert_grads_close(hg, og, rtol=GRAD_RTOL, floors=None):
+    floors = floors or {}
     for k, ref in og.items():
         ref = ref.double()
         got = hg[k].double().reshape(ref.shape)
-        scale = ref.abs().max().item()
+        scale = max(ref.abs().max().item(), floors.get(k, 0.0))
         err = (got - ref).abs().max().item()
-        assert err <= rtol * scale + 1e-9, f"d{k}: max abs err {err:.3e} vs {rtol:.0e} * max|ref| {scale:.3e}"
+        assert err <= rtol * scale + 1e-9, f"d{k}: max abs err {err:.3e} vs {rtol:.0e} * scale {scale:.3e}"

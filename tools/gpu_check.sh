@@ -1,16 +1,34 @@
 #!/bin/bash
-# One gpurun call: GPU tests, smoke, bench lines, rocprofv3 kernel trace. Outputs -> gpurun_out/.
+# One gpurun call; sections chosen by arguments (default: all). Outputs -> gpurun_out/.
+#   tests smoke bench benchall prof pmc
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-echo "== pytest -m gpu"; timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -40 | tee gpurun_out/pytest_gpu.log
-echo "== smoke"; timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -5 | tee gpurun_out/smoke.log
-echo "== bench 1M"; timeout 600 python bench.py --steps 10 --warmup 3 2> gpurun_out/bench_1M.err | tee gpurun_out/bench_1M.json
-tail -5 gpurun_out/bench_1M.err
-for wl in 100k-800-sh3 250k-512-sh0 5k-256-sh0; do
-  echo "== bench $wl"; timeout 300 python bench.py --workload $wl --steps 20 --warmup 5 --cpu-budget 0 2> gpurun_out/bench_$wl.err | tee gpurun_out/bench_$wl.json
-done
-echo "== bench 1M trained"; timeout 300 python bench.py --kind trained --steps 10 --warmup 3 --cpu-budget 0 2> gpurun_out/bench_1M_trained.err | tee gpurun_out/bench_1M_trained.json
-echo "== rocprofv3 kernel trace (1M)"
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_1M -o r01 -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --cpu-budget 0 --no-roofline > $GRAFT_REPO_ROOT/gpurun_out/prof_1M.log 2>&1)
-tail -3 gpurun_out/prof_1M.log
-find gpurun_out/prof_1M -name "*stats*" | head
+SECTIONS="${@:-tests smoke bench benchall prof}"
+R=$GRAFT_REPO_ROOT
+for s in $SECTIONS; do case $s in
+tests)
+  echo "== pytest -m gpu"; timeout 1200 python -m pytest tests -m gpu -q -p no:cacheprovider --tb=short -rf > gpurun_out/pytest_gpu.log 2>&1
+  tail -25 gpurun_out/pytest_gpu.log;;
+smoke)
+  echo "== smoke"; timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -3 | tee gpurun_out/smoke.log;;
+bench)
+  echo "== bench 1M"; timeout 900 python bench.py 2> gpurun_out/bench_1M.err | tee gpurun_out/bench_1M.json
+  tail -3 gpurun_out/bench_1M.err;;
+benchall)
+  for wl in 100k-800-sh3 250k-512-sh0 5k-256-sh0; do
+    echo "== bench $wl"; timeout 300 python bench.py --workload $wl --cpu-budget 0 2> gpurun_out/bench_$wl.err | tee gpurun_out/bench_$wl.json
+  done
+  echo "== bench 1M trained"; timeout 300 python bench.py --kind trained --cpu-budget 0 2> gpurun_out/bench_1M_trained.err | tee gpurun_out/bench_1M_trained.json;;
+prof)
+  echo "== rocprofv3 kernel trace (1M)"
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_1M -o r01 -- python $R/bench.py --steps 5 --warmup 2 --cpu-budget 0 --no-roofline > $R/gpurun_out/prof_1M.log 2>&1)
+  tail -2 gpurun_out/prof_1M.log; find gpurun_out/prof_1M -name "*stats*" | head
+  f=$(find gpurun_out/prof_1M -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -12 "$f";;
+pmc)
+  echo "== rocprofv3 PMC passes (1M)"
+  for c in FETCH_SIZE WRITE_SIZE; do
+    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_$c -o r01 -- python $R/bench.py --steps 3 --warmup 1 --cpu-budget 0 --no-roofline > $R/gpurun_out/pmc_$c.log 2>&1)
+    tail -1 gpurun_out/pmc_$c.log
+  done
+  python tools/pmc_summary.py gpurun_out 2>&1 | tail -20;;
+esac; done
