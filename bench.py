@@ -131,6 +131,7 @@ def main():
     ap.add_argument("--kind", default="blob", choices=["blob", "trained"])
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-oracle compositing; 0 disables")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--trace-steps", action="store_true", help="print every timed step's wall time to stderr")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -183,11 +184,18 @@ def main():
     for _ in range(a.warmup):
         step()
     sync()
+    trace = []
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
+        if a.trace_steps:
+            torch.cuda.synchronize()
+            trace.append(time.perf_counter())
     sync()
     dt = time.perf_counter() - t0
+    if a.trace_steps and rank == 0:
+        prev = t0
+        print("step ms:", " ".join(f"{(t - p) * 1e3:.2f}" for p, t in zip([t0] + trace[:-1], trace)), file=sys.stderr)
     if world > 1:
         td = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(td, op=dist.ReduceOp.MAX)

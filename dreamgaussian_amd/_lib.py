@@ -92,6 +92,12 @@ class Scratch:
         self._cb = RESIZE_FN(self._resize)
         self.alloc = GsrAlloc(None, self._cb)
 
+    def release(self):
+        """Drop the ctypes callback (it closes a reference cycle through the bound method, which
+        would keep the scratch tensor alive until the cyclic GC runs); keeps `tensor`."""
+        self._cb = None
+        self.alloc = None
+
     def _resize(self, _ctx, nbytes):
         try:
             self.tensor = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=self.device)

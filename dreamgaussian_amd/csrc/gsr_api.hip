@@ -10,6 +10,7 @@
 
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include <math.h>
 #include <vector>
 #include <mutex>
@@ -97,10 +98,12 @@ GeomLayout geom_layout(int N, int H, int W) {
     return L;
 }
 struct BinLayout { size_t entries, recs, total; };
-BinLayout bin_layout(size_t M) {
+BinLayout bin_layout(size_t M, bool copy) {
     BinLayout L;
     size_t o = 0;
-    L.recs = o; o += align_up(M * sizeof(SplatRec));      // first: the backward needs no M to find it
+    // first: the sorted list (64-byte records, or 4-byte Gaussian indices) -- the backward finds
+    // it at offset 0 without knowing M
+    L.recs = o; o += align_up(M * (copy ? sizeof(SplatRec) : 4));
     L.entries = o; o += align_up(M * 8);
     L.total = o < 256 ? 256 : o;
     return L;
@@ -140,7 +143,30 @@ int check_inputs(int N, int K, const GsrView* v, const float* means3D, const flo
     return 0;
 }
 
-constexpr int kHistLdsMaxTiles = 16384;   // 64 KiB of LDS histogram
+constexpr int kHistLdsMaxTiles = 16384;
+
+// GSR_RENDER_V0=1 selects the first-generation compositing kernels (scalar-load list walk) for
+// A/B measurements; the default is the LDS-staged generation.
+// GSR_SORT=bitonic selects the LDS bitonic network for every tile (default: bucket sort with
+// the network as the skew fallback). GSR_RECORDS=copy makes the sort write each tile's sorted
+// 64-byte record stream; the default (byid) keeps only sorted Gaussian indices and the
+// compositing kernels gather records from the per-Gaussian array.
+bool use_sort_bitonic() {
+    static const bool v = [] { const char* e = getenv("GSR_SORT"); return e && strcmp(e, "bitonic") == 0; }();
+    return v;
+}
+bool use_record_copy() {
+    static const bool v = [] {
+        const char* e = getenv("GSR_RECORDS");
+        const char* r = getenv("GSR_RENDER_V0");
+        return (e && strcmp(e, "copy") == 0) || (r && r[0] == '1') || use_sort_bitonic();
+    }();
+    return v;
+}
+bool use_render_v0() {
+    static const bool v = [] { const char* e = getenv("GSR_RENDER_V0"); return e && e[0] == '1'; }();
+    return v;
+}   // 64 KiB of LDS histogram
 
 }  // namespace
 
@@ -240,11 +266,13 @@ extern "C" int gsr_forward(const GsrView* view, int32_t N, int32_t K,
     if (stats) { stats->num_instances = (int64_t)M; stats->num_instances_ref = (int64_t)M_ref; stats->num_visible = (int64_t)V; stats->max_tile_count = (int64_t)maxc; }
     if (M >= 0xfffffff0ull) return fail(-5, "too many tile instances (%s%lld)", "", (long long)M);
 
-    const BinLayout BL = bin_layout((size_t)M);
+    const bool copy = use_record_copy();
+    const BinLayout BL = bin_layout((size_t)M, copy);
     char* bbuf = (char*)bin.resize(bin.ctx, BL.total);
     if (!bbuf) return fail(-4, "bin scratch allocation failed%s", "");
     unsigned long long* entries = (unsigned long long*)(bbuf + BL.entries);
     SplatRec* srecs = (SplatRec*)(bbuf + BL.recs);
+    uint32_t* sorted_ids = (uint32_t*)(bbuf + BL.recs);
 
     if (M > 0) {
         const size_t lds = hist_in_lds ? (size_t)T * 4 : 0;
@@ -253,25 +281,57 @@ extern "C" int gsr_forward(const GsrView* view, int32_t N, int32_t K,
         prof_begin(stream); hipLaunchKernelGGL(gsr_scatter, dim3(grid_n), dim3(256), lds, stream, N, emit, tile_off, cursor, entries,
                            vc.gx, T, hist_in_lds, (uint32_t)M);
         LAUNCH_CHECK(view, stream, "scatter");
-        // per-tile sort, three size classes
-        prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_lds<2048, 256>), dim3(T), dim3(256), 2048 * 8, stream, tile_off, entries, recs, srecs, 0u, 2048u);
-        LAUNCH_CHECK(view, stream, "tile_sort_small");
-        if (maxc > 2048) {
+        // per-tile sort, size classes by list length
+        SplatRec* out_recs = copy ? srecs : nullptr;
+        uint32_t* out_ids = copy ? nullptr : sorted_ids;
+        if (use_sort_bitonic()) {
+            prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_lds<2048, 256>), dim3(T), dim3(256), 2048 * 8, stream, tile_off, entries, recs, srecs, 0u, 2048u);
+            LAUNCH_CHECK(view, stream, "tile_sort_small");
+            if (maxc > 2048) {
+                static bool attr_set = false;
+                if (!attr_set) {
+                    HIP_TRY(hipFuncSetAttribute((const void*)gsr_tile_sort_lds<16384, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8));
+                    attr_set = true;
+                }
+                prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_lds<16384, 1024>), dim3(T), dim3(1024), 16384 * 8, stream, tile_off, entries, recs, srecs, 2048u, 16384u);
+                LAUNCH_CHECK(view, stream, "tile_sort_large");
+            }
+        } else {
+            constexpr size_t lds_s = 2048 * 8 + (512 + 1 + 512 + 40) * 4;
+            constexpr size_t lds_m = 8192 * 8 + (2048 + 1 + 2048 + 40) * 4;
+            constexpr size_t lds_l = 16384 * 8 + (2048 + 1 + 2048 + 40) * 4;
             static bool attr_set = false;
             if (!attr_set) {
-                HIP_TRY(hipFuncSetAttribute((const void*)gsr_tile_sort_lds<16384, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8));
+                HIP_TRY(hipFuncSetAttribute((const void*)gsr_tile_sort_bucket<8192, 1024, 2048>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
+                HIP_TRY(hipFuncSetAttribute((const void*)gsr_tile_sort_bucket<16384, 1024, 2048>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l));
                 attr_set = true;
             }
-            prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_lds<16384, 1024>), dim3(T), dim3(1024), 16384 * 8, stream, tile_off, entries, recs, srecs, 2048u, 16384u);
-            LAUNCH_CHECK(view, stream, "tile_sort_large");
+            prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<2048, 256, 512>), dim3(T), dim3(256), lds_s, stream, tile_off, entries, recs, out_recs, out_ids, 0u, 2048u);
+            LAUNCH_CHECK(view, stream, "tile_sort_small");
+            if (maxc > 2048) {
+                prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<8192, 1024, 2048>), dim3(T), dim3(1024), lds_m, stream, tile_off, entries, recs, out_recs, out_ids, 2048u, 8192u);
+                LAUNCH_CHECK(view, stream, "tile_sort_medium");
+            }
+            if (maxc > 8192) {
+                prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<16384, 1024, 2048>), dim3(T), dim3(1024), lds_l, stream, tile_off, entries, recs, out_recs, out_ids, 8192u, 16384u);
+                LAUNCH_CHECK(view, stream, "tile_sort_large");
+            }
         }
         if (maxc > 16384) {
-            prof_begin(stream); hipLaunchKernelGGL(gsr_tile_sort_global, dim3(T), dim3(1024), 0, stream, tile_off, entries, recs, srecs, 16384u);
+            prof_begin(stream); hipLaunchKernelGGL(gsr_tile_sort_global_ids, dim3(T), dim3(1024), 0, stream, tile_off, entries, recs, out_recs, out_ids, 16384u);
             LAUNCH_CHECK(view, stream, "tile_sort_global");
         }
     }
-    prof_begin(stream); hipLaunchKernelGGL(gsr_render_fwd, dim3(T), dim3(256), 0, stream, tile_off, srecs, view->bg, W, H, vc.gx,
-                       out_color, out_depth, out_alpha, final_T, n_contrib);
+    prof_begin(stream);
+    if (use_render_v0())
+        hipLaunchKernelGGL(gsr_render_fwd_v0, dim3(T), dim3(256), 0, stream, tile_off, srecs, view->bg, W, H, vc.gx,
+                           out_color, out_depth, out_alpha, final_T, n_contrib);
+    else if (copy)
+        hipLaunchKernelGGL(gsr_render_fwd<false>, dim3(T), dim3(256), 0, stream, tile_off, srecs, (const uint32_t*)nullptr, view->bg, W, H, vc.gx,
+                           out_color, out_depth, out_alpha, final_T, n_contrib);
+    else
+        hipLaunchKernelGGL(gsr_render_fwd<true>, dim3(T), dim3(256), 0, stream, tile_off, recs, sorted_ids, view->bg, W, H, vc.gx,
+                           out_color, out_depth, out_alpha, final_T, n_contrib);
     LAUNCH_CHECK(view, stream, "render_fwd");
     return 0;
 }
@@ -314,8 +374,16 @@ extern "C" int gsr_backward(const GsrView* view, int32_t N, int32_t K,
     HIP_TRY(hipMemsetAsync(g2d, 0, (size_t)N * GSR_G2D_STRIDE * 4, stream));
     prof_end(stream, "memset_bwd");
 
-    prof_begin(stream); hipLaunchKernelGGL(gsr_render_bwd, dim3(T), dim3(256), 0, stream, tile_off, srecs, view->bg, W, H, vc.gx,
-                       final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, g2d);
+    prof_begin(stream);
+    if (use_render_v0())
+        hipLaunchKernelGGL(gsr_render_bwd_v0, dim3(T), dim3(256), 0, stream, tile_off, srecs, view->bg, W, H, vc.gx,
+                           final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, g2d);
+    else if (use_record_copy())
+        hipLaunchKernelGGL(gsr_render_bwd<false>, dim3(T), dim3(256), 0, stream, tile_off, srecs, (const uint32_t*)nullptr, view->bg, W, H, vc.gx,
+                           final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, g2d);
+    else
+        hipLaunchKernelGGL(gsr_render_bwd<true>, dim3(T), dim3(256), 0, stream, tile_off, recs, (const uint32_t*)bin, view->bg, W, H, vc.gx,
+                           final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, g2d);
     LAUNCH_CHECK(view, stream, "render_bwd");
 
     const int grid_n = (int)fmin((double)((N + 255) / 256), 2048.0);

@@ -167,6 +167,131 @@ gsr_tile_sort_global(const uint32_t* __restrict__ tile_off, unsigned long long* 
     gather_records(entries + s, n, geom, out + s, 1024);
 }
 
+
+// ---------------------------------------------------------------------------------------
+// K4b: per-tile BUCKET sort (default). The bitonic network above costs log^2 passes over LDS
+// (105 barrier-separated passes for 8k keys). Depth keys of one tile are spread smoothly
+// between the tile's nearest and farthest Gaussian, so one counting pass into ~n/4 buckets
+// by linearly quantised depth (monotone => bucket order = depth order) followed by an
+// insertion sort of each few-element bucket on the full 64-bit key (depth bits, then index:
+// the same total order as the network) is O(n). A tile whose keys pile up in one bucket
+// (max bucket > kBucketLimit, e.g. thousands of equal depths) falls back to the network.
+// Output: the tile's Gaussian indices in final order (out_ids) and/or its 64-byte record
+// stream (out_recs).
+// dynamic LDS: u64 keys[CAP] | u32 off[NBMAX+1] | u32 cur[NBMAX] | u32 red[40]
+// ---------------------------------------------------------------------------------------
+constexpr uint32_t kBucketLimit = 64;
+
+template <int NT>
+__device__ __forceinline__ void block_excl_scan_u32(uint32_t* a, int n, uint32_t* wsum) {
+    const int per = (n + NT - 1) / NT;
+    const int beg = min((int)threadIdx.x * per, n), end = min(beg + per, n);
+    uint32_t local = 0;
+    for (int i = beg; i < end; ++i) local += a[i];
+    uint32_t incl = local;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    uint32_t run = base + incl - local;
+    for (int i = beg; i < end; ++i) { const uint32_t c = a[i]; a[i] = run; run += c; }
+    __syncthreads();
+}
+
+template <int CAP, int NT, int NBMAX>
+__global__ void __launch_bounds__(NT)
+gsr_tile_sort_bucket(const uint32_t* __restrict__ tile_off, const unsigned long long* __restrict__ entries,
+                     const SplatRec* __restrict__ geom, SplatRec* __restrict__ out_recs,
+                     uint32_t* __restrict__ out_ids, uint32_t lo_excl, uint32_t hi_incl) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem_raw);
+    uint32_t* off = reinterpret_cast<uint32_t*>(smem_raw + (size_t)CAP * 8);
+    uint32_t* cur = off + (NBMAX + 1);
+    uint32_t* red = cur + NBMAX;                       // [0..15] wave partials, [32] min, [33] max, [34] max bucket
+    const uint32_t s = tile_off[blockIdx.x];
+    const uint32_t n = tile_off[blockIdx.x + 1] - s;
+    if (n <= lo_excl || n > hi_incl) return;
+    const unsigned long long* __restrict__ src = entries + s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    bool use_network = n <= 512;
+    if (!use_network) {
+        uint32_t mn = 0xffffffffu, mx = 0u;
+        for (uint32_t i = threadIdx.x; i < n; i += NT) { const uint32_t d = (uint32_t)(src[i] >> 32); mn = min(mn, d); mx = max(mx, d); }
+        mx = wave_max_u32(mx);
+        mn = ~wave_max_u32(~mn);
+        if (threadIdx.x == 0) { red[32] = 0xffffffffu; red[33] = 0u; red[34] = 0u; }
+        __syncthreads();
+        if (lane == 0) { atomicMin(&red[32], mn); atomicMax(&red[33], mx); }
+        __syncthreads();
+        const float fmin = __uint_as_float(red[32]), fmax = __uint_as_float(red[33]);
+        const int NB = min(NBMAX, max(1, (int)(n >> 2)));
+        const float range = fmax - fmin;
+        const float scale = range > 0.f ? (float)NB / range : 0.f;
+        for (int b = threadIdx.x; b <= NB; b += NT) { off[b] = 0; if (b < NB) cur[b] = 0; }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += NT) {
+            const float f = __uint_as_float((uint32_t)(src[i] >> 32));
+            const int b = min((int)((f - fmin) * scale), NB - 1);
+            atomicAdd(&off[b], 1u);
+        }
+        __syncthreads();
+        uint32_t m = 0;
+        for (int b = threadIdx.x; b < NB; b += NT) m = max(m, off[b]);
+        m = wave_max_u32(m);
+        if (lane == 0) atomicMax(&red[34], m);
+        __syncthreads();
+        use_network = red[34] > kBucketLimit;             // block-uniform
+        if (!use_network) {
+            block_excl_scan_u32<NT>(off, NB + 1, red);      // off[NB] = n
+            for (uint32_t i = threadIdx.x; i < n; i += NT) {
+                const unsigned long long k = src[i];
+                const float f = __uint_as_float((uint32_t)(k >> 32));
+                const int b = min((int)((f - fmin) * scale), NB - 1);
+                keys[off[b] + atomicAdd(&cur[b], 1u)] = k;
+            }
+            __syncthreads();
+            for (int b = threadIdx.x; b < NB; b += NT) {
+                const uint32_t lo = off[b], hi = off[b + 1];
+                for (uint32_t i = lo + 1; i < hi; ++i) {
+                    const unsigned long long k = keys[i];
+                    uint32_t j = i;
+                    while (j > lo && keys[j - 1] > k) { keys[j] = keys[j - 1]; --j; }
+                    keys[j] = k;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (use_network) {
+        for (uint32_t i = threadIdx.x; i < n; i += NT) keys[i] = src[i];
+        __syncthreads();
+        bitonic_sort(keys, n, NT);
+    }
+    (void)wave;
+    if (out_ids) for (uint32_t i = threadIdx.x; i < n; i += NT) out_ids[s + i] = (uint32_t)keys[i];
+    if (out_recs) gather_records(keys, n, geom, out_recs + s, NT);
+}
+
+// lists longer than the largest LDS class: network in place in HBM, then the same outputs
+extern "C" __global__ void __launch_bounds__(1024)
+gsr_tile_sort_global_ids(const uint32_t* __restrict__ tile_off, unsigned long long* __restrict__ entries,
+                         const SplatRec* __restrict__ geom, SplatRec* __restrict__ out_recs,
+                         uint32_t* __restrict__ out_ids, uint32_t lo_excl) {
+    const uint32_t s = tile_off[blockIdx.x];
+    const uint32_t n = tile_off[blockIdx.x + 1] - s;
+    if (n <= lo_excl) return;
+    bitonic_sort(entries + s, n, 1024);
+    if (out_ids) for (uint32_t i = threadIdx.x; i < n; i += 1024) out_ids[s + i] = (uint32_t)entries[s + i];
+    if (out_recs) gather_records(entries + s, n, geom, out_recs + s, 1024);
+}
+
+template __global__ void gsr_tile_sort_bucket<2048, 256, 512>(const uint32_t*, const unsigned long long*, const SplatRec*, SplatRec*, uint32_t*, uint32_t, uint32_t);
+template __global__ void gsr_tile_sort_bucket<8192, 1024, 2048>(const uint32_t*, const unsigned long long*, const SplatRec*, SplatRec*, uint32_t*, uint32_t, uint32_t);
+template __global__ void gsr_tile_sort_bucket<16384, 1024, 2048>(const uint32_t*, const unsigned long long*, const SplatRec*, SplatRec*, uint32_t*, uint32_t, uint32_t);
+
 template __global__ void gsr_tile_sort_lds<2048, 256>(const uint32_t*, const unsigned long long*,
                                                       const SplatRec*, SplatRec*, uint32_t, uint32_t);
 template __global__ void gsr_tile_sort_lds<16384, 1024>(const uint32_t*, const unsigned long long*,

@@ -12,14 +12,16 @@
 // stage). 64 B = one s_load_dwordx16: the render kernels read records with SCALAR loads
 // because every lane of a wave consumes the same Gaussian.
 struct __attribute__((aligned(16))) SplatRec {
+    // dwords 0..11: everything the forward compositing needs (three 16-byte loads)
     float x, y;        // projected mean, pixel coordinates
     float qa, qb;      // -0.5*A*log2e, -B*log2e      (conic A,B,C; G = exp2(qa dx^2 + qb dx dy + qc dy^2))
     float qc, opac;    // -0.5*C*log2e, opacity
     float r, g;        // colour (after +0.5 and clamp at 0)
     float b, depth;    // view-space z
-    uint32_t id;       // Gaussian index
     uint32_t bbx;      // int16 xmin | int16 xmax << 16 : pixel columns where alpha can reach 1/255
     uint32_t bby;      // same for rows
+    // dwords 12..15: backward / binning only
+    uint32_t id;       // Gaussian index
     uint32_t rectx;    // emission tile rect  x0 | x1 << 16   (x1 exclusive)
     uint32_t recty;    //                     y0 | y1 << 16
     uint32_t flags;    // bit0..2 colour channel clamped at 0; bit3 emits instances
@@ -80,6 +82,45 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
         v = v + __int_as_float(m);
     }
     return v;
+}
+
+// ---- transposing wave reduction (gfx950 v_permlane32_swap / v_permlane16_swap) -------------
+// red32(a,b): lanes of one half hold sum over {l, l^32} of a, the other half the same for b.
+__device__ __forceinline__ float red32(float a, float b) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// red16(a,b): same one level down (16-lane rows): alternate rows hold a-sums and b-sums.
+__device__ __forceinline__ float red16(float a, float b) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// the same data movement applied to integer tags (which quantity a lane ends up holding)
+__device__ __forceinline__ uint32_t tag32(uint32_t a, uint32_t b) {
+    return __builtin_amdgcn_permlane32_swap(a, b, false, false)[0];
+}
+__device__ __forceinline__ uint32_t tag16(uint32_t a, uint32_t b) {
+    return __builtin_amdgcn_permlane16_swap(a, b, false, false)[0];
+}
+#define DPP_ROW_ROR(n) (0x120 + (n))
+// every lane of a 16-lane row receives the row's total
+__device__ __forceinline__ float row_sum16(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_ROW_ROR(8), 0xf, 0xf, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_ROW_ROR(4), 0xf, 0xf, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_ROW_ROR(2), 0xf, 0xf, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_ROW_ROR(1), 0xf, 0xf, false));
+    return v;
+}
+// number of set bits of `mask` below this lane
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+// LDS produced and consumed by the SAME wave: DS operations of a wave execute in order, only the
+// compiler must be kept from reordering around the hand-off
+__device__ __forceinline__ void wave_lds_handoff() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {

@@ -21,7 +21,7 @@ __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcp
 }
 
 extern "C" __global__ void __launch_bounds__(256)
-gsr_render_fwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict__ recs,
+gsr_render_fwd_v0(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict__ recs,
                const float* __restrict__ bg, int W, int H, int gx,
                float* __restrict__ out_color, float* __restrict__ out_depth,
                float* __restrict__ out_alpha, float* __restrict__ final_T,
@@ -74,7 +74,7 @@ gsr_render_fwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict
 }
 
 extern "C" __global__ void __launch_bounds__(256)
-gsr_render_bwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict__ recs,
+gsr_render_bwd_v0(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict__ recs,
                const float* __restrict__ bg, int W, int H, int gx,
                const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
                const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
@@ -158,3 +158,259 @@ gsr_render_bwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict
         }
     }
 }
+
+
+// =========================================================================================
+// v1: per-wave LDS staging.
+//
+// v0 above reads one record per iteration with a scalar load and stalls for its full latency
+// (measured 290 cycles per list entry at 1M Gaussians). v1 keeps the "four independent waves,
+// 8x8 pixels each, no workgroup barrier" structure but moves the list walk off the latency
+// path: a wave fetches 64 consecutive list entries with vector loads (one record per lane),
+// tests each record's alpha>=1/255 box against its own 8x8 block in parallel, compacts the
+// survivors into a private LDS ring (ballot + mbcnt prefix) and then runs the per-pixel loop
+// over the survivors only, reading them back with wave-uniform (broadcast) ds_read_b128
+// issued one entry ahead of their use (two-entry ping-pong, no register renaming).
+// BY_ID: the list holds Gaussian indices and records are gathered from the per-Gaussian array
+// (no sorted 64-byte copy per instance); otherwise the list IS the sorted record stream.
+// =========================================================================================
+#define GSR_RB 64   // list entries fetched per wave per round
+
+template <bool BY_ID>
+__device__ __forceinline__ const float4* list_record(const SplatRec* __restrict__ recs,
+                                                     const uint32_t* __restrict__ ids, uint32_t i) {
+    return reinterpret_cast<const float4*>(BY_ID ? recs + ids[i] : recs + i);
+}
+
+template <bool BY_ID>
+__global__ void __launch_bounds__(256)
+gsr_render_fwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict__ recs,
+               const uint32_t* __restrict__ ids,
+               const float* __restrict__ bg, int W, int H, int gx,
+               float* __restrict__ out_color, float* __restrict__ out_depth,
+               float* __restrict__ out_alpha, float* __restrict__ final_T,
+               uint32_t* __restrict__ n_contrib) {
+    __shared__ float4 stage[4][3][GSR_RB];                 // 12 KiB: [wave][field group][slot]
+    const int tile = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int bx = (tile % gx) * GSR_TILE + (wave & 1) * 8;
+    const int by = (tile / gx) * GSR_TILE + (wave >> 1) * 8;
+    if (bx >= W || by >= H) return;                       // whole block outside the image
+    const int px = bx + (lane & 7), py = by + (lane >> 3);
+    const bool inside = (px < W) && (py < H);
+    const float pxf = (float)px, pyf = (float)py;
+    const uint32_t start = tile_off[tile], end = tile_off[tile + 1];
+    float4* __restrict__ sa = stage[wave][0];
+    float4* __restrict__ sb = stage[wave][1];
+    float4* __restrict__ sc = stage[wave][2];
+
+    float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, A = 0.f;
+    uint32_t last = 0;
+    bool done = !inside;
+
+    // ea = x y qa qb | eb = qc opac r g | ec = b depth pos -
+#define GSR_FWD_ENTRY(ea, eb, ec)                                                              \
+    {                                                                                          \
+        const float dx = ea.x - pxf, dy = ea.y - pyf;                                          \
+        const float power = ea.z * dx * dx + eb.x * dy * dy + ea.w * dx * dy; /* log2 units */ \
+        const float alpha = fminf(0.99f, eb.y * fast_exp2(power));                             \
+        const bool ok = !done && (power <= 0.f) && (alpha >= (1.0f / 255.0f));                 \
+        const float test_T = T * (1.f - alpha);                                                \
+        const bool stop = ok && (test_T < 0.0001f);                                            \
+        const bool acc = ok && !stop;                                                          \
+        const float w = acc ? alpha * T : 0.f;                                                 \
+        C0 += eb.z * w; C1 += eb.w * w; C2 += ec.x * w;                                        \
+        D += ec.y * w; A += w;                                                                 \
+        T = acc ? test_T : T;                                                                  \
+        last = acc ? __float_as_uint(ec.z) : last;                                             \
+        done = done || stop;                                                                   \
+    }
+
+    for (uint32_t base = start; base < end; base += GSR_RB) {
+        if (__ballot(!done) == 0ull) break;
+        const uint32_t i = base + lane;
+        bool hit = false;
+        float4 ra, rb, rc;
+        if (i < end) {
+            const float4* __restrict__ p = list_record<BY_ID>(recs, ids, i);
+            ra = p[0]; rb = p[1]; rc = p[2];
+            const uint32_t bbx = __float_as_uint(rc.z), bby = __float_as_uint(rc.w);
+            hit = !(unpack_hi16(bbx) < bx || unpack_lo16(bbx) > bx + 7 ||
+                    unpack_hi16(bby) < by || unpack_lo16(bby) > by + 7);
+        }
+        const unsigned long long mask = __ballot(hit);
+        if (mask == 0ull) continue;
+        const int n = __popcll(mask);
+        if (hit) {
+            const uint32_t pos = lanes_below(mask);
+            rc.z = __uint_as_float(i - start + 1);        // 1-based list position replaces the box
+            sa[pos] = ra; sb[pos] = rb; sc[pos] = rc;
+        }
+        wave_lds_handoff();
+        float4 e0a = sa[0], e0b = sb[0], e0c = sc[0];
+        for (int j = 0; j < n; j += 2) {
+            const int j1 = min(j + 1, n - 1);
+            const float4 e1a = sa[j1], e1b = sb[j1], e1c = sc[j1];   // in flight during entry j
+            GSR_FWD_ENTRY(e0a, e0b, e0c)
+            const int j2 = min(j + 2, n - 1);
+            e0a = sa[j2]; e0b = sb[j2]; e0c = sc[j2];                // in flight during entry j+1
+            if (j + 1 < n) GSR_FWD_ENTRY(e1a, e1b, e1c)
+        }
+        wave_lds_handoff();                               // reads above precede the next round's writes
+    }
+#undef GSR_FWD_ENTRY
+    if (inside) {
+        const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
+        final_T[pix] = T;
+        n_contrib[pix] = last;
+        out_color[pix] = C0 + T * bg[0];
+        out_color[HW + pix] = C1 + T * bg[1];
+        out_color[2 * HW + pix] = C2 + T * bg[2];
+        out_depth[pix] = D;
+        out_alpha[pix] = A;
+    }
+}
+
+// Backward, same staging walked back to front. The ten per-Gaussian sums leave the wave through
+// a transposing reduction: v_permlane32_swap / v_permlane16_swap fold ten registers into three
+// whose 16-lane rows each carry one quantity, four DPP row rotations finish the rows, and
+// three atomic instructions (one lane per row) add them to the Gaussian's accumulator -- 28
+// cross-lane instructions and 3 atomics per (block, Gaussian) instead of 60 and 10.
+template <bool BY_ID>
+__global__ void __launch_bounds__(256)
+gsr_render_bwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict__ recs,
+               const uint32_t* __restrict__ ids,
+               const float* __restrict__ bg, int W, int H, int gx,
+               const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+               const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
+               const float* __restrict__ dL_dalpha, float* __restrict__ g2d) {
+    __shared__ float4 stage[4][4][GSR_RB];                 // 16 KiB
+    const int tile = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int bx = (tile % gx) * GSR_TILE + (wave & 1) * 8;
+    const int by = (tile / gx) * GSR_TILE + (wave >> 1) * 8;
+    if (bx >= W || by >= H) return;
+    const int px = bx + (lane & 7), py = by + (lane >> 3);
+    const bool inside = (px < W) && (py < H);
+    const float pxf = (float)px, pyf = (float)py;
+    const uint32_t start = tile_off[tile];
+    float4* __restrict__ sa = stage[wave][0];
+    float4* __restrict__ sb = stage[wave][1];
+    float4* __restrict__ sc = stage[wave][2];
+    float4* __restrict__ sd = stage[wave][3];
+
+    // which accumulator slot each lane's reduced registers carry: push the slot numbers through
+    // the same swap network once (robust to the swap direction convention)
+    const uint32_t slot0 = tag16(tag32(0u, 5u), tag32(1u, 6u));
+    const uint32_t slot1 = tag16(tag32(2u, 7u), tag32(3u, 8u));
+    const uint32_t slot2 = tag16(tag32(4u, 9u), tag32(10u, 11u));   // 10, 11: padding slots (zeros)
+    const bool row_leader = (lane & 15) == 0;
+
+    float T_final = 1.f, gC0 = 0.f, gC1 = 0.f, gC2 = 0.f, gD = 0.f, gA = 0.f;
+    uint32_t last_contrib = 0;
+    if (inside) {
+        const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
+        T_final = final_T[pix];
+        last_contrib = n_contrib[pix];
+        gC0 = dL_dcolor[pix]; gC1 = dL_dcolor[HW + pix]; gC2 = dL_dcolor[2 * HW + pix];
+        gD = dL_ddepth[pix]; gA = dL_dalpha[pix];
+    }
+    const float bg_dot = bg[0] * gC0 + bg[1] * gC1 + bg[2] * gC2;
+    const int wave_last = (int)__builtin_amdgcn_readfirstlane(wave_max_u32(last_contrib));
+
+    float T = T_final;
+    float accC0 = 0.f, accC1 = 0.f, accC2 = 0.f, accD = 0.f, accA = 0.f;
+    float last_alpha = 0.f, lastC0 = 0.f, lastC1 = 0.f, lastC2 = 0.f, lastD = 0.f;
+
+    // ea = x y qa qb | eb = qc opac r g | ec = b depth pos - | ed = id - - -
+#define GSR_BWD_ENTRY(ea, eb, ec, ed)                                                            \
+    {                                                                                            \
+        const float qa = ea.z, qb = ea.w, qc = eb.x, opac = eb.y;                                \
+        const float cr = eb.z, cg = eb.w, cb = ec.x, cdepth = ec.y;                              \
+        const uint32_t kpos = __float_as_uint(ec.z);                                             \
+        const float dx = ea.x - pxf, dy = ea.y - pyf;                                            \
+        const float power = qa * dx * dx + qc * dy * dy + qb * dx * dy;                          \
+        const float G = fast_exp2(power);                                                        \
+        const float alpha = fminf(0.99f, opac * G);                                              \
+        const bool ok = (kpos <= last_contrib) && (power <= 0.f) && (alpha >= (1.0f / 255.0f));  \
+        if (__ballot(ok) != 0ull) {                       /* somebody in this block blended it */ \
+            float dL_dal = 0.f, w = 0.f;                  /* stay 0 in lanes that did not blend */  \
+            if (ok) {                                                                            \
+                const float oma_inv = fast_rcp(1.f - alpha);                                     \
+                T = T * oma_inv;                                                                 \
+                w = alpha * T;                                                                   \
+                accC0 = last_alpha * lastC0 + (1.f - last_alpha) * accC0; lastC0 = cr;           \
+                accC1 = last_alpha * lastC1 + (1.f - last_alpha) * accC1; lastC1 = cg;           \
+                accC2 = last_alpha * lastC2 + (1.f - last_alpha) * accC2; lastC2 = cb;           \
+                accD = last_alpha * lastD + (1.f - last_alpha) * accD; lastD = cdepth;           \
+                accA = last_alpha + (1.f - last_alpha) * accA;                                   \
+                dL_dal = (cr - accC0) * gC0 + (cg - accC1) * gC1 + (cb - accC2) * gC2            \
+                       + (cdepth - accD) * gD + (1.f - accA) * gA;                               \
+                dL_dal *= T;                                                                     \
+                last_alpha = alpha;                                                              \
+                dL_dal += (-T_final * oma_inv) * bg_dot;                                         \
+            }                                                                                    \
+            const float Gm = ok ? G : 0.f;                /* G may be inf where power > 0 */      \
+            const float dL_dG = opac * dL_dal;                                                   \
+            const float gdx = Gm * dx, gdy = Gm * dy;                                            \
+            const float v0 = dL_dG * (2.f * qa * gdx + qb * gdy);  /* mean2D.x (ln2*0.5W in K6) */ \
+            const float v1 = dL_dG * (2.f * qc * gdy + qb * gdx);  /* mean2D.y */                \
+            const float v2 = -0.5f * gdx * dx * dL_dG;             /* dL/dA */                   \
+            const float v3 = -gdx * dy * dL_dG;                    /* dL/dB */                   \
+            const float v4 = -0.5f * gdy * dy * dL_dG;             /* dL/dC */                   \
+            const float v5 = Gm * dL_dal;                          /* dL/dopacity */             \
+            const float v6 = w * gC0, v7 = w * gC1, v8 = w * gC2;  /* dL/drgb */                 \
+            const float v9 = w * gD;                               /* dL/ddepth */               \
+            const float t0 = row_sum16(red16(red32(v0, v5), red32(v1, v6)));                     \
+            const float t1 = row_sum16(red16(red32(v2, v7), red32(v3, v8)));                     \
+            const float t2 = row_sum16(red16(red32(v4, v9), 0.f));                               \
+            if (row_leader) {                                                                    \
+                const uint32_t gid = __builtin_amdgcn_readfirstlane(__float_as_uint(ed.x));      \
+                float* dst = g2d + (size_t)gid * GSR_G2D_STRIDE;                                 \
+                atomicAdd(dst + slot0, t0);                                                      \
+                atomicAdd(dst + slot1, t1);                                                      \
+                if (slot2 < 10u) atomicAdd(dst + slot2, t2);                                     \
+            }                                                                                    \
+        }                                                                                        \
+    }
+
+    for (int hi = wave_last; hi > 0; hi -= GSR_RB) {      // list positions (hi-64, hi], 1-based
+        const int k = hi - lane;                          // lane 0 holds the farthest entry
+        bool hit = false;
+        float4 ra, rb, rc, rd;
+        if (k >= 1) {
+            const float4* __restrict__ p = list_record<BY_ID>(recs, ids, start + (uint32_t)k - 1u);
+            ra = p[0]; rb = p[1]; rc = p[2]; rd = p[3];
+            const uint32_t bbx = __float_as_uint(rc.z), bby = __float_as_uint(rc.w);
+            hit = !(unpack_hi16(bbx) < bx || unpack_lo16(bbx) > bx + 7 ||
+                    unpack_hi16(bby) < by || unpack_lo16(bby) > by + 7);
+        }
+        const unsigned long long mask = __ballot(hit);
+        if (mask == 0ull) continue;
+        const int n = __popcll(mask);
+        if (hit) {
+            const uint32_t pos = lanes_below(mask);       // ascending lane = descending position
+            rc.z = __uint_as_float((uint32_t)k);
+            sa[pos] = ra; sb[pos] = rb; sc[pos] = rc; sd[pos] = rd;
+        }
+        wave_lds_handoff();
+        float4 e0a = sa[0], e0b = sb[0], e0c = sc[0], e0d = sd[0];
+        for (int j = 0; j < n; j += 2) {
+            const int j1 = min(j + 1, n - 1);
+            const float4 e1a = sa[j1], e1b = sb[j1], e1c = sc[j1], e1d = sd[j1];
+            GSR_BWD_ENTRY(e0a, e0b, e0c, e0d)
+            const int j2 = min(j + 2, n - 1);
+            e0a = sa[j2]; e0b = sb[j2]; e0c = sc[j2]; e0d = sd[j2];
+            if (j + 1 < n) GSR_BWD_ENTRY(e1a, e1b, e1c, e1d)
+        }
+        wave_lds_handoff();
+    }
+#undef GSR_BWD_ENTRY
+}
+
+template __global__ void gsr_render_fwd<false>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, float*, float*, float*, float*, uint32_t*);
+template __global__ void gsr_render_fwd<true>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, float*, float*, float*, float*, uint32_t*);
+template __global__ void gsr_render_bwd<false>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, const float*, const uint32_t*, const float*, const float*, const float*, float*);
+template __global__ void gsr_render_bwd<true>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, const float*, const uint32_t*, const float*, const float*, const float*, float*);

@@ -26,5 +26,6 @@ def distCUDA2(points: torch.Tensor) -> torch.Tensor:
     with torch.cuda.device(dev):
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         rc = lib.gsr_dist2(P, _lib.ptr(pts), _lib.ptr(out), tmp.alloc, stream)
+    tmp.release()
     _lib.check(rc, "gsr_dist2")
     return out

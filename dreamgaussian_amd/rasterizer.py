@@ -98,7 +98,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
         depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
         alpha = torch.empty(1, H, W, dtype=torch.float32, device=dev)
-        radii = torch.zeros(N, dtype=torch.int32, device=dev)
+        radii = torch.empty(N, dtype=torch.int32, device=dev)     # every element written by K1
         geom, binb, img = _lib.Scratch(dev), _lib.Scratch(dev), _lib.Scratch(dev)
         stats = _lib.GsrStats()
         with torch.cuda.device(dev):
@@ -108,6 +108,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                                  _lib.ptr(op), _lib.ptr(sc), _lib.ptr(rot), _lib.ptr(cov),
                                  _lib.ptr(color), _lib.ptr(depth), _lib.ptr(alpha), _lib.ptr(radii),
                                  geom.alloc, binb.alloc, img.alloc, C.byref(stats), stream)
+        for sc_ in (geom, binb, img):
+            sc_.release()
         _lib.check(rc, "gsr_forward")
         _last_stats.update(M=stats.num_instances, M_ref=stats.num_instances_ref,
                            V=stats.num_visible, max_tile=stats.max_tile_count, N=N, H=H, W=W, K=K)
@@ -139,7 +141,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         z = lambda g, shape: (torch.zeros(shape, dtype=torch.float32, device=dev) if g is None
                               else g.to(torch.float32).contiguous())
         gc, gd, ga = z(grad_color, (3, H, W)), z(grad_depth, (1, H, W)), z(grad_alpha, (1, H, W))
-        f = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        # K6 writes every element of every gradient (exact zeros for culled Gaussians): no memset
+        f = lambda *s: (torch.empty if N > 0 else torch.zeros)(*s, dtype=torch.float32, device=dev)
         d_m3, d_m2, d_op = f(N, 3), f(N, 3), f(N, 1)
         d_sh = f(N, K, 3) if has_sh else None
         d_col = f(N, 3) if has_col else None
@@ -158,6 +161,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                     P(cov) if has_cov else None, P(radii), P(gc), P(gd), P(ga),
                     P(geom), P(binb), P(img), P(d_m3), P(d_m2), P(d_sh), P(d_col), P(d_op),
                     P(d_sc), P(d_rot), P(d_cov), tmp.alloc, stream)
+            tmp.release()
             _lib.check(rc, "gsr_backward")
         s = ctx.shapes
         rs_ = lambda g, shape: None if g is None or shape is None else g.reshape(shape)

@@ -10,6 +10,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
 def pytest_configure(config):
+    import torch
+    # the GPU box has 256 host cores; torch's CPU ops (the oracle) crawl with that many threads
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` on the GPU box)")
 
 

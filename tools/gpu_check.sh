@@ -12,7 +12,7 @@ tests)
 smoke)
   echo "== smoke"; timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -3 | tee gpurun_out/smoke.log;;
 bench)
-  echo "== bench 1M"; timeout 900 python bench.py 2> gpurun_out/bench_1M.err | tee gpurun_out/bench_1M.json
+  echo "== bench 1M"; timeout 900 python bench.py $BENCH_ARGS 2> gpurun_out/bench_1M.err | tee gpurun_out/bench_1M.json
   tail -3 gpurun_out/bench_1M.err;;
 benchall)
   for wl in 100k-800-sh3 250k-512-sh0 5k-256-sh0; do
@@ -24,6 +24,13 @@ prof)
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_1M -o r01 -- python $R/bench.py --steps 5 --warmup 2 --cpu-budget 0 --no-roofline > $R/gpurun_out/prof_1M.log 2>&1)
   tail -2 gpurun_out/prof_1M.log; find gpurun_out/prof_1M -name "*stats*" | head
   f=$(find gpurun_out/prof_1M -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -12 "$f";;
+ab)
+  # A/B of the env-selectable variants: parity suite + 1M bench for each
+  for v in "" "GSR_RECORDS=copy" "GSR_SORT=bitonic" "GSR_RENDER_V0=1"; do
+    echo "== variant [$v] tests"; env $v timeout 600 python -m pytest tests -m gpu -q -p no:cacheprovider --tb=line -x 2>&1 | tail -4
+    echo "== variant [$v] bench 1M"; env $v timeout 300 python bench.py --cpu-budget 0 --trace-steps 2>gpurun_out/ab_err.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['ms_per_step_with_events'], d['kernels_ms_per_step'])"
+    grep "step ms" gpurun_out/ab_err.log
+  done;;
 pmc)
   echo "== rocprofv3 PMC passes (1M)"
   for c in FETCH_SIZE WRITE_SIZE; do
