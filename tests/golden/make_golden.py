@@ -107,14 +107,15 @@ def part2():
          torch.rand(1, H, W, generator=g, dtype=torch.float64)]
     t = {k: v.double().requires_grad_(True) for k, v in sc.items()}
     m2d = torch.zeros(N, 3, dtype=torch.float64, requires_grad=True)
-    c, r, d, a = O.rasterize(t["means3D"], m2d, t["opacities"], S, shs=t["shs"], scales=t["scales"],
-                             rotations=t["rotations"])
+    c, r, d, a, aux = O.rasterize(t["means3D"], m2d, t["opacities"], S, shs=t["shs"], scales=t["scales"],
+                                  rotations=t["rotations"], return_aux=True)
     torch.autograd.backward([c, d, a], w)
     out = {f"in_{k}": v.numpy() for k, v in sc.items()}
     out.update(pose=O.orbit_pose(-15.0, 40.0, 2.0), W=W, H=H, deg=deg,
                w_color=w[0].numpy(), w_depth=w[1].numpy(), w_alpha=w[2].numpy(),
                color=c.detach().numpy(), radii=r.numpy(), depth=d.detach().numpy(), alpha=a.detach().numpy(),
-               grad_means2D=m2d.grad.numpy())
+               grad_means2D=m2d.grad.numpy(), fragile_pixels=aux["fragile_pixels"].numpy(),
+               fragile_gaussians=aux["fragile_gaussians"].numpy())
     out.update({f"grad_{k}": v.grad.numpy() for k, v in t.items()})
     np.savez_compressed(os.path.join(HERE, "oracle_render_small.npz"), **out)
     print("wrote oracle_render_small.npz")

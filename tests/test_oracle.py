@@ -36,6 +36,21 @@ def test_float64_and_float32_agree():
         assert (g32[k].double() - g64[k]).abs().max() <= 2e-3 * g64[k].abs().max() + 1e-9, k
 
 
+def test_fragile_decisions_explain_every_fp32_vs_fp64_difference():
+    """The oracle flags (pixel, Gaussian) pairs whose discrete tests sit within fp32 noise of their
+    threshold. Outside the flagged pixels / Gaussians the float32 and float64 oracles must agree
+    strictly -- the same rule the GPU parity tests apply (this scene has one real flip)."""
+    from util import assert_forward_close, assert_grads_close, grad_floors
+    sc = O.make_scene(2000, 2, 0, "blob")
+    S = O.make_settings(O.orbit_pose(0.0, 180.0, 2.0), 320, 96, sh_degree=2)
+    w = weights_for(96, 320)
+    o64, g64, aux = run_oracle(sc, S, w, torch.float64)
+    o32, g32, _ = run_oracle(sc, S, w, torch.float32)
+    assert 0 < int(aux["fragile_pixels"].sum()) < 50 and int(aux["fragile_gaussians"].sum()) < 50
+    assert_forward_close(o32, o64, aux)
+    assert_grads_close(g32, g64, aux, floors=grad_floors(sc, g64))
+
+
 def test_culled_gaussians_have_zero_radius_and_zero_grads():
     sc, S = scene(N=300)
     sc["means3D"][:50, 2] += 5.0          # behind the camera at z=+2 looking down -z(world)

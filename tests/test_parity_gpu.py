@@ -46,8 +46,8 @@ def test_forward_backward_match_oracle(gpu, case):
     ho, hg, st = run_hip(sc, S, gpu, w)
     oo, og, aux = run_oracle(sc, S, w, torch.float64)
     assert abs(st["M_ref"] - aux["M"]) <= 1e-4 * aux["M"] + 8 and st["V"] == aux["V"]
-    assert_forward_close(ho, oo)
-    assert_grads_close(hg, og, floors=grad_floors(sc, og))
+    assert_forward_close(ho, oo, aux)
+    assert_grads_close(hg, og, aux, floors=grad_floors(sc, og))
 
 
 def test_committed_golden_vector(gpu, golden_dir):
@@ -58,8 +58,9 @@ def test_committed_golden_vector(gpu, golden_dir):
     ho, hg, _ = run_hip(sc, S, gpu, w)
     oo = [torch.from_numpy(z["color"]), torch.from_numpy(z["radii"]), torch.from_numpy(z["depth"]), torch.from_numpy(z["alpha"])]
     og = {k: torch.from_numpy(z[f"grad_{k}"]) for k in ("means3D", "shs", "opacities", "scales", "rotations", "means2D")}
-    assert_forward_close(ho, oo)
-    assert_grads_close(hg, og, floors=grad_floors(sc, og))
+    aux = dict(fragile_pixels=torch.from_numpy(z["fragile_pixels"]), fragile_gaussians=torch.from_numpy(z["fragile_gaussians"]))
+    assert_forward_close(ho, oo, aux)
+    assert_grads_close(hg, og, aux, floors=grad_floors(sc, og))
 
 
 def test_precomputed_colors_and_covariance(gpu):
@@ -72,9 +73,9 @@ def test_precomputed_colors_and_covariance(gpu):
     sc2 = dict(means3D=sc["means3D"], opacities=sc["opacities"], colors_precomp=col, cov3D_precomp=cov6)
     w = weights_for(H, W)
     ho, hg, _ = run_hip(sc2, S, gpu, w)
-    oo, og, _ = run_oracle(sc2, S, w, torch.float64)
-    assert_forward_close(ho, oo)
-    assert_grads_close(hg, og, floors=grad_floors(sc, og))
+    oo, og, aux = run_oracle(sc2, S, w, torch.float64)
+    assert_forward_close(ho, oo, aux)
+    assert_grads_close(hg, og, aux, floors=grad_floors(sc, og))
 
 
 def test_scale_modifier_and_culling(gpu):
@@ -87,12 +88,12 @@ def test_scale_modifier_and_culling(gpu):
     S = O.make_settings(O.orbit_pose(0.0, 0.0, 2.0), W, H, sh_degree=1, scale_modifier=0.6)
     w = weights_for(H, W)
     ho, hg, _ = run_hip(sc, S, gpu, w)
-    oo, og, _ = run_oracle(sc, S, w, torch.float64)
+    oo, og, aux = run_oracle(sc, S, w, torch.float64)
     assert (ho[1][:100] == 0).all()
     for k in hg:
         assert hg[k][:100].abs().max() == 0, k
-    assert_forward_close(ho, oo)
-    assert_grads_close(hg, og, floors=grad_floors(sc, og))
+    assert_forward_close(ho, oo, aux)
+    assert_grads_close(hg, og, aux, floors=grad_floors(sc, og))
 
 
 def test_empty_single_and_background_only(gpu):
@@ -106,9 +107,9 @@ def test_empty_single_and_background_only(gpu):
     for n in (1, 2, 65):
         sc = O.make_scene(n, 0, 0, "blob")
         ho, hg, _ = run_hip(sc, S, gpu, weights_for(24, 40))
-        oo, og, _ = run_oracle(sc, S, weights_for(24, 40), torch.float64)
-        assert_forward_close(ho, oo)
-        assert_grads_close(hg, og, floors=grad_floors(sc, og))
+        oo, og, aux = run_oracle(sc, S, weights_for(24, 40), torch.float64)
+        assert_forward_close(ho, oo, aux)
+        assert_grads_close(hg, og, aux, floors=grad_floors(sc, og))
 
 
 def test_mark_visible(gpu):
@@ -134,9 +135,9 @@ def test_depth_ties_and_heavy_tile(gpu):
     w = weights_for(H, W)
     ho, hg, st = run_hip(sc, S, gpu, w)
     assert st["max_tile"] > 2048
-    oo, og, _ = run_oracle(sc, S, w, torch.float64)
-    assert_forward_close(ho, oo)
-    assert_grads_close(hg, og, floors=grad_floors(sc, og))
+    oo, og, aux = run_oracle(sc, S, w, torch.float64)
+    assert_forward_close(ho, oo, aux)
+    assert_grads_close(hg, og, aux, floors=grad_floors(sc, og))
 
 
 @pytest.mark.parametrize("N,deg,size", [(100_000, 3, 800), (1_000_000, 3, 800)], ids=["cfg1_100k", "cfg2_1M"])
@@ -183,9 +184,9 @@ def test_full_size_subsample_against_oracle(gpu):
     S = O.make_settings(O.orbit_pose(0, 0, 2.0), 800, 800, sh_degree=3)
     w = weights_for(800, 800)
     ho, hg, _ = run_hip(sc, S, gpu, w)
-    oo, og, _ = run_oracle(sc, S, w, torch.float32)
-    assert_forward_close(ho, oo, atol=5e-5)
-    assert_grads_close(hg, og, rtol=5e-4, floors=grad_floors(sc, og))       # fp32 oracle here: its own rounding is ~1e-4
+    oo, og, aux = run_oracle(sc, S, w, torch.float32)
+    assert_forward_close(ho, oo, aux, atol=5e-5)
+    assert_grads_close(hg, og, aux, rtol=5e-4, floors=grad_floors(sc, og))       # fp32 oracle here: its own rounding is ~1e-4
 
 
 def test_gradient_holder_protocol(gpu):

@@ -52,12 +52,16 @@ FWD_ATOL = 2e-5          # color / alpha, absolute (values are O(1)); depth rela
 GRAD_RTOL = 1e-4         # per attribute, relative to that attribute's max |grad| (float64 oracle as arbiter)
 
 
-def assert_forward_close(ho, oo, atol=FWD_ATOL, outlier_frac=2e-5, outlier_abs=8e-3):
-    """radii equal up to boundary flips; color/depth/alpha within atol (depth: atol * max depth).
-    Discrete per-(pixel,Gaussian) decisions (alpha >= 1/255, T(1-alpha) >= 1e-4) sit on fp32
-    boundaries for ~1e-6 of the evaluated pairs (v_exp_f32 vs libm exp), i.e. a flip every million
-    pairs or so: up to 2 + outlier_frac * npixels PIXELS may differ by up to one minimal
-    contribution (2/255 of the value range); every other value must be within atol."""
+FRAGILE_ABS = 8e-3       # a pixel with an ambiguous discrete decision may differ by one minimal contribution (2/255)
+FRAGILE_GRAD_REL = 5e-2  # ... and the Gaussian of that pair by its single-pair gradient share
+
+
+def assert_forward_close(ho, oo, aux=None, atol=FWD_ATOL):
+    """radii equal up to boundary flips; color/depth/alpha within atol (depth: atol * max depth)
+    on every pixel, except pixels where the ORACLE flags an ambiguous discrete decision
+    (aux["fragile_pixels"]: an alpha >= 1/255 or T(1-alpha) >= 1e-4 test within fp32 evaluation
+    noise of its threshold -- any two fp32 implementations may decide those differently), which
+    must be within one minimal contribution (FRAGILE_ABS)."""
     dr = (ho[1].to(torch.int64) - oo[1].to(torch.int64)).abs()
     # radius = ceil(3 sqrt(lambda)) is discontinuous: fp32 rounding differences (fma contraction,
     # sqrt) may flip a value sitting on an integer boundary, by one, on a handful of Gaussians
@@ -65,16 +69,15 @@ def assert_forward_close(ho, oo, atol=FWD_ATOL, outlier_frac=2e-5, outlier_abs=8
         nbad = int((dr != 0).sum())
         assert int(dr.max()) <= 1 and nbad <= max(1, dr.numel() // 5000), \
             f"radii mismatch on {nbad} Gaussians (max |diff| {int(dr.max())})"
+    frag = None if aux is None else torch.as_tensor(aux["fragile_pixels"]).bool()
     for name, i in (("color", 0), ("depth", 2), ("alpha", 3)):
         ref = oo[i].double()
         err = (ho[i].double() - ref).abs()
         scale = max(1.0, ref.abs().max().item())
-        tol = atol * scale
-        bad = (err > tol)
-        nout = int(bad.reshape(-1, bad.shape[-2], bad.shape[-1]).any(0).sum())      # pixels, not channels
-        allowed = 2 + int(bad.shape[-2] * bad.shape[-1] * outlier_frac)
-        assert nout <= allowed and err.max().item() <= outlier_abs * scale, \
-            f"{name}: {nout} pixels above {tol:.1e} (allowed {allowed}), max abs err {err.max().item():.3e}"
+        strict = err if frag is None else err.masked_fill(frag[None].expand_as(err), 0.0)
+        assert strict.max().item() <= atol * scale, \
+            f"{name}: max abs err {strict.max().item():.3e} > {atol * scale:.1e} on a pixel without ambiguous decisions"
+        assert err.max().item() <= FRAGILE_ABS * scale, f"{name}: max abs err {err.max().item():.3e} on a fragile pixel"
 
 
 def grad_floors(sc, og):
@@ -87,11 +90,19 @@ def grad_floors(sc, og):
     return floors
 
 
-def assert_grads_close(hg, og, rtol=GRAD_RTOL, floors=None):
+def assert_grads_close(hg, og, aux=None, rtol=GRAD_RTOL, floors=None):
+    """Each attribute's gradient within rtol * max|ref| (row-wise strict), except the rows of
+    Gaussians the oracle flags as part of an ambiguous discrete decision (see above)."""
     floors = floors or {}
+    fg = None if aux is None else torch.as_tensor(aux["fragile_gaussians"]).bool()
     for k, ref in og.items():
         ref = ref.double()
         got = hg[k].double().reshape(ref.shape)
         scale = max(ref.abs().max().item(), floors.get(k, 0.0))
-        err = (got - ref).abs().max().item()
-        assert err <= rtol * scale + 1e-9, f"d{k}: max abs err {err:.3e} vs {rtol:.0e} * scale {scale:.3e}"
+        err = (got - ref).abs().reshape(ref.shape[0], -1).max(1).values if ref.shape[0] else torch.zeros(0)
+        strict = err if fg is None else err[~fg]
+        if strict.numel():
+            assert strict.max().item() <= rtol * scale + 1e-9, \
+                f"d{k}: max abs err {strict.max().item():.3e} vs {rtol:.0e} * scale {scale:.3e}"
+        if err.numel():
+            assert err.max().item() <= FRAGILE_GRAD_REL * scale + 1e-9, f"d{k}: fragile row err {err.max().item():.3e}"
