@@ -61,7 +61,7 @@ def load() -> C.CDLL:
             [GsrAlloc, GsrAlloc, GsrAlloc, C.POINTER(GsrStats), vp]
         lib.gsr_backward.restype = C.c_int
         lib.gsr_backward.argtypes = [C.POINTER(GsrView), i32, i32] + [p] * 7 + [p] + [p] * 3 + \
-            [p] * 3 + [p] * 8 + [GsrAlloc, vp]
+            [p] * 3 + [C.POINTER(GsrStats)] + [p] * 8 + [GsrAlloc, vp]
         lib.gsr_mark_visible.restype = C.c_int
         lib.gsr_mark_visible.argtypes = [C.POINTER(GsrView), i32, p, p, vp]
         lib.gsr_dist2.restype = C.c_int

@@ -80,7 +80,7 @@ int launch_status(bool debug, hipStream_t stream, const char* name) {
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 struct GeomLayout {
-    size_t recs, emit, tile_count, cursor, tile_off, counters, total;
+    size_t recs, emit, tile_count, cursor, tile_off, tile_seg, counters, total;
     int nTiles;
 };
 GeomLayout geom_layout(int N, int H, int W) {
@@ -94,10 +94,11 @@ GeomLayout geom_layout(int N, int H, int W) {
     L.cursor = o; o += align_up((size_t)L.nTiles * 4);
     L.counters = o; o += align_up(8 * 8);
     L.tile_off = o; o += align_up((size_t)(L.nTiles + 1) * 4);
+    L.tile_seg = o; o += align_up((size_t)(L.nTiles + 1) * 4);
     L.total = o;
     return L;
 }
-struct BinLayout { size_t entries, recs, total; };
+struct BinLayout { size_t entries, recs, ckpt, total; };
 BinLayout bin_layout(size_t M, bool copy) {
     BinLayout L;
     size_t o = 0;
@@ -105,6 +106,8 @@ BinLayout bin_layout(size_t M, bool copy) {
     // it at offset 0 without knowing M
     L.recs = o; o += align_up(M * (copy ? sizeof(SplatRec) : 4));
     L.entries = o; o += align_up(M * 8);
+    // backward checkpoints: sum over tiles of floor((n_t-1)/GSR_SEG) <= M/GSR_SEG slots
+    L.ckpt = o; o += align_up((M / GSR_SEG + 1) * (size_t)GSR_CKPT_FLOATS * 4);
     L.total = o < 256 ? 256 : o;
     return L;
 }
@@ -163,6 +166,11 @@ bool use_record_copy() {
     }();
     return v;
 }
+// GSR_BWD=b2f selects the back-to-front (one workgroup per tile) backward compositing kernel.
+bool use_bwd_b2f() {
+    static const bool v = [] { const char* e = getenv("GSR_BWD"); return e && strcmp(e, "b2f") == 0; }();
+    return v;
+}
 bool use_render_v0() {
     static const bool v = [] { const char* e = getenv("GSR_RENDER_V0"); return e && e[0] == '1'; }();
     return v;
@@ -205,7 +213,8 @@ extern "C" int gsr_profile_read(int cap, const char** names, float* total_ms, in
 extern "C" const char* gsr_version(void) { return "gsr 0.1 (gfx950, wave64, 16x16 bins / 8x8 wave blocks)"; }
 
 extern "C" size_t gsr_geom_bytes(int32_t N, int32_t H, int32_t W) { return geom_layout(N, H, W).total; }
-extern "C" size_t gsr_img_bytes(int32_t H, int32_t W) { return align_up((size_t)H * W * 4) * 2; }
+// final_T | n_contrib | totals[5] (the five per-pixel sums without background)
+extern "C" size_t gsr_img_bytes(int32_t H, int32_t W) { return align_up((size_t)H * W * 4) * 7; }
 
 extern "C" int gsr_forward(const GsrView* view, int32_t N, int32_t K,
                            const float* means3D, const float* shs, const float* colors_precomp,
@@ -232,9 +241,11 @@ extern "C" int gsr_forward(const GsrView* view, int32_t N, int32_t K,
     uint32_t* tile_count = (uint32_t*)(gbuf + GL.tile_count);
     uint32_t* cursor = (uint32_t*)(gbuf + GL.cursor);
     uint32_t* tile_off = (uint32_t*)(gbuf + GL.tile_off);
+    uint32_t* tile_seg = (uint32_t*)(gbuf + GL.tile_seg);
     unsigned long long* counters = (unsigned long long*)(gbuf + GL.counters);
     float* final_T = (float*)ibuf;
     uint32_t* n_contrib = (uint32_t*)(ibuf + align_up((size_t)H * W * 4));
+    float* totals = (float*)(ibuf + 2 * align_up((size_t)H * W * 4));
 
     // tile_count | cursor | counters are contiguous: one memset
     prof_begin(stream);
@@ -255,7 +266,7 @@ extern "C" int gsr_forward(const GsrView* view, int32_t N, int32_t K,
                            tile_count, counters, hist_in_lds);
         LAUNCH_CHECK(view, stream, "preprocess_fwd");
     }
-    prof_begin(stream); hipLaunchKernelGGL(gsr_tile_scan, dim3(1), dim3(1024), 0, stream, tile_count, tile_off, T, counters);
+    prof_begin(stream); hipLaunchKernelGGL(gsr_tile_scan, dim3(1), dim3(1024), 0, stream, tile_count, tile_off, T, counters, tile_seg);
     LAUNCH_CHECK(view, stream, "tile_scan");
 
     // the one host round trip of the forward: how many (tile,Gaussian) instances to allocate
@@ -273,6 +284,7 @@ extern "C" int gsr_forward(const GsrView* view, int32_t N, int32_t K,
     unsigned long long* entries = (unsigned long long*)(bbuf + BL.entries);
     SplatRec* srecs = (SplatRec*)(bbuf + BL.recs);
     uint32_t* sorted_ids = (uint32_t*)(bbuf + BL.recs);
+    float* ckpt = (float*)(bbuf + BL.ckpt);
 
     if (M > 0) {
         const size_t lds = hist_in_lds ? (size_t)T * 4 : 0;
@@ -328,10 +340,10 @@ extern "C" int gsr_forward(const GsrView* view, int32_t N, int32_t K,
                            out_color, out_depth, out_alpha, final_T, n_contrib);
     else if (copy)
         hipLaunchKernelGGL(gsr_render_fwd<false>, dim3(T), dim3(256), 0, stream, tile_off, srecs, (const uint32_t*)nullptr, view->bg, W, H, vc.gx,
-                           out_color, out_depth, out_alpha, final_T, n_contrib);
+                           out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg);
     else
         hipLaunchKernelGGL(gsr_render_fwd<true>, dim3(T), dim3(256), 0, stream, tile_off, recs, sorted_ids, view->bg, W, H, vc.gx,
-                           out_color, out_depth, out_alpha, final_T, n_contrib);
+                           out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg);
     LAUNCH_CHECK(view, stream, "render_fwd");
     return 0;
 }
@@ -342,6 +354,7 @@ extern "C" int gsr_backward(const GsrView* view, int32_t N, int32_t K,
                             const float* cov3D_precomp, const int32_t* radii,
                             const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
                             const void* geom, const void* bin, const void* img,
+                            const GsrStats* fwd_stats,
                             float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs, float* dL_dcolors,
                             float* dL_dopacities, float* dL_dscales, float* dL_drotations,
                             float* dL_dcov3D, GsrAlloc tmp, gsr_stream_t stream_) {
@@ -365,7 +378,18 @@ extern "C" int gsr_backward(const GsrView* view, int32_t N, int32_t K,
     const unsigned long long* counters = (const unsigned long long*)(gbuf + GL.counters);
     const float* final_T = (const float*)ibuf;
     const uint32_t* n_contrib = (const uint32_t*)(ibuf + align_up((size_t)H * W * 4));
-    (void)counters;
+    const float* totals = (const float*)(ibuf + 2 * align_up((size_t)H * W * 4));
+    const uint32_t* tile_seg = (const uint32_t*)(gbuf + GL.tile_seg);
+    // M and the longest tile list of the matching forward (for the checkpoint offset and the
+    // segment grid): from the caller's GsrStats, else read back from the device (blocking)
+    unsigned long long M = 0, maxc = 0;
+    if (fwd_stats) { M = (unsigned long long)fwd_stats->num_instances; maxc = (unsigned long long)fwd_stats->max_tile_count; }
+    else {
+        unsigned long long h[4];
+        HIP_TRY(hipMemcpyAsync(h, counters, sizeof(h), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        M = h[2]; maxc = h[3];
+    }
     const SplatRec* srecs = (const SplatRec*)bin;          // BinLayout.recs == 0
 
     float* g2d = (float*)tmp.resize(tmp.ctx, align_up((size_t)N * GSR_G2D_STRIDE * 4));
@@ -378,12 +402,24 @@ extern "C" int gsr_backward(const GsrView* view, int32_t N, int32_t K,
     if (use_render_v0())
         hipLaunchKernelGGL(gsr_render_bwd_v0, dim3(T), dim3(256), 0, stream, tile_off, srecs, view->bg, W, H, vc.gx,
                            final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, g2d);
-    else if (use_record_copy())
-        hipLaunchKernelGGL(gsr_render_bwd<false>, dim3(T), dim3(256), 0, stream, tile_off, srecs, (const uint32_t*)nullptr, view->bg, W, H, vc.gx,
-                           final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, g2d);
-    else
-        hipLaunchKernelGGL(gsr_render_bwd<true>, dim3(T), dim3(256), 0, stream, tile_off, recs, (const uint32_t*)bin, view->bg, W, H, vc.gx,
-                           final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, g2d);
+    else if (use_bwd_b2f()) {
+        if (use_record_copy())
+            hipLaunchKernelGGL(gsr_render_bwd<false>, dim3(T), dim3(256), 0, stream, tile_off, srecs, (const uint32_t*)nullptr, view->bg, W, H, vc.gx,
+                               final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, g2d);
+        else
+            hipLaunchKernelGGL(gsr_render_bwd<true>, dim3(T), dim3(256), 0, stream, tile_off, recs, (const uint32_t*)bin, view->bg, W, H, vc.gx,
+                               final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, g2d);
+    } else if (M > 0) {
+        const bool copy = use_record_copy();
+        const float* ckpt = (const float*)((const char*)bin + bin_layout((size_t)M, copy).ckpt);
+        const unsigned segs = (unsigned)((maxc + GSR_SEG - 1) / GSR_SEG);
+        if (copy)
+            hipLaunchKernelGGL(gsr_render_bwd_f2b<false>, dim3(T, segs), dim3(256), 0, stream, tile_off, srecs, (const uint32_t*)nullptr, view->bg, W, H, vc.gx,
+                               final_T, n_contrib, totals, ckpt, tile_seg, dL_dcolor, dL_ddepth, dL_dalpha, g2d);
+        else
+            hipLaunchKernelGGL(gsr_render_bwd_f2b<true>, dim3(T, segs), dim3(256), 0, stream, tile_off, recs, (const uint32_t*)bin, view->bg, W, H, vc.gx,
+                               final_T, n_contrib, totals, ckpt, tile_seg, dL_dcolor, dL_ddepth, dL_dalpha, g2d);
+    }
     LAUNCH_CHECK(view, stream, "render_bwd");
 
     const int grid_n = (int)fmin((double)((N + 255) / 256), 2048.0);

@@ -18,30 +18,43 @@
 // ---------------------------------------------------------------------------------------
 extern "C" __global__ void __launch_bounds__(1024)
 gsr_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_off, int T,
-              unsigned long long* __restrict__ counters) {
+              unsigned long long* __restrict__ counters, uint32_t* __restrict__ tile_seg) {
+    // tile_seg[t] = index of tile t's first checkpoint slot = exclusive scan of floor((n_t-1)/GSR_SEG)
     __shared__ unsigned long long wsum[16];
+    __shared__ uint32_t wsegs[16];
     __shared__ uint32_t wmax[16];
     const int per = (T + 1023) / 1024;
-    const int beg = threadIdx.x * per, end = min(beg + per, T);
+    const int beg = min((int)threadIdx.x * per, T), end = min(beg + per, T);
     unsigned long long local = 0;
-    uint32_t lmax = 0;
-    for (int i = beg; i < end; ++i) { const uint32_t c = tile_count[i]; local += c; lmax = max(lmax, c); }
+    uint32_t lmax = 0, lsegs = 0;
+    for (int i = beg; i < end; ++i) {
+        const uint32_t c = tile_count[i];
+        local += c; lmax = max(lmax, c); lsegs += c ? (c - 1) / GSR_SEG : 0u;
+    }
     // inclusive scan inside the wave
     unsigned long long incl = local;
+    uint32_t sincl = lsegs;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const unsigned long long o = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += o;
+        const uint32_t so = __shfl_up(sincl, off, 64);
+        if (lane >= off) { incl += o; sincl += so; }
     }
     lmax = wave_max_u32(lmax);
-    if (lane == 63) wsum[wave] = incl;
+    if (lane == 63) { wsum[wave] = incl; wsegs[wave] = sincl; }
     if (lane == 0) wmax[wave] = lmax;
     __syncthreads();
     unsigned long long wave_base = 0;
-    for (int w = 0; w < wave; ++w) wave_base += wsum[w];
+    uint32_t seg_base = 0;
+    for (int w = 0; w < wave; ++w) { wave_base += wsum[w]; seg_base += wsegs[w]; }
     unsigned long long run = wave_base + incl - local;
-    for (int i = beg; i < end; ++i) { tile_off[i] = (uint32_t)run; run += tile_count[i]; }
+    uint32_t srun = seg_base + sincl - lsegs;
+    for (int i = beg; i < end; ++i) {
+        const uint32_t c = tile_count[i];
+        tile_off[i] = (uint32_t)run; run += c;
+        tile_seg[i] = srun; srun += c ? (c - 1) / GSR_SEG : 0u;
+    }
     if (threadIdx.x == 1023) {
         tile_off[T] = (uint32_t)(wave_base + incl);
         counters[2] = wave_base + incl;

@@ -189,7 +189,8 @@ gsr_render_fwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict
                const float* __restrict__ bg, int W, int H, int gx,
                float* __restrict__ out_color, float* __restrict__ out_depth,
                float* __restrict__ out_alpha, float* __restrict__ final_T,
-               uint32_t* __restrict__ n_contrib) {
+               uint32_t* __restrict__ n_contrib, float* __restrict__ totals /*[5][H*W]*/,
+               float* __restrict__ ckpt, const uint32_t* __restrict__ tile_seg) {
     __shared__ float4 stage[4][3][GSR_RB];                 // 12 KiB: [wave][field group][slot]
     const int tile = blockIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -227,8 +228,14 @@ gsr_render_fwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict
         done = done || stop;                                                                   \
     }
 
+    const uint32_t seg_slot0 = tile_seg[tile];
     for (uint32_t base = start; base < end; base += GSR_RB) {
         if (__ballot(!done) == 0ull) break;
+        const uint32_t rel = base - start;
+        if (rel != 0u && (rel & (GSR_SEG - 1)) == 0u) {    // segment cut: checkpoint for the backward
+            float* c = ckpt + (size_t)(seg_slot0 + rel / GSR_SEG - 1u) * GSR_CKPT_FLOATS + (wave * 64 + lane);
+            c[0] = T; c[256] = C0; c[512] = C1; c[768] = C2; c[1024] = D; c[1280] = A;
+        }
         const uint32_t i = base + lane;
         bool hit = false;
         float4 ra, rb, rc;
@@ -269,6 +276,8 @@ gsr_render_fwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict
         out_color[2 * HW + pix] = C2 + T * bg[2];
         out_depth[pix] = D;
         out_alpha[pix] = A;
+        totals[pix] = C0; totals[HW + pix] = C1; totals[2 * HW + pix] = C2;   // sums without background
+        totals[3 * HW + pix] = D; totals[4 * HW + pix] = A;
     }
 }
 
@@ -410,7 +419,160 @@ gsr_render_bwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict
 #undef GSR_BWD_ENTRY
 }
 
-template __global__ void gsr_render_fwd<false>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, float*, float*, float*, float*, uint32_t*);
-template __global__ void gsr_render_fwd<true>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, float*, float*, float*, float*, uint32_t*);
+template __global__ void gsr_render_fwd<false>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, float*, float*, float*, float*, uint32_t*, float*, float*, const uint32_t*);
+template __global__ void gsr_render_fwd<true>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, float*, float*, float*, float*, uint32_t*, float*, float*, const uint32_t*);
 template __global__ void gsr_render_bwd<false>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, const float*, const uint32_t*, const float*, const float*, const float*, float*);
 template __global__ void gsr_render_bwd<true>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, const float*, const uint32_t*, const float*, const float*, const float*, float*);
+
+
+// =========================================================================================
+// Backward, FRONT TO BACK and depth-segmented (default).
+//
+// dL/dalpha_i = T_i (c_i.g) - [ sum_{j>i} w_j (c_j.g) + T_final (bg.g) ] / (1 - alpha_i)
+// with c.g the incoming-gradient-weighted scalar cr gC0 + cg gC1 + cb gC2 + depth gD + gA, and
+// sum_{j>i} = total - prefix_i - w_i (c_i.g): only FORWARD-running quantities (T and one scalar
+// prefix) are needed, the five per-channel "colour behind" recurrences of the back-to-front
+// form collapse into one, there is no T/(1-alpha) unrolling, and a tile's list can be cut into
+// independent segments: the forward leaves (T, C0, C1, C2, D, A) per pixel at every
+// GSR_SEG-th list position, and workgroup (tile, s) starts from checkpoint s. The longest
+// sequential walk drops from the tile's whole list (8.5k entries at 1M Gaussians) to GSR_SEG.
+// =========================================================================================
+template <bool BY_ID>
+__global__ void __launch_bounds__(256)
+gsr_render_bwd_f2b(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict__ recs,
+                   const uint32_t* __restrict__ ids,
+                   const float* __restrict__ bg, int W, int H, int gx,
+                   const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+                   const float* __restrict__ totals, const float* __restrict__ ckpt,
+                   const uint32_t* __restrict__ tile_seg,
+                   const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
+                   const float* __restrict__ dL_dalpha, float* __restrict__ g2d) {
+    __shared__ float4 stage[4][4][GSR_RB];                 // 16 KiB
+    const int tile = blockIdx.x;
+    const uint32_t seg = blockIdx.y;
+    const uint32_t start = tile_off[tile];
+    const uint32_t n = tile_off[tile + 1] - start;
+    const uint32_t seg_lo = seg * GSR_SEG;                 // this workgroup: list positions (seg_lo, seg_hi]
+    if (seg_lo >= n) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int bx = (tile % gx) * GSR_TILE + (wave & 1) * 8;
+    const int by = (tile / gx) * GSR_TILE + (wave >> 1) * 8;
+    if (bx >= W || by >= H) return;
+    const int px = bx + (lane & 7), py = by + (lane >> 3);
+    const bool inside = (px < W) && (py < H);
+    const float pxf = (float)px, pyf = (float)py;
+    float4* __restrict__ sa = stage[wave][0];
+    float4* __restrict__ sb = stage[wave][1];
+    float4* __restrict__ sc = stage[wave][2];
+    float4* __restrict__ sd = stage[wave][3];
+
+    float T_final = 1.f, gC0 = 0.f, gC1 = 0.f, gC2 = 0.f, gD = 0.f, gA = 0.f, Cg_total = 0.f;
+    uint32_t last_contrib = 0;
+    if (inside) {
+        const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
+        T_final = final_T[pix];
+        last_contrib = n_contrib[pix];
+        gC0 = dL_dcolor[pix]; gC1 = dL_dcolor[HW + pix]; gC2 = dL_dcolor[2 * HW + pix];
+        gD = dL_ddepth[pix]; gA = dL_dalpha[pix];
+        Cg_total = totals[pix] * gC0 + totals[HW + pix] * gC1 + totals[2 * HW + pix] * gC2
+                 + totals[3 * HW + pix] * gD + totals[4 * HW + pix] * gA;
+    }
+    const uint32_t wave_last = __builtin_amdgcn_readfirstlane(wave_max_u32(last_contrib));
+    if (wave_last <= seg_lo) return;                      // nothing in this segment was blended here
+    const uint32_t seg_hi = min(seg_lo + (uint32_t)GSR_SEG, wave_last);
+    const float tfbg = T_final * (bg[0] * gC0 + bg[1] * gC1 + bg[2] * gC2);
+
+    float T = 1.f, Cgf = 0.f;                             // transmittance and c.g prefix before the segment
+    if (seg > 0) {
+        const float* c = ckpt + (size_t)(tile_seg[tile] + seg - 1u) * GSR_CKPT_FLOATS + (wave * 64 + lane);
+        T = c[0];
+        Cgf = c[256] * gC0 + c[512] * gC1 + c[768] * gC2 + c[1024] * gD + c[1280] * gA;
+    }
+
+    const uint32_t slot0 = tag16(tag32(0u, 5u), tag32(1u, 6u));
+    const uint32_t slot1 = tag16(tag32(2u, 7u), tag32(3u, 8u));
+    const uint32_t slot2 = tag16(tag32(4u, 9u), tag32(10u, 11u));   // 10, 11: padding slots (zeros)
+    const bool row_leader = (lane & 15) == 0;
+
+    // ea = x y qa qb | eb = qc opac r g | ec = b depth pos - | ed = id - - -
+#define GSR_F2B_ENTRY(ea, eb, ec, ed)                                                            \
+    {                                                                                            \
+        const float qa = ea.z, qb = ea.w, qc = eb.x, opac = eb.y;                                \
+        const uint32_t kpos = __float_as_uint(ec.z);                                             \
+        const float dx = ea.x - pxf, dy = ea.y - pyf;                                            \
+        const float power = qa * dx * dx + qc * dy * dy + qb * dx * dy;                          \
+        const float G = fast_exp2(power);                                                        \
+        const float alpha = fminf(0.99f, opac * G);                                              \
+        const bool ok = (kpos <= last_contrib) && (power <= 0.f) && (alpha >= (1.0f / 255.0f));  \
+        if (__ballot(ok) != 0ull) {                       /* somebody in this block blended it */ \
+            float dL_dal = 0.f, w = 0.f;                  /* stay 0 in lanes that did not blend */  \
+            if (ok) {                                                                            \
+                const float cgi = eb.z * gC0 + eb.w * gC1 + ec.x * gC2 + ec.y * gD + gA;         \
+                const float oma = 1.f - alpha;                                                   \
+                w = alpha * T;                                                                   \
+                const float wc = w * cgi;                                                        \
+                dL_dal = T * cgi - (Cg_total - Cgf - wc + tfbg) * fast_rcp(oma);                 \
+                Cgf += wc;                                                                       \
+                T *= oma;                                                                        \
+            }                                                                                    \
+            const float Gm = ok ? G : 0.f;                /* G may be inf where power > 0 */      \
+            const float dL_dG = opac * dL_dal;                                                   \
+            const float gdx = Gm * dx, gdy = Gm * dy;                                            \
+            const float v0 = dL_dG * (2.f * qa * gdx + qb * gdy);  /* mean2D.x (ln2*0.5W in K6) */ \
+            const float v1 = dL_dG * (2.f * qc * gdy + qb * gdx);  /* mean2D.y */                \
+            const float v2 = -0.5f * gdx * dx * dL_dG;             /* dL/dA */                   \
+            const float v3 = -gdx * dy * dL_dG;                    /* dL/dB */                   \
+            const float v4 = -0.5f * gdy * dy * dL_dG;             /* dL/dC */                   \
+            const float v5 = Gm * dL_dal;                          /* dL/dopacity */             \
+            const float v6 = w * gC0, v7 = w * gC1, v8 = w * gC2;  /* dL/drgb */                 \
+            const float v9 = w * gD;                               /* dL/ddepth */               \
+            const float t0 = row_sum16(red16(red32(v0, v5), red32(v1, v6)));                     \
+            const float t1 = row_sum16(red16(red32(v2, v7), red32(v3, v8)));                     \
+            const float t2 = row_sum16(red16(red32(v4, v9), 0.f));                               \
+            if (row_leader) {                                                                    \
+                const uint32_t gid = __builtin_amdgcn_readfirstlane(__float_as_uint(ed.x));      \
+                float* dst = g2d + (size_t)gid * GSR_G2D_STRIDE;                                 \
+                atomicAdd(dst + slot0, t0);                                                      \
+                atomicAdd(dst + slot1, t1);                                                      \
+                if (slot2 < 10u) atomicAdd(dst + slot2, t2);                                     \
+            }                                                                                    \
+        }                                                                                        \
+    }
+
+    for (uint32_t pos0 = seg_lo; pos0 < seg_hi; pos0 += GSR_RB) {   // 0-based positions pos0 .. pos0+63
+        const uint32_t i = pos0 + lane;
+        bool hit = false;
+        float4 ra, rb, rc, rd;
+        if (i < seg_hi) {
+            const float4* __restrict__ p = list_record<BY_ID>(recs, ids, start + i);
+            ra = p[0]; rb = p[1]; rc = p[2]; rd = p[3];
+            const uint32_t bbx = __float_as_uint(rc.z), bby = __float_as_uint(rc.w);
+            hit = !(unpack_hi16(bbx) < bx || unpack_lo16(bbx) > bx + 7 ||
+                    unpack_hi16(bby) < by || unpack_lo16(bby) > by + 7);
+        }
+        const unsigned long long mask = __ballot(hit);
+        if (mask == 0ull) continue;
+        const int cnt = __popcll(mask);
+        if (hit) {
+            const uint32_t pos = lanes_below(mask);       // ascending lane = ascending list position
+            rc.z = __uint_as_float(i + 1u);               // 1-based list position
+            sa[pos] = ra; sb[pos] = rb; sc[pos] = rc; sd[pos] = rd;
+        }
+        wave_lds_handoff();
+        float4 e0a = sa[0], e0b = sb[0], e0c = sc[0], e0d = sd[0];
+        for (int j = 0; j < cnt; j += 2) {
+            const int j1 = min(j + 1, cnt - 1);
+            const float4 e1a = sa[j1], e1b = sb[j1], e1c = sc[j1], e1d = sd[j1];
+            GSR_F2B_ENTRY(e0a, e0b, e0c, e0d)
+            const int j2 = min(j + 2, cnt - 1);
+            e0a = sa[j2]; e0b = sb[j2]; e0c = sc[j2]; e0d = sd[j2];
+            if (j + 1 < cnt) GSR_F2B_ENTRY(e1a, e1b, e1c, e1d)
+        }
+        wave_lds_handoff();
+    }
+#undef GSR_F2B_ENTRY
+}
+
+template __global__ void gsr_render_bwd_f2b<false>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, const float*, const uint32_t*, const float*, const float*, const uint32_t*, const float*, const float*, const float*, float*);
+template __global__ void gsr_render_bwd_f2b<true>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, const float*, const uint32_t*, const float*, const float*, const uint32_t*, const float*, const float*, const float*, float*);

@@ -115,6 +115,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                            V=stats.num_visible, max_tile=stats.max_tile_count, N=N, H=H, W=W, K=K)
         ctx.raster_settings = rs
         ctx.dims = (N, K)
+        ctx.fwd_stats = stats
         ctx.present = (shc is not None, col is not None, sc is not None, cov is not None)
         empty = torch.empty(0, device=dev)
         ctx.save_for_backward(m3, shc if shc is not None else empty, col if col is not None else empty,
@@ -159,7 +160,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                     C.byref(view), N, K, P(m3), P(shc) if has_sh else None, P(col) if has_col else None,
                     P(op), P(sc) if has_sr else None, P(rot) if has_sr else None,
                     P(cov) if has_cov else None, P(radii), P(gc), P(gd), P(ga),
-                    P(geom), P(binb), P(img), P(d_m3), P(d_m2), P(d_sh), P(d_col), P(d_op),
+                    P(geom), P(binb), P(img), C.byref(ctx.fwd_stats), P(d_m3), P(d_m2), P(d_sh), P(d_col), P(d_op),
                     P(d_sc), P(d_rot), P(d_cov), tmp.alloc, stream)
             tmp.release()
             _lib.check(rc, "gsr_backward")

@@ -85,7 +85,9 @@ int gsr_forward(const GsrView* view, int32_t N, int32_t K,
 
 /* Backward. Same inputs as the forward plus the incoming gradients
  *   dL_dcolor [3,H,W]  dL_ddepth [H,W]  dL_dalpha [H,W]
- * and the three scratch buffers of the matching forward. Outputs (dense, exact zeros for
+ * and the three scratch buffers of the matching forward, plus (optional, [host]) the GsrStats
+ * that forward returned -- without it the backward reads the two counters it needs back from
+ * the device (one blocking copy). Outputs (dense, exact zeros for
  * culled Gaussians; a NULL output is skipped where that is meaningful):
  *   dL_dmeans3D [N,3]  dL_dmeans2D [N,3] (x,y in NDC units = pixel grad * 0.5*(W,H); z=0)
  *   dL_dshs [N,K,3] | dL_dcolors [N,3]   dL_dopacities [N]
@@ -97,6 +99,7 @@ int gsr_backward(const GsrView* view, int32_t N, int32_t K,
                  const float* cov3D_precomp, const int32_t* radii,
                  const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
                  const void* geom, const void* bin, const void* img,
+                 const GsrStats* fwd_stats,
                  float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs, float* dL_dcolors,
                  float* dL_dopacities, float* dL_dscales, float* dL_drotations,
                  float* dL_dcov3D, GsrAlloc tmp, gsr_stream_t stream);

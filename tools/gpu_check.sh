@@ -26,16 +26,17 @@ prof)
   f=$(find gpurun_out/prof_1M -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -12 "$f";;
 ab)
   # A/B of the env-selectable variants: parity suite + 1M bench for each
-  for v in "" "GSR_RECORDS=copy" "GSR_SORT=bitonic" "GSR_RENDER_V0=1"; do
+  for v in ${AB_VARIANTS:-"" "GSR_BWD=b2f" "GSR_RECORDS=copy"}; do
     echo "== variant [$v] tests"; env $v timeout 600 python -m pytest tests -m gpu -q -p no:cacheprovider --tb=line -x 2>&1 | tail -4
     echo "== variant [$v] bench 1M"; env $v timeout 300 python bench.py --cpu-budget 0 --trace-steps 2>gpurun_out/ab_err.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['ms_per_step_with_events'], d['kernels_ms_per_step'])"
     grep "step ms" gpurun_out/ab_err.log
   done;;
 pmc)
   echo "== rocprofv3 PMC passes (1M)"
-  for c in FETCH_SIZE WRITE_SIZE; do
-    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_$c -o r01 -- python $R/bench.py --steps 3 --warmup 1 --cpu-budget 0 --no-roofline > $R/gpurun_out/pmc_$c.log 2>&1)
-    tail -1 gpurun_out/pmc_$c.log
+  for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE SQ_INSTS_VMEM SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_VMEM"; do
+    tag=$(echo $c | cut -d" " -f1)
+    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_$tag -o r01 -- python $R/bench.py --steps 3 --warmup 1 --cpu-budget 0 --no-roofline > $R/gpurun_out/pmc_$tag.log 2>&1)
+    tail -1 gpurun_out/pmc_$tag.log | cut -c1-200
   done
-  python tools/pmc_summary.py gpurun_out 2>&1 | tail -20;;
+  python tools/pmc_summary.py gpurun_out 2>&1 | tail -30;;
 esac; done
