@@ -167,6 +167,12 @@ bool use_record_copy() {
     return v;
 }
 // GSR_BWD=b2f selects the back-to-front (one workgroup per tile) backward compositing kernel.
+// GSR_SH=stage makes the forward per-Gaussian kernel transpose SH rows through LDS (coalesced
+// loads, 2 waves/SIMD); the default reads rows directly with 16-byte loads at full occupancy.
+bool use_sh_stage() {
+    static const bool v = [] { const char* e = getenv("GSR_SH"); return e && strcmp(e, "stage") == 0; }();
+    return v;
+}
 bool use_bwd_b2f() {
     static const bool v = [] { const char* e = getenv("GSR_BWD"); return e && strcmp(e, "b2f") == 0; }();
     return v;
@@ -253,17 +259,18 @@ extern "C" int gsr_forward(const GsrView* view, int32_t N, int32_t K,
     prof_end(stream, "memset_fwd");
 
     const int hist_in_lds = T <= kHistLdsMaxTiles;
-    const int grid_n = N > 0 ? (int)fmin((double)((N + 255) / 256), 512.0) : 0;
+    const int sh_direct = use_sh_stage() ? 0 : 1;
+    const int grid_n = N > 0 ? (int)fmin((double)((N + 255) / 256), sh_direct ? 2048.0 : 512.0) : 0;
     if (N > 0) {
         const size_t hist_bytes = hist_in_lds ? (((size_t)T * 4 + 15) & ~(size_t)15) : 0;
-        const size_t sh_bytes = (shs && K > 1) ? (size_t)256 * (3 * K + 1) * 4 : 0;
+        const size_t sh_bytes = (shs && K > 1 && !sh_direct) ? (size_t)256 * (3 * K + 1) * 4 : 0;
         const size_t lds = hist_bytes + sh_bytes;
         if (lds > 160 * 1024) return fail(-1, "preprocess needs more than 160 KiB of LDS%s", "");
         if (lds > 48 * 1024)
             HIP_TRY(hipFuncSetAttribute((const void*)gsr_preprocess_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         prof_begin(stream); hipLaunchKernelGGL(gsr_preprocess_fwd, dim3(grid_n), dim3(256), lds, stream, vc, N, K, means3D, shs,
                            colors_precomp, opacities, scales, rotations, cov3D_precomp, recs, emit, radii,
-                           tile_count, counters, hist_in_lds);
+                           tile_count, counters, hist_in_lds, sh_direct);
         LAUNCH_CHECK(view, stream, "preprocess_fwd");
     }
     prof_begin(stream); hipLaunchKernelGGL(gsr_tile_scan, dim3(1), dim3(1024), 0, stream, tile_count, tile_off, T, counters, tile_seg);

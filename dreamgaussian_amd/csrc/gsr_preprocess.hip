@@ -166,13 +166,16 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
                    SplatRec* __restrict__ recs, EmitRec* __restrict__ emit,
                    int32_t* __restrict__ radii, uint32_t* __restrict__ tile_count,
                    unsigned long long* __restrict__ counters /*[0]=M_ref [1]=V*/,
-                   int hist_in_lds) {
+                   int hist_in_lds, int sh_direct) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int nTiles = vc.gx * vc.gy;
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem_raw);
     float* shbuf = reinterpret_cast<float*>(smem_raw + (hist_in_lds ? ((nTiles * 4 + 15) & ~15) : 0));
     const int rowlen = 3 * K;
-    const bool stage = (shs != nullptr) && (K > 1);
+    // sh_direct: every lane reads its own SH row with 16-byte loads (no LDS transpose): LDS then
+    // only holds the tile histogram and ~4x more waves fit on a CU -- the kernel is latency-bound
+    // (PMC: 79% of wave cycles waiting at 2 waves/SIMD with the 50 KiB staging buffer).
+    const bool stage = (shs != nullptr) && (K > 1) && !sh_direct;
 
     if (hist_in_lds) {
         for (int t = threadIdx.x; t < nTiles; t += blockDim.x) hist[t] = 0;
@@ -260,10 +263,23 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
                         sh_basis(vc.sh_degree, dx, dy, dz, B);
                         const int nb = (vc.sh_degree + 1) * (vc.sh_degree + 1);
                         const float* row = stage ? (shbuf + threadIdx.x * (rowlen + 1)) : (shs + (size_t)idx * rowlen);
+                        float coef[48];
+                        if (!stage && (rowlen & 3) == 0) {          // 16-byte aligned rows: wide loads
+                            const float4* __restrict__ r4 = reinterpret_cast<const float4*>(row);
+#pragma unroll
+                            for (int q = 0; q < 12; ++q) {
+                                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                                if (4 * q < 3 * nb) v = r4[q];
+                                coef[4 * q] = v.x; coef[4 * q + 1] = v.y; coef[4 * q + 2] = v.z; coef[4 * q + 3] = v.w;
+                            }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 48; ++e) coef[e] = (e < 3 * nb) ? row[e] : 0.f;
+                        }
                         cr = cg = cb = 0.f;
 #pragma unroll
-                        for (int k = 0; k < 16; ++k) {   // static indices: B[] stays in registers
-                            if (k < nb) { cr += B[k] * row[3 * k]; cg += B[k] * row[3 * k + 1]; cb += B[k] * row[3 * k + 2]; }
+                        for (int k = 0; k < 16; ++k) {   // static indices: B[] and coef[] stay in registers
+                            if (k < nb) { cr += B[k] * coef[3 * k]; cg += B[k] * coef[3 * k + 1]; cb += B[k] * coef[3 * k + 2]; }
                         }
                         cr += 0.5f; cg += 0.5f; cb += 0.5f;
                         if (cr < 0.f) { flags |= 1u; cr = 0.f; }

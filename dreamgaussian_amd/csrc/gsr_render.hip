@@ -191,7 +191,7 @@ gsr_render_fwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict
                float* __restrict__ out_alpha, float* __restrict__ final_T,
                uint32_t* __restrict__ n_contrib, float* __restrict__ totals /*[5][H*W]*/,
                float* __restrict__ ckpt, const uint32_t* __restrict__ tile_seg) {
-    __shared__ float4 stage[4][3][GSR_RB];                 // 12 KiB: [wave][field group][slot]
+    __shared__ float4 stage[4][3][GSR_RB + 2];             // 12.4 KiB: [wave][field group][slot (+2 pad)]
     const int tile = blockIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -229,8 +229,28 @@ gsr_render_fwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict
     }
 
     const uint32_t seg_slot0 = tile_seg[tile];
+    // Two-deep fetch pipeline: while round r is composited, the records of round r+1 (whose
+    // list entries were fetched during round r-1) and the list entries of round r+2 are in flight.
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra;
+    uint32_t id_next = 0;
+    if (start + lane < end) {
+        const float4* __restrict__ p = list_record<BY_ID>(recs, ids, start + lane);
+        ra = p[0]; rb = p[1]; rc = p[2];
+    }
+    if (BY_ID && start + GSR_RB + lane < end) id_next = ids[start + GSR_RB + lane];
     for (uint32_t base = start; base < end; base += GSR_RB) {
         if (__ballot(!done) == 0ull) break;
+        float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na, nc = na;
+        uint32_t id_next2 = 0;
+        {
+            const uint32_t i1 = base + GSR_RB + lane;
+            if (i1 < end) {
+                const float4* __restrict__ p = reinterpret_cast<const float4*>(BY_ID ? recs + id_next : recs + i1);
+                na = p[0]; nb = p[1]; nc = p[2];
+            }
+            const uint32_t i2 = base + 2 * GSR_RB + lane;
+            if (BY_ID && i2 < end) id_next2 = ids[i2];
+        }
         const uint32_t rel = base - start;
         if (rel != 0u && (rel & (GSR_SEG - 1)) == 0u) {    // segment cut: checkpoint for the backward
             float* c = ckpt + (size_t)(seg_slot0 + rel / GSR_SEG - 1u) * GSR_CKPT_FLOATS + (wave * 64 + lane);
@@ -238,33 +258,30 @@ gsr_render_fwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict
         }
         const uint32_t i = base + lane;
         bool hit = false;
-        float4 ra, rb, rc;
         if (i < end) {
-            const float4* __restrict__ p = list_record<BY_ID>(recs, ids, i);
-            ra = p[0]; rb = p[1]; rc = p[2];
             const uint32_t bbx = __float_as_uint(rc.z), bby = __float_as_uint(rc.w);
             hit = !(unpack_hi16(bbx) < bx || unpack_lo16(bbx) > bx + 7 ||
                     unpack_hi16(bby) < by || unpack_lo16(bby) > by + 7);
         }
         const unsigned long long mask = __ballot(hit);
-        if (mask == 0ull) continue;
-        const int n = __popcll(mask);
-        if (hit) {
-            const uint32_t pos = lanes_below(mask);
-            rc.z = __uint_as_float(i - start + 1);        // 1-based list position replaces the box
-            sa[pos] = ra; sb[pos] = rb; sc[pos] = rc;
+        if (mask != 0ull) {
+            const int n = __popcll(mask);
+            if (hit) {
+                const uint32_t pos = lanes_below(mask);
+                rc.z = __uint_as_float(i - start + 1);    // 1-based list position replaces the box
+                sa[pos] = ra; sb[pos] = rb; sc[pos] = rc;
+            }
+            wave_lds_handoff();
+            float4 e0a = sa[0], e0b = sb[0], e0c = sc[0];
+            for (int j = 0; j < n; j += 2) {              // slots n, n+1 are padding: read, never used
+                const float4 e1a = sa[j + 1], e1b = sb[j + 1], e1c = sc[j + 1];   // in flight during entry j
+                GSR_FWD_ENTRY(e0a, e0b, e0c)
+                e0a = sa[j + 2]; e0b = sb[j + 2]; e0c = sc[j + 2];               // in flight during entry j+1
+                if (j + 1 < n) GSR_FWD_ENTRY(e1a, e1b, e1c)
+            }
+            wave_lds_handoff();                           // reads above precede the next round's writes
         }
-        wave_lds_handoff();
-        float4 e0a = sa[0], e0b = sb[0], e0c = sc[0];
-        for (int j = 0; j < n; j += 2) {
-            const int j1 = min(j + 1, n - 1);
-            const float4 e1a = sa[j1], e1b = sb[j1], e1c = sc[j1];   // in flight during entry j
-            GSR_FWD_ENTRY(e0a, e0b, e0c)
-            const int j2 = min(j + 2, n - 1);
-            e0a = sa[j2]; e0b = sb[j2]; e0c = sc[j2];                // in flight during entry j+1
-            if (j + 1 < n) GSR_FWD_ENTRY(e1a, e1b, e1c)
-        }
-        wave_lds_handoff();                               // reads above precede the next round's writes
+        ra = na; rb = nb; rc = nc; id_next = id_next2;
     }
 #undef GSR_FWD_ENTRY
     if (inside) {
@@ -447,7 +464,7 @@ gsr_render_bwd_f2b(const uint32_t* __restrict__ tile_off, const SplatRec* __rest
                    const uint32_t* __restrict__ tile_seg,
                    const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
                    const float* __restrict__ dL_dalpha, float* __restrict__ g2d) {
-    __shared__ float4 stage[4][4][GSR_RB];                 // 16 KiB
+    __shared__ float4 stage[4][4][GSR_RB + 2];             // 16.5 KiB (+2 pad slots)
     const int tile = blockIdx.x;
     const uint32_t seg = blockIdx.y;
     const uint32_t start = tile_off[tile];
@@ -540,36 +557,52 @@ gsr_render_bwd_f2b(const uint32_t* __restrict__ tile_off, const SplatRec* __rest
         }                                                                                        \
     }
 
+    // two-deep fetch pipeline as in the forward
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra, rd = ra;
+    uint32_t id_next = 0;
+    if (seg_lo + lane < seg_hi) {
+        const float4* __restrict__ p = list_record<BY_ID>(recs, ids, start + seg_lo + lane);
+        ra = p[0]; rb = p[1]; rc = p[2]; rd = p[3];
+    }
+    if (BY_ID && seg_lo + GSR_RB + lane < seg_hi) id_next = ids[start + seg_lo + GSR_RB + lane];
     for (uint32_t pos0 = seg_lo; pos0 < seg_hi; pos0 += GSR_RB) {   // 0-based positions pos0 .. pos0+63
+        float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na, nc = na, nd = na;
+        uint32_t id_next2 = 0;
+        {
+            const uint32_t i1 = pos0 + GSR_RB + lane;
+            if (i1 < seg_hi) {
+                const float4* __restrict__ p = reinterpret_cast<const float4*>(BY_ID ? recs + id_next : recs + (start + i1));
+                na = p[0]; nb = p[1]; nc = p[2]; nd = p[3];
+            }
+            const uint32_t i2 = pos0 + 2 * GSR_RB + lane;
+            if (BY_ID && i2 < seg_hi) id_next2 = ids[start + i2];
+        }
         const uint32_t i = pos0 + lane;
         bool hit = false;
-        float4 ra, rb, rc, rd;
         if (i < seg_hi) {
-            const float4* __restrict__ p = list_record<BY_ID>(recs, ids, start + i);
-            ra = p[0]; rb = p[1]; rc = p[2]; rd = p[3];
             const uint32_t bbx = __float_as_uint(rc.z), bby = __float_as_uint(rc.w);
             hit = !(unpack_hi16(bbx) < bx || unpack_lo16(bbx) > bx + 7 ||
                     unpack_hi16(bby) < by || unpack_lo16(bby) > by + 7);
         }
         const unsigned long long mask = __ballot(hit);
-        if (mask == 0ull) continue;
-        const int cnt = __popcll(mask);
-        if (hit) {
-            const uint32_t pos = lanes_below(mask);       // ascending lane = ascending list position
-            rc.z = __uint_as_float(i + 1u);               // 1-based list position
-            sa[pos] = ra; sb[pos] = rb; sc[pos] = rc; sd[pos] = rd;
+        if (mask != 0ull) {
+            const int cnt = __popcll(mask);
+            if (hit) {
+                const uint32_t pos = lanes_below(mask);   // ascending lane = ascending list position
+                rc.z = __uint_as_float(i + 1u);           // 1-based list position
+                sa[pos] = ra; sb[pos] = rb; sc[pos] = rc; sd[pos] = rd;
+            }
+            wave_lds_handoff();
+            float4 e0a = sa[0], e0b = sb[0], e0c = sc[0], e0d = sd[0];
+            for (int j = 0; j < cnt; j += 2) {            // slots cnt, cnt+1 are padding: read, never used
+                const float4 e1a = sa[j + 1], e1b = sb[j + 1], e1c = sc[j + 1], e1d = sd[j + 1];
+                GSR_F2B_ENTRY(e0a, e0b, e0c, e0d)
+                e0a = sa[j + 2]; e0b = sb[j + 2]; e0c = sc[j + 2]; e0d = sd[j + 2];
+                if (j + 1 < cnt) GSR_F2B_ENTRY(e1a, e1b, e1c, e1d)
+            }
+            wave_lds_handoff();
         }
-        wave_lds_handoff();
-        float4 e0a = sa[0], e0b = sb[0], e0c = sc[0], e0d = sd[0];
-        for (int j = 0; j < cnt; j += 2) {
-            const int j1 = min(j + 1, cnt - 1);
-            const float4 e1a = sa[j1], e1b = sb[j1], e1c = sc[j1], e1d = sd[j1];
-            GSR_F2B_ENTRY(e0a, e0b, e0c, e0d)
-            const int j2 = min(j + 2, cnt - 1);
-            e0a = sa[j2]; e0b = sb[j2]; e0c = sc[j2]; e0d = sd[j2];
-            if (j + 1 < cnt) GSR_F2B_ENTRY(e1a, e1b, e1c, e1d)
-        }
-        wave_lds_handoff();
+        ra = na; rb = nb; rc = nc; rd = nd; id_next = id_next2;
     }
 #undef GSR_F2B_ENTRY
 }
