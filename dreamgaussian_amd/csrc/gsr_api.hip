@@ -80,7 +80,7 @@ int launch_status(bool debug, hipStream_t stream, const char* name) {
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 struct GeomLayout {
-    size_t recs, emit, tile_count, cursor, tile_off, tile_seg, counters, total;
+    size_t recs, emit, tile_count, cursor, tile_off, tile_seg, tile_order, counters, total;
     int nTiles;
 };
 GeomLayout geom_layout(int N, int H, int W) {
@@ -95,6 +95,7 @@ GeomLayout geom_layout(int N, int H, int W) {
     L.counters = o; o += align_up(8 * 8);
     L.tile_off = o; o += align_up((size_t)(L.nTiles + 1) * 4);
     L.tile_seg = o; o += align_up((size_t)(L.nTiles + 1) * 4);
+    L.tile_order = o; o += align_up((size_t)L.nTiles * 4);
     L.total = o;
     return L;
 }
@@ -167,10 +168,21 @@ bool use_record_copy() {
     return v;
 }
 // GSR_BWD=b2f selects the back-to-front (one workgroup per tile) backward compositing kernel.
-// GSR_SH=stage makes the forward per-Gaussian kernel transpose SH rows through LDS (coalesced
-// loads, 2 waves/SIMD); the default reads rows directly with 16-byte loads at full occupancy.
+// GSR_SH=direct makes the forward per-Gaussian kernel read SH rows with per-lane 16-byte loads
+// (no LDS transpose, 4x the occupancy); measured SLOWER at 1M Gaussians (0.236 vs 0.152 ms:
+// 192-byte-strided rows defeat the coalescer), so the LDS transpose stays the default.
 bool use_sh_stage() {
-    static const bool v = [] { const char* e = getenv("GSR_SH"); return e && strcmp(e, "stage") == 0; }();
+    static const bool v = [] { const char* e = getenv("GSR_SH"); return !(e && strcmp(e, "direct") == 0); }();
+    return v;
+}
+// GSR_TILE_ORDER=off launches the forward compositing tiles in row-major instead of heaviest-first order.
+bool use_tile_order_off() {
+    static const bool v = [] { const char* e = getenv("GSR_TILE_ORDER"); return e && strcmp(e, "off") == 0; }();
+    return v;
+}
+// GSR_FWD_SCHED=1: forward compositing variant with a pinned LDS-read / VALU interleave.
+bool use_fwd_sched() {
+    static const bool v = [] { const char* e = getenv("GSR_FWD_SCHED"); return e && e[0] == '1'; }();
     return v;
 }
 bool use_bwd_b2f() {
@@ -248,6 +260,7 @@ extern "C" int gsr_forward(const GsrView* view, int32_t N, int32_t K,
     uint32_t* cursor = (uint32_t*)(gbuf + GL.cursor);
     uint32_t* tile_off = (uint32_t*)(gbuf + GL.tile_off);
     uint32_t* tile_seg = (uint32_t*)(gbuf + GL.tile_seg);
+    uint32_t* tile_order = nullptr;
     unsigned long long* counters = (unsigned long long*)(gbuf + GL.counters);
     float* final_T = (float*)ibuf;
     uint32_t* n_contrib = (uint32_t*)(ibuf + align_up((size_t)H * W * 4));
@@ -260,7 +273,8 @@ extern "C" int gsr_forward(const GsrView* view, int32_t N, int32_t K,
 
     const int hist_in_lds = T <= kHistLdsMaxTiles;
     const int sh_direct = use_sh_stage() ? 0 : 1;
-    const int grid_n = N > 0 ? (int)fmin((double)((N + 255) / 256), sh_direct ? 2048.0 : 512.0) : 0;
+    const int grid_n = N > 0 ? (int)fmin((double)((N + 255) / 256), 512.0) : 0;
+    const int grid_pre = N > 0 ? (int)fmin((double)((N + 255) / 256), sh_direct ? 2048.0 : 512.0) : 0;
     if (N > 0) {
         const size_t hist_bytes = hist_in_lds ? (((size_t)T * 4 + 15) & ~(size_t)15) : 0;
         const size_t sh_bytes = (shs && K > 1 && !sh_direct) ? (size_t)256 * (3 * K + 1) * 4 : 0;
@@ -268,13 +282,20 @@ extern "C" int gsr_forward(const GsrView* view, int32_t N, int32_t K,
         if (lds > 160 * 1024) return fail(-1, "preprocess needs more than 160 KiB of LDS%s", "");
         if (lds > 48 * 1024)
             HIP_TRY(hipFuncSetAttribute((const void*)gsr_preprocess_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        prof_begin(stream); hipLaunchKernelGGL(gsr_preprocess_fwd, dim3(grid_n), dim3(256), lds, stream, vc, N, K, means3D, shs,
+        prof_begin(stream); hipLaunchKernelGGL(gsr_preprocess_fwd, dim3(grid_pre), dim3(256), lds, stream, vc, N, K, means3D, shs,
                            colors_precomp, opacities, scales, rotations, cov3D_precomp, recs, emit, radii,
                            tile_count, counters, hist_in_lds, sh_direct);
         LAUNCH_CHECK(view, stream, "preprocess_fwd");
     }
     prof_begin(stream); hipLaunchKernelGGL(gsr_tile_scan, dim3(1), dim3(1024), 0, stream, tile_count, tile_off, T, counters, tile_seg);
     LAUNCH_CHECK(view, stream, "tile_scan");
+    if (T <= 8192 && !use_tile_order_off()) {             // heaviest tiles first (64 KiB of LDS keys)
+        tile_order = (uint32_t*)(gbuf + GL.tile_order);
+        static bool attr_set = false;
+        if (!attr_set) { HIP_TRY(hipFuncSetAttribute((const void*)gsr_tile_order, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8)); attr_set = true; }
+        prof_begin(stream); hipLaunchKernelGGL(gsr_tile_order, dim3(1), dim3(1024), (size_t)T * 8, stream, tile_count, T, tile_order);
+        LAUNCH_CHECK(view, stream, "tile_order");
+    }
 
     // the one host round trip of the forward: how many (tile,Gaussian) instances to allocate
     if (!g_pinned) HIP_TRY(hipHostMalloc((void**)&g_pinned, 8 * sizeof(unsigned long long), hipHostMallocDefault));
@@ -345,12 +366,15 @@ extern "C" int gsr_forward(const GsrView* view, int32_t N, int32_t K,
     if (use_render_v0())
         hipLaunchKernelGGL(gsr_render_fwd_v0, dim3(T), dim3(256), 0, stream, tile_off, srecs, view->bg, W, H, vc.gx,
                            out_color, out_depth, out_alpha, final_T, n_contrib);
-    else if (copy)
-        hipLaunchKernelGGL(gsr_render_fwd<false>, dim3(T), dim3(256), 0, stream, tile_off, srecs, (const uint32_t*)nullptr, view->bg, W, H, vc.gx,
-                           out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg);
-    else
-        hipLaunchKernelGGL(gsr_render_fwd<true>, dim3(T), dim3(256), 0, stream, tile_off, recs, sorted_ids, view->bg, W, H, vc.gx,
-                           out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg);
+    else {
+#define GSR_LAUNCH_FWD(B, S, RECS, IDS)                                                              \
+        hipLaunchKernelGGL((gsr_render_fwd<B, S>), dim3(T), dim3(256), 0, stream, tile_off, RECS, IDS, view->bg, W, H, vc.gx, \
+                           out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, tile_order)
+        const bool sched = use_fwd_sched();
+        if (copy) { if (sched) GSR_LAUNCH_FWD(false, true, srecs, (const uint32_t*)nullptr); else GSR_LAUNCH_FWD(false, false, srecs, (const uint32_t*)nullptr); }
+        else { if (sched) GSR_LAUNCH_FWD(true, true, recs, sorted_ids); else GSR_LAUNCH_FWD(true, false, recs, sorted_ids); }
+#undef GSR_LAUNCH_FWD
+    }
     LAUNCH_CHECK(view, stream, "render_fwd");
     return 0;
 }

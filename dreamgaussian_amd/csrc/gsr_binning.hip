@@ -140,6 +140,20 @@ __device__ __forceinline__ void bitonic_sort(KeyPtr keys, uint32_t n, int nthrea
     }
 }
 
+// Heaviest-first launch order for the compositing forward (longest-processing-time-first: the
+// dispatcher hands workgroups to CUs in index order, so tile weights are dealt round-robin).
+// dynamic LDS: T u64 keys.
+extern "C" __global__ void __launch_bounds__(1024)
+gsr_tile_order(const uint32_t* __restrict__ tile_count, int T, uint32_t* __restrict__ order) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem_raw);
+    for (int t = threadIdx.x; t < T; t += 1024)
+        keys[t] = ((unsigned long long)(0xffffffffu - tile_count[t]) << 32) | (uint32_t)t;
+    __syncthreads();
+    bitonic_sort(keys, (uint32_t)T, 1024);
+    for (int t = threadIdx.x; t < T; t += 1024) order[t] = (uint32_t)keys[t];
+}
+
 // write the tile's records in sorted order: 4 lanes move one 64-byte record
 __device__ __forceinline__ void gather_records(const unsigned long long* keys, uint32_t n,
                                                const SplatRec* __restrict__ geom,

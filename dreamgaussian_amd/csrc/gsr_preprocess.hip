@@ -117,12 +117,27 @@ __device__ __forceinline__ void stage_rows_in(const float* __restrict__ src, flo
     const int total = cnt * rowlen;
     const int pitch = rowlen + 1;
     if ((rowlen & 3) == 0) {
+        // all of a thread's loads are issued before the first LDS write: one HBM round trip per
+        // batch of STAGE_U loads instead of one per load (the simple loop waits on every load)
+        constexpr int STAGE_U = 12;
         const float4* s4 = reinterpret_cast<const float4*>(src);
-        for (int i = threadIdx.x; i < total / 4; i += blockDim.x) {
-            const float4 v = s4[i];
-            const int e = 4 * i, row = e / rowlen, col = e - row * rowlen;  // rowlen%4==0: no row straddle
-            float* d = lds + row * pitch + col;
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        const int nvec = total / 4, stride = blockDim.x;
+        for (int i0 = threadIdx.x; i0 < nvec; i0 += stride * STAGE_U) {
+            float4 v[STAGE_U];
+#pragma unroll
+            for (int u = 0; u < STAGE_U; ++u) {
+                const int i = i0 + u * stride;
+                if (i < nvec) v[u] = s4[i];
+            }
+#pragma unroll
+            for (int u = 0; u < STAGE_U; ++u) {
+                const int i = i0 + u * stride;
+                if (i < nvec) {
+                    const int e = 4 * i, row = e / rowlen, col = e - row * rowlen;  // rowlen%4==0: no row straddle
+                    float* d = lds + row * pitch + col;
+                    d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+                }
+            }
         }
     } else {
         for (int e = threadIdx.x; e < total; e += blockDim.x) {

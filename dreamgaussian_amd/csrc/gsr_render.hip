@@ -182,7 +182,7 @@ __device__ __forceinline__ const float4* list_record(const SplatRec* __restrict_
     return reinterpret_cast<const float4*>(BY_ID ? recs + ids[i] : recs + i);
 }
 
-template <bool BY_ID>
+template <bool BY_ID, bool SCHED>
 __global__ void __launch_bounds__(256)
 gsr_render_fwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict__ recs,
                const uint32_t* __restrict__ ids,
@@ -190,9 +190,10 @@ gsr_render_fwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict
                float* __restrict__ out_color, float* __restrict__ out_depth,
                float* __restrict__ out_alpha, float* __restrict__ final_T,
                uint32_t* __restrict__ n_contrib, float* __restrict__ totals /*[5][H*W]*/,
-               float* __restrict__ ckpt, const uint32_t* __restrict__ tile_seg) {
+               float* __restrict__ ckpt, const uint32_t* __restrict__ tile_seg,
+               const uint32_t* __restrict__ tile_order /* heaviest tile first, or NULL */) {
     __shared__ float4 stage[4][3][GSR_RB + 2];             // 12.4 KiB: [wave][field group][slot (+2 pad)]
-    const int tile = blockIdx.x;
+    const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int bx = (tile % gx) * GSR_TILE + (wave & 1) * 8;
@@ -211,12 +212,12 @@ gsr_render_fwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict
     bool done = !inside;
 
     // ea = x y qa qb | eb = qc opac r g | ec = b depth pos -
-#define GSR_FWD_ENTRY(ea, eb, ec)                                                              \
+#define GSR_FWD_ENTRY(ea, eb, ec, valid)                                                       \
     {                                                                                          \
         const float dx = ea.x - pxf, dy = ea.y - pyf;                                          \
         const float power = ea.z * dx * dx + eb.x * dy * dy + ea.w * dx * dy; /* log2 units */ \
         const float alpha = fminf(0.99f, eb.y * fast_exp2(power));                             \
-        const bool ok = !done && (power <= 0.f) && (alpha >= (1.0f / 255.0f));                 \
+        const bool ok = (valid) && !done && (power <= 0.f) && (alpha >= (1.0f / 255.0f));      \
         const float test_T = T * (1.f - alpha);                                                \
         const bool stop = ok && (test_T < 0.0001f);                                            \
         const bool acc = ok && !stop;                                                          \
@@ -229,6 +230,9 @@ gsr_render_fwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict
     }
 
     const uint32_t seg_slot0 = tile_seg[tile];
+    // padding slots are read (never used): keep them finite so that 0 * garbage stays 0
+    for (int q = lane; q < 3 * (GSR_RB + 2); q += 64) (&stage[wave][0][0])[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    wave_lds_handoff();
     // Two-deep fetch pipeline: while round r is composited, the records of round r+1 (whose
     // list entries were fetched during round r-1) and the list entries of round r+2 are in flight.
     float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra;
@@ -273,11 +277,19 @@ gsr_render_fwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict
             }
             wave_lds_handoff();
             float4 e0a = sa[0], e0b = sb[0], e0c = sc[0];
-            for (int j = 0; j < n; j += 2) {              // slots n, n+1 are padding: read, never used
+            // two entries per trip, both unconditional (the second is masked off on an odd tail) so
+            // that the body stays one basic block and the LDS reads are issued ahead of their use
+            for (int j = 0; j < n; j += 2) {              // slots n, n+1 are padding: read, masked
                 const float4 e1a = sa[j + 1], e1b = sb[j + 1], e1c = sc[j + 1];   // in flight during entry j
-                GSR_FWD_ENTRY(e0a, e0b, e0c)
+                GSR_FWD_ENTRY(e0a, e0b, e0c, true)
                 e0a = sa[j + 2]; e0b = sb[j + 2]; e0c = sc[j + 2];               // in flight during entry j+1
-                if (j + 1 < n) GSR_FWD_ENTRY(e1a, e1b, e1c)
+                GSR_FWD_ENTRY(e1a, e1b, e1c, j + 1 < n)
+                if constexpr (SCHED) {   // pin the interleave: reads j+1 | math j | reads j+2 | math j+1
+                    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 22, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 22, 0);
+                }
             }
             wave_lds_handoff();                           // reads above precede the next round's writes
         }
@@ -436,8 +448,9 @@ gsr_render_bwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict
 #undef GSR_BWD_ENTRY
 }
 
-template __global__ void gsr_render_fwd<false>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, float*, float*, float*, float*, uint32_t*, float*, float*, const uint32_t*);
-template __global__ void gsr_render_fwd<true>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, float*, float*, float*, float*, uint32_t*, float*, float*, const uint32_t*);
+#define GSR_FWD_INST(B, S) template __global__ void gsr_render_fwd<B, S>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, float*, float*, float*, float*, uint32_t*, float*, float*, const uint32_t*, const uint32_t*);
+GSR_FWD_INST(false, false) GSR_FWD_INST(true, false) GSR_FWD_INST(false, true) GSR_FWD_INST(true, true)
+#undef GSR_FWD_INST
 template __global__ void gsr_render_bwd<false>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, const float*, const uint32_t*, const float*, const float*, const float*, float*);
 template __global__ void gsr_render_bwd<true>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, const float*, const uint32_t*, const float*, const float*, const float*, float*);
 
@@ -513,7 +526,7 @@ gsr_render_bwd_f2b(const uint32_t* __restrict__ tile_off, const SplatRec* __rest
     const bool row_leader = (lane & 15) == 0;
 
     // ea = x y qa qb | eb = qc opac r g | ec = b depth pos - | ed = id - - -
-#define GSR_F2B_ENTRY(ea, eb, ec, ed)                                                            \
+#define GSR_F2B_ENTRY(ea, eb, ec, ed, valid)                                                     \
     {                                                                                            \
         const float qa = ea.z, qb = ea.w, qc = eb.x, opac = eb.y;                                \
         const uint32_t kpos = __float_as_uint(ec.z);                                             \
@@ -521,7 +534,7 @@ gsr_render_bwd_f2b(const uint32_t* __restrict__ tile_off, const SplatRec* __rest
         const float power = qa * dx * dx + qc * dy * dy + qb * dx * dy;                          \
         const float G = fast_exp2(power);                                                        \
         const float alpha = fminf(0.99f, opac * G);                                              \
-        const bool ok = (kpos <= last_contrib) && (power <= 0.f) && (alpha >= (1.0f / 255.0f));  \
+        const bool ok = (valid) && (kpos <= last_contrib) && (power <= 0.f) && (alpha >= (1.0f / 255.0f)); \
         if (__ballot(ok) != 0ull) {                       /* somebody in this block blended it */ \
             float dL_dal = 0.f, w = 0.f;                  /* stay 0 in lanes that did not blend */  \
             if (ok) {                                                                            \
@@ -557,6 +570,8 @@ gsr_render_bwd_f2b(const uint32_t* __restrict__ tile_off, const SplatRec* __rest
         }                                                                                        \
     }
 
+    for (int q = lane; q < 4 * (GSR_RB + 2); q += 64) (&stage[wave][0][0])[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    wave_lds_handoff();
     // two-deep fetch pipeline as in the forward
     float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra, rd = ra;
     uint32_t id_next = 0;
@@ -596,9 +611,9 @@ gsr_render_bwd_f2b(const uint32_t* __restrict__ tile_off, const SplatRec* __rest
             float4 e0a = sa[0], e0b = sb[0], e0c = sc[0], e0d = sd[0];
             for (int j = 0; j < cnt; j += 2) {            // slots cnt, cnt+1 are padding: read, never used
                 const float4 e1a = sa[j + 1], e1b = sb[j + 1], e1c = sc[j + 1], e1d = sd[j + 1];
-                GSR_F2B_ENTRY(e0a, e0b, e0c, e0d)
+                GSR_F2B_ENTRY(e0a, e0b, e0c, e0d, true)
                 e0a = sa[j + 2]; e0b = sb[j + 2]; e0c = sc[j + 2]; e0d = sd[j + 2];
-                if (j + 1 < cnt) GSR_F2B_ENTRY(e1a, e1b, e1c, e1d)
+                GSR_F2B_ENTRY(e1a, e1b, e1c, e1d, j + 1 < cnt)
             }
             wave_lds_handoff();
         }
