@@ -289,11 +289,9 @@ extern "C" int gsr_forward(const GsrView* view, int32_t N, int32_t K,
     }
     prof_begin(stream); hipLaunchKernelGGL(gsr_tile_scan, dim3(1), dim3(1024), 0, stream, tile_count, tile_off, T, counters, tile_seg);
     LAUNCH_CHECK(view, stream, "tile_scan");
-    if (T <= 8192 && !use_tile_order_off()) {             // heaviest tiles first (64 KiB of LDS keys)
+    if (!use_tile_order_off()) {                          // heaviest tiles first
         tile_order = (uint32_t*)(gbuf + GL.tile_order);
-        static bool attr_set = false;
-        if (!attr_set) { HIP_TRY(hipFuncSetAttribute((const void*)gsr_tile_order, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8)); attr_set = true; }
-        prof_begin(stream); hipLaunchKernelGGL(gsr_tile_order, dim3(1), dim3(1024), (size_t)T * 8, stream, tile_count, T, tile_order);
+        prof_begin(stream); hipLaunchKernelGGL(gsr_tile_order, dim3(1), dim3(1024), 0, stream, tile_count, T, counters, tile_order);
         LAUNCH_CHECK(view, stream, "tile_order");
     }
 

@@ -142,16 +142,38 @@ __device__ __forceinline__ void bitonic_sort(KeyPtr keys, uint32_t n, int nthrea
 
 // Heaviest-first launch order for the compositing forward (longest-processing-time-first: the
 // dispatcher hands workgroups to CUs in index order, so tile weights are dealt round-robin).
-// dynamic LDS: T u64 keys.
+// An approximate order is enough: counting sort of the tiles into 256 weight classes (O(T), a
+// few microseconds; an exact LDS bitonic sort of 2500 keys on one workgroup took 31 us).
 extern "C" __global__ void __launch_bounds__(1024)
-gsr_tile_order(const uint32_t* __restrict__ tile_count, int T, uint32_t* __restrict__ order) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem_raw);
-    for (int t = threadIdx.x; t < T; t += 1024)
-        keys[t] = ((unsigned long long)(0xffffffffu - tile_count[t]) << 32) | (uint32_t)t;
+gsr_tile_order(const uint32_t* __restrict__ tile_count, int T, const unsigned long long* __restrict__ counters,
+               uint32_t* __restrict__ order) {
+    __shared__ uint32_t cls_cnt[256];
+    __shared__ uint32_t cls_off[256];
+    const uint32_t maxc = (uint32_t)counters[3];
+    const float scale = maxc > 0 ? 255.0f / (float)maxc : 0.f;
+    if (threadIdx.x < 256) cls_cnt[threadIdx.x] = 0;
     __syncthreads();
-    bitonic_sort(keys, (uint32_t)T, 1024);
-    for (int t = threadIdx.x; t < T; t += 1024) order[t] = (uint32_t)keys[t];
+    for (int t = threadIdx.x; t < T; t += 1024) {
+        const uint32_t c = 255u - min(255u, (uint32_t)((float)tile_count[t] * scale));   // class 0 = heaviest
+        atomicAdd(&cls_cnt[c], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {                               // exclusive scan of 256 counters by one wave
+        uint32_t v[4], sum = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v[q] = cls_cnt[threadIdx.x * 4 + q]; sum += v[q]; }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(incl, o, 64); if ((int)threadIdx.x >= o) incl += u; }
+        uint32_t run = incl - sum;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { cls_off[threadIdx.x * 4 + q] = run; run += v[q]; }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += 1024) {
+        const uint32_t c = 255u - min(255u, (uint32_t)((float)tile_count[t] * scale));
+        order[atomicAdd(&cls_off[c], 1u)] = (uint32_t)t;
+    }
 }
 
 // write the tile's records in sorted order: 4 lanes move one 64-byte record
