@@ -80,8 +80,11 @@ gsr_scatter(int N, const EmitRec* __restrict__ emit, const uint32_t* __restrict_
         for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < N; idx += gridDim.x * blockDim.x) {
             const uint4 em = reinterpret_cast<const uint4*>(emit)[idx];
             const int x0 = em.x & 0xffff, x1 = em.x >> 16, y0 = em.y & 0xffff, y1 = em.y >> 16;
+            const bool masked = (x1 - x0) * (y1 - y0) <= GSR_EMIT_MASK_TILES;
+            uint32_t bit = 1u;
             for (int ty = y0; ty < y1; ++ty)
-                for (int tx = x0; tx < x1; ++tx) atomicAdd(&hist[ty * gx + tx], 1u);
+                for (int tx = x0; tx < x1; ++tx, bit <<= 1)
+                    if (!masked || (em.w & bit)) atomicAdd(&hist[ty * gx + tx], 1u);
         }
         __syncthreads();
         for (int t = threadIdx.x; t < nTiles; t += blockDim.x) {
@@ -94,8 +97,11 @@ gsr_scatter(int N, const EmitRec* __restrict__ emit, const uint32_t* __restrict_
         const uint4 em = reinterpret_cast<const uint4*>(emit)[idx];
         const int x0 = em.x & 0xffff, x1 = em.x >> 16, y0 = em.y & 0xffff, y1 = em.y >> 16;
         const unsigned long long key = ((unsigned long long)em.z << 32) | (uint32_t)idx;
+        const bool masked = (x1 - x0) * (y1 - y0) <= GSR_EMIT_MASK_TILES;
+        uint32_t bit = 1u;
         for (int ty = y0; ty < y1; ++ty)
-            for (int tx = x0; tx < x1; ++tx) {
+            for (int tx = x0; tx < x1; ++tx, bit <<= 1) {
+                if (masked && !(em.w & bit)) continue;
                 const int t = ty * gx + tx;
                 uint32_t pos;
                 if (hist_in_lds) pos = atomicAdd(&hist[t], 1u);

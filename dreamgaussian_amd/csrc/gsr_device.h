@@ -38,8 +38,10 @@ static_assert(sizeof(SplatRec) == 64, "SplatRec must be 64 bytes");
 
 // per-Gaussian streaming side array for the scatter kernel (coalesced 16 B / lane)
 struct __attribute__((aligned(16))) EmitRec {
-    uint32_t rectx, recty, depth_bits, pad;
+    uint32_t rectx, recty, depth_bits;
+    uint32_t mask;   // rects of <= 32 tiles: bit (ty-y0)*(x1-x0)+(tx-x0) set = emit into that tile
 };
+#define GSR_EMIT_MASK_TILES 32
 
 // screen-space gradient accumulators written by render_bwd (atomics), read by preprocess_bwd
 // [0] sum dL/dG*G*(2qa dx + qb dy)   -> mean2D.x   (times ln2 * 0.5 W later)
@@ -88,6 +90,36 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
         v = v + __int_as_float(m);
     }
     return v;
+}
+
+// ---- exact support test ---------------------------------------------------------------
+// Largest value over the pixel rectangle [x0,x1] x [y0,y1] of the (concave, log2-scaled) exponent
+//   power(p) = qa dx^2 + qb dx dy + qc dy^2,  d = (gx,gy) - p,  qa, qc < 0, 4 qa qc > qb^2.
+// 0 if the centre is inside; otherwise the maximum sits on the boundary, where each edge is a
+// 1-D concave quadratic maximised in closed form. alpha = o * exp2(power) can reach 1/255
+// somewhere in the rectangle only if this value >= -log2(255 o): an exact (not bounding-box)
+// cull of (Gaussian, pixel block) pairs that contribute nothing in the reference either.
+__device__ __forceinline__ float rect_max_power(float gx, float gy, float qa, float qb, float qc,
+                                                float x0, float x1, float y0, float y1) {
+    const float dxl = gx - x1, dxh = gx - x0, dyl = gy - y1, dyh = gy - y0;
+    const float hx = -0.5f * qb * __builtin_amdgcn_rcpf(qa);   // argmax dx = hx * dy on a dy = const edge
+    const float hy = -0.5f * qb * __builtin_amdgcn_rcpf(qc);   // argmax dy = hy * dx on a dx = const edge
+    float best = -3.0e38f;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const float dx = e ? dxh : dxl;
+        const float dy = fminf(fmaxf(hy * dx, dyl), dyh);
+        best = fmaxf(best, qa * dx * dx + (qb * dx + qc * dy) * dy);
+        const float ey = e ? dyh : dyl;
+        const float ex = fminf(fmaxf(hx * ey, dxl), dxh);
+        best = fmaxf(best, qc * ey * ey + (qb * ey + qa * ex) * ex);
+    }
+    const bool inside = (dxl <= 0.f) && (dxh >= 0.f) && (dyl <= 0.f) && (dyh >= 0.f);
+    return inside ? 0.f : best;
+}
+// threshold for the test above, with a margin far above fp32 rounding of the in-kernel exponent
+__device__ __forceinline__ float min_visible_power(float opac) {
+    return -__builtin_amdgcn_logf(255.f * opac) - 1.0e-3f;     // v_log_f32 = log2; NaN/inf for opac <= 0 never passes ">="
 }
 
 // ---- transposing wave reduction (gfx950 v_permlane32_swap / v_permlane16_swap) -------------

@@ -215,7 +215,7 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
         rec.x = rec.y = rec.qa = rec.qb = rec.qc = rec.opac = rec.r = rec.g = rec.b = rec.depth = 0.f;
         rec.id = (uint32_t)idx; rec.bbx = pack16(1, 0); rec.bby = pack16(1, 0);
         rec.rectx = 0; rec.recty = 0; rec.flags = 0;
-        EmitRec em; em.rectx = 0; em.recty = 0; em.depth_bits = 0; em.pad = 0;
+        EmitRec em; em.rectx = 0; em.recty = 0; em.depth_bits = 0; em.mask = 0;
         int32_t radius_out = 0;
 
         const float mx = means3D[3 * idx], my = means3D[3 * idx + 1], mz = means3D[3 * idx + 2];
@@ -327,15 +327,30 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
                         }
                     }
                     if (ex1 > ex0 && ey1 > ey0) {
-                        flags |= GSR_FLAG_EMIT;
-                        rec.rectx = pack16(ex0, ex1); rec.recty = pack16(ey0, ey1);
-                        em.rectx = rec.rectx; em.recty = rec.recty; em.depth_bits = __float_as_uint(pv.z);
+                        // tile-exact emission for small rects: keep a tile only if alpha can reach
+                        // 1/255 on one of its pixels (bit mask travels to the scatter kernel)
+                        const bool masked = (ex1 - ex0) * (ey1 - ey0) <= GSR_EMIT_MASK_TILES;
+                        const float pmin = min_visible_power(op);
+                        uint32_t mask = 0, bit = 1u;
                         for (int ty = ey0; ty < ey1; ++ty)
-                            for (int tx = ex0; tx < ex1; ++tx) {
+                            for (int tx = ex0; tx < ex1; ++tx, bit <<= 1) {
+                                if (masked) {
+                                    const float xa = (float)(tx * GSR_TILE), ya = (float)(ty * GSR_TILE);
+                                    const float xb = fminf(xa + (GSR_TILE - 1), (float)(vc.W - 1));
+                                    const float yb = fminf(ya + (GSR_TILE - 1), (float)(vc.H - 1));
+                                    if (!(rect_max_power(px, py, rec.qa, rec.qb, rec.qc, xa, xb, ya, yb) >= pmin)) continue;
+                                    mask |= bit;
+                                }
                                 const int t = ty * vc.gx + tx;
                                 if (hist_in_lds) atomicAdd(&hist[t], 1u);
                                 else atomicAdd(&tile_count[t], 1u);
                             }
+                        if (!masked || mask != 0u) {
+                            flags |= GSR_FLAG_EMIT;
+                            rec.rectx = pack16(ex0, ex1); rec.recty = pack16(ey0, ey1);
+                            em.rectx = rec.rectx; em.recty = rec.recty; em.depth_bits = __float_as_uint(pv.z);
+                            em.mask = masked ? mask : 0xffffffffu;
+                        }
                     }
                     rec.flags = flags;
                 }

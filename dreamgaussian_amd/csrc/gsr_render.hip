@@ -262,11 +262,9 @@ gsr_render_fwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict
         }
         const uint32_t i = base + lane;
         bool hit = false;
-        if (i < end) {
-            const uint32_t bbx = __float_as_uint(rc.z), bby = __float_as_uint(rc.w);
-            hit = !(unpack_hi16(bbx) < bx || unpack_lo16(bbx) > bx + 7 ||
-                    unpack_hi16(bby) < by || unpack_lo16(bby) > by + 7);
-        }
+        if (i < end)      // can alpha reach 1/255 anywhere in this wave's 8x8 block?
+            hit = rect_max_power(ra.x, ra.y, ra.z, ra.w, rb.x, (float)bx, (float)(bx + 7), (float)by, (float)(by + 7))
+                  >= min_visible_power(rb.y);
         const unsigned long long mask = __ballot(hit);
         if (mask != 0ull) {
             const int n = __popcll(mask);
@@ -594,11 +592,9 @@ gsr_render_bwd_f2b(const uint32_t* __restrict__ tile_off, const SplatRec* __rest
         }
         const uint32_t i = pos0 + lane;
         bool hit = false;
-        if (i < seg_hi) {
-            const uint32_t bbx = __float_as_uint(rc.z), bby = __float_as_uint(rc.w);
-            hit = !(unpack_hi16(bbx) < bx || unpack_lo16(bbx) > bx + 7 ||
-                    unpack_hi16(bby) < by || unpack_lo16(bby) > by + 7);
-        }
+        if (i < seg_hi)
+            hit = rect_max_power(ra.x, ra.y, ra.z, ra.w, rb.x, (float)bx, (float)(bx + 7), (float)by, (float)(by + 7))
+                  >= min_visible_power(rb.y);
         const unsigned long long mask = __ballot(hit);
         if (mask != 0ull) {
             const int cnt = __popcll(mask);

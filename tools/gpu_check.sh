@@ -30,6 +30,9 @@ ab)
     echo "== variant [$v] tests"; env $v timeout 600 python -m pytest tests -m gpu -q -p no:cacheprovider --tb=line -x 2>&1 | tail -4
     echo "== variant [$v] bench 1M"; env $v timeout 300 python bench.py --cpu-budget 0 --trace-steps 2>gpurun_out/ab_err.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['ms_per_step_with_events'], d['kernels_ms_per_step'])"
     grep "step ms" gpurun_out/ab_err.log
+    if [ -n "$AB_TRAINED" ]; then
+      echo "== variant [$v] bench 1M trained"; env $v timeout 300 python bench.py --cpu-budget 0 --kind trained 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['config']['M'], d['config']['M_emitted'], d['kernels_ms_per_step'])"
+    fi
   done;;
 pmc)
   echo "== rocprofv3 PMC passes (1M)"
