@@ -185,6 +185,18 @@ bool use_fwd_sched() {
     static const bool v = [] { const char* e = getenv("GSR_FWD_SCHED"); return e && e[0] == '1'; }();
     return v;
 }
+// GSR_CULL: "exact" (default) = ellipse-vs-block test in both compositing kernels' staging,
+// "aabb" = bounding-box test, "fwd" / "bwd" = exact in that kernel only.
+int cull_mode(bool fwd) {
+    static const int v = [] {
+        const char* e = getenv("GSR_CULL");
+        if (!e || strcmp(e, "exact") == 0) return 3;
+        if (strcmp(e, "fwd") == 0) return 1;
+        if (strcmp(e, "bwd") == 0) return 2;
+        return 0;
+    }();
+    return fwd ? (v & 1) : ((v >> 1) & 1);
+}
 bool use_bwd_b2f() {
     static const bool v = [] { const char* e = getenv("GSR_BWD"); return e && strcmp(e, "b2f") == 0; }();
     return v;
@@ -367,7 +379,7 @@ extern "C" int gsr_forward(const GsrView* view, int32_t N, int32_t K,
     else {
 #define GSR_LAUNCH_FWD(B, S, RECS, IDS)                                                              \
         hipLaunchKernelGGL((gsr_render_fwd<B, S>), dim3(T), dim3(256), 0, stream, tile_off, RECS, IDS, view->bg, W, H, vc.gx, \
-                           out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, tile_order)
+                           out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, tile_order, cull_mode(true))
         const bool sched = use_fwd_sched();
         if (copy) { if (sched) GSR_LAUNCH_FWD(false, true, srecs, (const uint32_t*)nullptr); else GSR_LAUNCH_FWD(false, false, srecs, (const uint32_t*)nullptr); }
         else { if (sched) GSR_LAUNCH_FWD(true, true, recs, sorted_ids); else GSR_LAUNCH_FWD(true, false, recs, sorted_ids); }
@@ -444,10 +456,10 @@ extern "C" int gsr_backward(const GsrView* view, int32_t N, int32_t K,
         const unsigned segs = (unsigned)((maxc + GSR_SEG - 1) / GSR_SEG);
         if (copy)
             hipLaunchKernelGGL(gsr_render_bwd_f2b<false>, dim3(T, segs), dim3(256), 0, stream, tile_off, srecs, (const uint32_t*)nullptr, view->bg, W, H, vc.gx,
-                               final_T, n_contrib, totals, ckpt, tile_seg, dL_dcolor, dL_ddepth, dL_dalpha, g2d);
+                               final_T, n_contrib, totals, ckpt, tile_seg, dL_dcolor, dL_ddepth, dL_dalpha, g2d, cull_mode(false));
         else
             hipLaunchKernelGGL(gsr_render_bwd_f2b<true>, dim3(T, segs), dim3(256), 0, stream, tile_off, recs, (const uint32_t*)bin, view->bg, W, H, vc.gx,
-                               final_T, n_contrib, totals, ckpt, tile_seg, dL_dcolor, dL_ddepth, dL_dalpha, g2d);
+                               final_T, n_contrib, totals, ckpt, tile_seg, dL_dcolor, dL_ddepth, dL_dalpha, g2d, cull_mode(false));
     }
     LAUNCH_CHECK(view, stream, "render_bwd");
 

@@ -191,7 +191,7 @@ gsr_render_fwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict
                float* __restrict__ out_alpha, float* __restrict__ final_T,
                uint32_t* __restrict__ n_contrib, float* __restrict__ totals /*[5][H*W]*/,
                float* __restrict__ ckpt, const uint32_t* __restrict__ tile_seg,
-               const uint32_t* __restrict__ tile_order /* heaviest tile first, or NULL */) {
+               const uint32_t* __restrict__ tile_order /* heaviest tile first, or NULL */, int exact_cull) {
     __shared__ float4 stage[4][3][GSR_RB + 2];             // 12.4 KiB: [wave][field group][slot (+2 pad)]
     const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -262,9 +262,16 @@ gsr_render_fwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict
         }
         const uint32_t i = base + lane;
         bool hit = false;
-        if (i < end)      // can alpha reach 1/255 anywhere in this wave's 8x8 block?
-            hit = rect_max_power(ra.x, ra.y, ra.z, ra.w, rb.x, (float)bx, (float)(bx + 7), (float)by, (float)(by + 7))
-                  >= min_visible_power(rb.y);
+        if (i < end) {    // can alpha reach 1/255 anywhere in this wave's 8x8 block?
+            if (exact_cull) {
+                hit = rect_max_power(ra.x, ra.y, ra.z, ra.w, rb.x, (float)bx, (float)(bx + 7), (float)by, (float)(by + 7))
+                      >= min_visible_power(rb.y);
+            } else {
+                const uint32_t bbx = __float_as_uint(rc.z), bby = __float_as_uint(rc.w);
+                hit = !(unpack_hi16(bbx) < bx || unpack_lo16(bbx) > bx + 7 ||
+                        unpack_hi16(bby) < by || unpack_lo16(bby) > by + 7);
+            }
+        }
         const unsigned long long mask = __ballot(hit);
         if (mask != 0ull) {
             const int n = __popcll(mask);
@@ -446,7 +453,7 @@ gsr_render_bwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict
 #undef GSR_BWD_ENTRY
 }
 
-#define GSR_FWD_INST(B, S) template __global__ void gsr_render_fwd<B, S>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, float*, float*, float*, float*, uint32_t*, float*, float*, const uint32_t*, const uint32_t*);
+#define GSR_FWD_INST(B, S) template __global__ void gsr_render_fwd<B, S>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, float*, float*, float*, float*, uint32_t*, float*, float*, const uint32_t*, const uint32_t*, int);
 GSR_FWD_INST(false, false) GSR_FWD_INST(true, false) GSR_FWD_INST(false, true) GSR_FWD_INST(true, true)
 #undef GSR_FWD_INST
 template __global__ void gsr_render_bwd<false>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, const float*, const uint32_t*, const float*, const float*, const float*, float*);
@@ -474,7 +481,7 @@ gsr_render_bwd_f2b(const uint32_t* __restrict__ tile_off, const SplatRec* __rest
                    const float* __restrict__ totals, const float* __restrict__ ckpt,
                    const uint32_t* __restrict__ tile_seg,
                    const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
-                   const float* __restrict__ dL_dalpha, float* __restrict__ g2d) {
+                   const float* __restrict__ dL_dalpha, float* __restrict__ g2d, int exact_cull) {
     __shared__ float4 stage[4][4][GSR_RB + 2];             // 16.5 KiB (+2 pad slots)
     const int tile = blockIdx.x;
     const uint32_t seg = blockIdx.y;
@@ -592,9 +599,16 @@ gsr_render_bwd_f2b(const uint32_t* __restrict__ tile_off, const SplatRec* __rest
         }
         const uint32_t i = pos0 + lane;
         bool hit = false;
-        if (i < seg_hi)
-            hit = rect_max_power(ra.x, ra.y, ra.z, ra.w, rb.x, (float)bx, (float)(bx + 7), (float)by, (float)(by + 7))
-                  >= min_visible_power(rb.y);
+        if (i < seg_hi) {
+            if (exact_cull) {
+                hit = rect_max_power(ra.x, ra.y, ra.z, ra.w, rb.x, (float)bx, (float)(bx + 7), (float)by, (float)(by + 7))
+                      >= min_visible_power(rb.y);
+            } else {
+                const uint32_t bbx = __float_as_uint(rc.z), bby = __float_as_uint(rc.w);
+                hit = !(unpack_hi16(bbx) < bx || unpack_lo16(bbx) > bx + 7 ||
+                        unpack_hi16(bby) < by || unpack_lo16(bby) > by + 7);
+            }
+        }
         const unsigned long long mask = __ballot(hit);
         if (mask != 0ull) {
             const int cnt = __popcll(mask);
@@ -618,5 +632,5 @@ gsr_render_bwd_f2b(const uint32_t* __restrict__ tile_off, const SplatRec* __rest
 #undef GSR_F2B_ENTRY
 }
 
-template __global__ void gsr_render_bwd_f2b<false>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, const float*, const uint32_t*, const float*, const float*, const uint32_t*, const float*, const float*, const float*, float*);
-template __global__ void gsr_render_bwd_f2b<true>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, const float*, const uint32_t*, const float*, const float*, const uint32_t*, const float*, const float*, const float*, float*);
+template __global__ void gsr_render_bwd_f2b<false>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, const float*, const uint32_t*, const float*, const float*, const uint32_t*, const float*, const float*, const float*, float*, int);
+template __global__ void gsr_render_bwd_f2b<true>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, const float*, const uint32_t*, const float*, const float*, const uint32_t*, const float*, const float*, const float*, float*, int);
