@@ -473,7 +473,7 @@ template __global__ void gsr_render_bwd<true>(const uint32_t*, const SplatRec*, 
 // sequential walk drops from the tile's whole list (8.5k entries at 1M Gaussians) to GSR_SEG.
 // =========================================================================================
 template <bool BY_ID>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 8)   // <= 64 VGPRs: the kernel leans on 8 waves/SIMD to cover its cross-lane chains
 gsr_render_bwd_f2b(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict__ recs,
                    const uint32_t* __restrict__ ids,
                    const float* __restrict__ bg, int W, int H, int gx,
@@ -516,7 +516,8 @@ gsr_render_bwd_f2b(const uint32_t* __restrict__ tile_off, const SplatRec* __rest
     const uint32_t wave_last = __builtin_amdgcn_readfirstlane(wave_max_u32(last_contrib));
     if (wave_last <= seg_lo) return;                      // nothing in this segment was blended here
     const uint32_t seg_hi = min(seg_lo + (uint32_t)GSR_SEG, wave_last);
-    const float tfbg = T_final * (bg[0] * gC0 + bg[1] * gC1 + bg[2] * gC2);
+    // everything behind entry i: (total + T_final bg.g) - prefix_i - w_i (c_i.g)
+    const float Cg_behind0 = Cg_total + T_final * (bg[0] * gC0 + bg[1] * gC1 + bg[2] * gC2);
 
     float T = 1.f, Cgf = 0.f;                             // transmittance and c.g prefix before the segment
     if (seg > 0) {
@@ -547,7 +548,7 @@ gsr_render_bwd_f2b(const uint32_t* __restrict__ tile_off, const SplatRec* __rest
                 const float oma = 1.f - alpha;                                                   \
                 w = alpha * T;                                                                   \
                 const float wc = w * cgi;                                                        \
-                dL_dal = T * cgi - (Cg_total - Cgf - wc + tfbg) * fast_rcp(oma);                 \
+                dL_dal = T * cgi - (Cg_behind0 - Cgf - wc) * fast_rcp(oma);                       \
                 Cgf += wc;                                                                       \
                 T *= oma;                                                                        \
             }                                                                                    \
@@ -577,29 +578,14 @@ gsr_render_bwd_f2b(const uint32_t* __restrict__ tile_off, const SplatRec* __rest
 
     for (int q = lane; q < 4 * (GSR_RB + 2); q += 64) (&stage[wave][0][0])[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     wave_lds_handoff();
-    // two-deep fetch pipeline as in the forward
-    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra, rd = ra;
-    uint32_t id_next = 0;
-    if (seg_lo + lane < seg_hi) {
-        const float4* __restrict__ p = list_record<BY_ID>(recs, ids, start + seg_lo + lane);
-        ra = p[0]; rb = p[1]; rc = p[2]; rd = p[3];
-    }
-    if (BY_ID && seg_lo + GSR_RB + lane < seg_hi) id_next = ids[start + seg_lo + GSR_RB + lane];
     for (uint32_t pos0 = seg_lo; pos0 < seg_hi; pos0 += GSR_RB) {   // 0-based positions pos0 .. pos0+63
-        float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na, nc = na, nd = na;
-        uint32_t id_next2 = 0;
-        {
-            const uint32_t i1 = pos0 + GSR_RB + lane;
-            if (i1 < seg_hi) {
-                const float4* __restrict__ p = reinterpret_cast<const float4*>(BY_ID ? recs + id_next : recs + (start + i1));
-                na = p[0]; nb = p[1]; nc = p[2]; nd = p[3];
-            }
-            const uint32_t i2 = pos0 + 2 * GSR_RB + lane;
-            if (BY_ID && i2 < seg_hi) id_next2 = ids[start + i2];
-        }
+        // (a two-deep prefetch of the next round's records measured no gain here and costs 18 VGPRs)
         const uint32_t i = pos0 + lane;
         bool hit = false;
+        float4 ra, rb, rc, rd;
         if (i < seg_hi) {
+            const float4* __restrict__ p = list_record<BY_ID>(recs, ids, start + i);
+            ra = p[0]; rb = p[1]; rc = p[2]; rd = p[3];
             if (exact_cull) {
                 hit = rect_max_power(ra.x, ra.y, ra.z, ra.w, rb.x, (float)bx, (float)(bx + 7), (float)by, (float)(by + 7))
                       >= min_visible_power(rb.y);
@@ -627,7 +613,6 @@ gsr_render_bwd_f2b(const uint32_t* __restrict__ tile_off, const SplatRec* __rest
             }
             wave_lds_handoff();
         }
-        ra = na; rb = nb; rc = nc; rd = nd; id_next = id_next2;
     }
 #undef GSR_F2B_ENTRY
 }
