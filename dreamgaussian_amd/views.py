@@ -50,7 +50,12 @@ def gather_views_async(color: torch.Tensor, depth: torch.Tensor, alpha: torch.Te
         buf[0].copy_(local)
         return None
     glist = [buf[i] for i in range(world)] if rank == dst else None
-    return dist.gather(local, glist, dst=dst, group=group, async_op=True)
+    try:
+        return dist.gather(local, glist, dst=dst, group=group, async_op=True)
+    except (RuntimeError, NotImplementedError):
+        # a backend without gather: every rank receives every view (same bytes per link on xGMI)
+        full = buf if rank == dst else torch.empty_like(buf)
+        return dist.all_gather_into_tensor(full.view(-1), local.view(-1), group=group, async_op=True)
 
 
 def gather_images(local: torch.Tensor, dst: Optional[int] = 0, group=None) -> Optional[torch.Tensor]:
