@@ -99,6 +99,7 @@ GeomLayout geom_layout(int N, int H, int W) {
     L.total = o;
     return L;
 }
+int seg_shift();
 struct BinLayout { size_t entries, recs, ckpt, total; };
 BinLayout bin_layout(size_t M, bool copy) {
     BinLayout L;
@@ -107,8 +108,8 @@ BinLayout bin_layout(size_t M, bool copy) {
     // it at offset 0 without knowing M
     L.recs = o; o += align_up(M * (copy ? sizeof(SplatRec) : 4));
     L.entries = o; o += align_up(M * 8);
-    // backward checkpoints: sum over tiles of floor((n_t-1)/GSR_SEG) <= M/GSR_SEG slots
-    L.ckpt = o; o += align_up((M / GSR_SEG + 1) * (size_t)GSR_CKPT_FLOATS * 4);
+    // backward checkpoints: sum over tiles of floor((n_t-1) >> seg_shift) <= (M >> seg_shift) slots
+    L.ckpt = o; o += align_up(((M >> seg_shift()) + 1) * (size_t)GSR_CKPT_FLOATS * 4);
     L.total = o < 256 ? 256 : o;
     return L;
 }
@@ -196,6 +197,15 @@ int cull_mode(bool fwd) {
         return 0;
     }();
     return fwd ? (v & 1) : ((v >> 1) & 1);
+}
+// GSR_SEG_SHIFT: log2 of the backward segment length in list positions (default 10).
+int seg_shift() {
+    static const int v = [] {
+        const char* e = getenv("GSR_SEG_SHIFT");
+        const int s = e ? atoi(e) : GSR_SEG_SHIFT_DEFAULT;
+        return (s < 6 || s > 14) ? GSR_SEG_SHIFT_DEFAULT : s;      // multiples of the 64-entry fetch round
+    }();
+    return v;
 }
 bool use_bwd_b2f() {
     static const bool v = [] { const char* e = getenv("GSR_BWD"); return e && strcmp(e, "b2f") == 0; }();
@@ -299,7 +309,7 @@ extern "C" int gsr_forward(const GsrView* view, int32_t N, int32_t K,
                            tile_count, counters, hist_in_lds, sh_direct);
         LAUNCH_CHECK(view, stream, "preprocess_fwd");
     }
-    prof_begin(stream); hipLaunchKernelGGL(gsr_tile_scan, dim3(1), dim3(1024), 0, stream, tile_count, tile_off, T, counters, tile_seg);
+    prof_begin(stream); hipLaunchKernelGGL(gsr_tile_scan, dim3(1), dim3(1024), 0, stream, tile_count, tile_off, T, counters, tile_seg, seg_shift());
     LAUNCH_CHECK(view, stream, "tile_scan");
     if (!use_tile_order_off()) {                          // heaviest tiles first
         tile_order = (uint32_t*)(gbuf + GL.tile_order);
@@ -379,7 +389,7 @@ extern "C" int gsr_forward(const GsrView* view, int32_t N, int32_t K,
     else {
 #define GSR_LAUNCH_FWD(B, S, RECS, IDS)                                                              \
         hipLaunchKernelGGL((gsr_render_fwd<B, S>), dim3(T), dim3(256), 0, stream, tile_off, RECS, IDS, view->bg, W, H, vc.gx, \
-                           out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, tile_order, cull_mode(true))
+                           out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, tile_order, cull_mode(true), seg_shift())
         const bool sched = use_fwd_sched();
         if (copy) { if (sched) GSR_LAUNCH_FWD(false, true, srecs, (const uint32_t*)nullptr); else GSR_LAUNCH_FWD(false, false, srecs, (const uint32_t*)nullptr); }
         else { if (sched) GSR_LAUNCH_FWD(true, true, recs, sorted_ids); else GSR_LAUNCH_FWD(true, false, recs, sorted_ids); }
@@ -453,13 +463,13 @@ extern "C" int gsr_backward(const GsrView* view, int32_t N, int32_t K,
     } else if (M > 0) {
         const bool copy = use_record_copy();
         const float* ckpt = (const float*)((const char*)bin + bin_layout((size_t)M, copy).ckpt);
-        const unsigned segs = (unsigned)((maxc + GSR_SEG - 1) / GSR_SEG);
+        const unsigned segs = (unsigned)((maxc + (1ull << seg_shift()) - 1) >> seg_shift());
         if (copy)
             hipLaunchKernelGGL(gsr_render_bwd_f2b<false>, dim3(T, segs), dim3(256), 0, stream, tile_off, srecs, (const uint32_t*)nullptr, view->bg, W, H, vc.gx,
-                               final_T, n_contrib, totals, ckpt, tile_seg, dL_dcolor, dL_ddepth, dL_dalpha, g2d, cull_mode(false));
+                               final_T, n_contrib, totals, ckpt, tile_seg, dL_dcolor, dL_ddepth, dL_dalpha, g2d, cull_mode(false), seg_shift());
         else
             hipLaunchKernelGGL(gsr_render_bwd_f2b<true>, dim3(T, segs), dim3(256), 0, stream, tile_off, recs, (const uint32_t*)bin, view->bg, W, H, vc.gx,
-                               final_T, n_contrib, totals, ckpt, tile_seg, dL_dcolor, dL_ddepth, dL_dalpha, g2d, cull_mode(false));
+                               final_T, n_contrib, totals, ckpt, tile_seg, dL_dcolor, dL_ddepth, dL_dalpha, g2d, cull_mode(false), seg_shift());
     }
     LAUNCH_CHECK(view, stream, "render_bwd");
 

@@ -18,8 +18,8 @@
 // ---------------------------------------------------------------------------------------
 extern "C" __global__ void __launch_bounds__(1024)
 gsr_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_off, int T,
-              unsigned long long* __restrict__ counters, uint32_t* __restrict__ tile_seg) {
-    // tile_seg[t] = index of tile t's first checkpoint slot = exclusive scan of floor((n_t-1)/GSR_SEG)
+              unsigned long long* __restrict__ counters, uint32_t* __restrict__ tile_seg, int seg_shift) {
+    // tile_seg[t] = index of tile t's first checkpoint slot = exclusive scan of floor((n_t-1) >> seg_shift)
     __shared__ unsigned long long wsum[16];
     __shared__ uint32_t wsegs[16];
     __shared__ uint32_t wmax[16];
@@ -29,7 +29,7 @@ gsr_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ ti
     uint32_t lmax = 0, lsegs = 0;
     for (int i = beg; i < end; ++i) {
         const uint32_t c = tile_count[i];
-        local += c; lmax = max(lmax, c); lsegs += c ? (c - 1) / GSR_SEG : 0u;
+        local += c; lmax = max(lmax, c); lsegs += c ? (c - 1) >> seg_shift : 0u;
     }
     // inclusive scan inside the wave
     unsigned long long incl = local;
@@ -53,7 +53,7 @@ gsr_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ ti
     for (int i = beg; i < end; ++i) {
         const uint32_t c = tile_count[i];
         tile_off[i] = (uint32_t)run; run += c;
-        tile_seg[i] = srun; srun += c ? (c - 1) / GSR_SEG : 0u;
+        tile_seg[i] = srun; srun += c ? (c - 1) >> seg_shift : 0u;
     }
     if (threadIdx.x == 1023) {
         tile_off[T] = (uint32_t)(wave_base + incl);

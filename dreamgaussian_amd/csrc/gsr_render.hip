@@ -191,7 +191,8 @@ gsr_render_fwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict
                float* __restrict__ out_alpha, float* __restrict__ final_T,
                uint32_t* __restrict__ n_contrib, float* __restrict__ totals /*[5][H*W]*/,
                float* __restrict__ ckpt, const uint32_t* __restrict__ tile_seg,
-               const uint32_t* __restrict__ tile_order /* heaviest tile first, or NULL */, int exact_cull) {
+               const uint32_t* __restrict__ tile_order /* heaviest tile first, or NULL */, int exact_cull,
+               int seg_shift) {
     __shared__ float4 stage[4][3][GSR_RB + 2];             // 12.4 KiB: [wave][field group][slot (+2 pad)]
     const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -256,8 +257,8 @@ gsr_render_fwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict
             if (BY_ID && i2 < end) id_next2 = ids[i2];
         }
         const uint32_t rel = base - start;
-        if (rel != 0u && (rel & (GSR_SEG - 1)) == 0u) {    // segment cut: checkpoint for the backward
-            float* c = ckpt + (size_t)(seg_slot0 + rel / GSR_SEG - 1u) * GSR_CKPT_FLOATS + (wave * 64 + lane);
+        if (rel != 0u && (rel & ((1u << seg_shift) - 1u)) == 0u) {    // segment cut: checkpoint for the backward
+            float* c = ckpt + (size_t)(seg_slot0 + (rel >> seg_shift) - 1u) * GSR_CKPT_FLOATS + (wave * 64 + lane);
             c[0] = T; c[256] = C0; c[512] = C1; c[768] = C2; c[1024] = D; c[1280] = A;
         }
         const uint32_t i = base + lane;
@@ -453,7 +454,7 @@ gsr_render_bwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict
 #undef GSR_BWD_ENTRY
 }
 
-#define GSR_FWD_INST(B, S) template __global__ void gsr_render_fwd<B, S>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, float*, float*, float*, float*, uint32_t*, float*, float*, const uint32_t*, const uint32_t*, int);
+#define GSR_FWD_INST(B, S) template __global__ void gsr_render_fwd<B, S>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, float*, float*, float*, float*, uint32_t*, float*, float*, const uint32_t*, const uint32_t*, int, int);
 GSR_FWD_INST(false, false) GSR_FWD_INST(true, false) GSR_FWD_INST(false, true) GSR_FWD_INST(true, true)
 #undef GSR_FWD_INST
 template __global__ void gsr_render_bwd<false>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, const float*, const uint32_t*, const float*, const float*, const float*, float*);
@@ -469,8 +470,8 @@ template __global__ void gsr_render_bwd<true>(const uint32_t*, const SplatRec*, 
 // prefix) are needed, the five per-channel "colour behind" recurrences of the back-to-front
 // form collapse into one, there is no T/(1-alpha) unrolling, and a tile's list can be cut into
 // independent segments: the forward leaves (T, C0, C1, C2, D, A) per pixel at every
-// GSR_SEG-th list position, and workgroup (tile, s) starts from checkpoint s. The longest
-// sequential walk drops from the tile's whole list (8.5k entries at 1M Gaussians) to GSR_SEG.
+// 2^seg_shift-th list position, and workgroup (tile, s) starts from checkpoint s. The longest
+// sequential walk drops from the tile's whole list (8.5k entries at 1M Gaussians) to one segment.
 // =========================================================================================
 template <bool BY_ID>
 __global__ void __launch_bounds__(256, 8)   // <= 64 VGPRs: the kernel leans on 8 waves/SIMD to cover its cross-lane chains
@@ -481,13 +482,13 @@ gsr_render_bwd_f2b(const uint32_t* __restrict__ tile_off, const SplatRec* __rest
                    const float* __restrict__ totals, const float* __restrict__ ckpt,
                    const uint32_t* __restrict__ tile_seg,
                    const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
-                   const float* __restrict__ dL_dalpha, float* __restrict__ g2d, int exact_cull) {
+                   const float* __restrict__ dL_dalpha, float* __restrict__ g2d, int exact_cull, int seg_shift) {
     __shared__ float4 stage[4][4][GSR_RB + 2];             // 16.5 KiB (+2 pad slots)
     const int tile = blockIdx.x;
     const uint32_t seg = blockIdx.y;
     const uint32_t start = tile_off[tile];
     const uint32_t n = tile_off[tile + 1] - start;
-    const uint32_t seg_lo = seg * GSR_SEG;                 // this workgroup: list positions (seg_lo, seg_hi]
+    const uint32_t seg_lo = seg << seg_shift;              // this workgroup: list positions (seg_lo, seg_hi]
     if (seg_lo >= n) return;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -515,7 +516,7 @@ gsr_render_bwd_f2b(const uint32_t* __restrict__ tile_off, const SplatRec* __rest
     }
     const uint32_t wave_last = __builtin_amdgcn_readfirstlane(wave_max_u32(last_contrib));
     if (wave_last <= seg_lo) return;                      // nothing in this segment was blended here
-    const uint32_t seg_hi = min(seg_lo + (uint32_t)GSR_SEG, wave_last);
+    const uint32_t seg_hi = min(seg_lo + (1u << seg_shift), wave_last);
     // everything behind entry i: (total + T_final bg.g) - prefix_i - w_i (c_i.g)
     const float Cg_behind0 = Cg_total + T_final * (bg[0] * gC0 + bg[1] * gC1 + bg[2] * gC2);
 
@@ -617,5 +618,5 @@ gsr_render_bwd_f2b(const uint32_t* __restrict__ tile_off, const SplatRec* __rest
 #undef GSR_F2B_ENTRY
 }
 
-template __global__ void gsr_render_bwd_f2b<false>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, const float*, const uint32_t*, const float*, const float*, const uint32_t*, const float*, const float*, const float*, float*, int);
-template __global__ void gsr_render_bwd_f2b<true>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, const float*, const uint32_t*, const float*, const float*, const uint32_t*, const float*, const float*, const float*, float*, int);
+template __global__ void gsr_render_bwd_f2b<false>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, const float*, const uint32_t*, const float*, const float*, const uint32_t*, const float*, const float*, const float*, float*, int, int);
+template __global__ void gsr_render_bwd_f2b<true>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, const float*, const uint32_t*, const float*, const float*, const uint32_t*, const float*, const float*, const float*, float*, int, int);

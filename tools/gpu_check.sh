@@ -27,7 +27,7 @@ prof)
 ab)
   # A/B of the env-selectable variants: parity suite + 1M bench for each
   for v in ${AB_VARIANTS:-"GSR_DEFAULT=1" "GSR_BWD=b2f" "GSR_RECORDS=copy"}; do
-    echo "== variant [$v] tests"; env $v timeout 600 python -m pytest tests -m gpu -q -p no:cacheprovider --tb=line -x 2>&1 | tail -4
+    if [ -z "$AB_NOTEST" ]; then echo "== variant [$v] tests"; env $v timeout 600 python -m pytest tests -m gpu -q -p no:cacheprovider --tb=line -x 2>&1 | tail -4; fi
     echo "== variant [$v] bench 1M"; env $v timeout 300 python bench.py --cpu-budget 0 --trace-steps 2>gpurun_out/ab_err.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['ms_per_step_with_events'], d['kernels_ms_per_step'])"
     grep "step ms" gpurun_out/ab_err.log
     if [ -n "$AB_TRAINED" ]; then
