@@ -147,6 +147,34 @@ __device__ __forceinline__ void stage_rows_in(const float* __restrict__ src, flo
     }
 }
 
+// Software-pipelined variant of stage_rows_in for 256-thread blocks and rows of <= 48 floats
+// (K <= 16): the loads of batch i+1 are issued into registers before batch i is computed and
+// are committed to LDS one iteration later, so the HBM round trip hides behind the math.
+constexpr int STAGE_PF = 12;   // 16-byte loads per thread per batch (256 threads x 12 x 16 B = 48 KiB)
+__device__ __forceinline__ void stage_issue(const float* __restrict__ src, int cnt, int rowlen, float4 (&v)[STAGE_PF]) {
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    const int nvec = (cnt * rowlen) >> 2;
+#pragma unroll
+    for (int u = 0; u < STAGE_PF; ++u) {
+        const int i = threadIdx.x + u * 256;
+        if (i < nvec) v[u] = s4[i];
+    }
+}
+template <int RL>   // RL > 0: compile-time row length (48 = SH degree 3), 0: runtime
+__device__ __forceinline__ void stage_commit(float* lds, int cnt, int rowlen_rt, const float4 (&v)[STAGE_PF]) {
+    const int rowlen = RL > 0 ? RL : rowlen_rt;
+    const int nvec = (cnt * rowlen) >> 2, pitch = rowlen + 1;
+#pragma unroll
+    for (int u = 0; u < STAGE_PF; ++u) {
+        const int i = threadIdx.x + u * 256;
+        if (i < nvec) {
+            const int e = 4 * i, row = e / rowlen, col = e - row * rowlen;
+            float* d = lds + row * pitch + col;
+            d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+        }
+    }
+}
+
 __device__ __forceinline__ void stage_rows_out(float* __restrict__ dst, const float* lds,
                                                int cnt, int rowlen) {
     const int total = cnt * rowlen;
@@ -201,11 +229,22 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
     const float* __restrict__ P = vc.proj;
     unsigned long long my_ref = 0, my_vis = 0;
 
+    const bool pipelined = stage && (rowlen & 3) == 0 && rowlen <= 4 * STAGE_PF && blockDim.x == 256;
+    float4 pf[STAGE_PF];
+    if (pipelined && (int)(blockIdx.x * blockDim.x) < N)
+        stage_issue(shs + (size_t)(blockIdx.x * blockDim.x) * rowlen, min((int)blockDim.x, N - (int)(blockIdx.x * blockDim.x)), rowlen, pf);
+
     for (int base = blockIdx.x * blockDim.x; base < N; base += gridDim.x * blockDim.x) {
         const int cnt = min((int)blockDim.x, N - base);
         if (stage) {
             __syncthreads();   // previous batch's readers are done
-            stage_rows_in(shs + (size_t)base * rowlen, shbuf, cnt, rowlen);
+            if (pipelined) {
+                if (rowlen == 48) stage_commit<48>(shbuf, cnt, rowlen, pf); else stage_commit<0>(shbuf, cnt, rowlen, pf);
+                const int next = base + gridDim.x * blockDim.x;
+                if (next < N) stage_issue(shs + (size_t)next * rowlen, min((int)blockDim.x, N - next), rowlen, pf);
+            } else {
+                stage_rows_in(shs + (size_t)base * rowlen, shbuf, cnt, rowlen);
+            }
             __syncthreads();
         }
         const int idx = base + threadIdx.x;
