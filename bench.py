@@ -161,7 +161,7 @@ def main():
     rast = D.GaussianRasterizer(raster_settings=rs)
     gather_buf = views.make_gather_buffer(world, 5, wl["H"], wl["W"], dev) if world > 1 else None
 
-    def step():
+    def step(gather=True):
         for v in t.values():
             v.grad = None
         m2d.grad = None
@@ -170,7 +170,7 @@ def main():
                                           scales=t["scales"], rotations=t["rotations"],
                                           cov3D_precomp=None)
         work = None
-        if world > 1:                                # RCCL gather of the rendered views to rank 0
+        if world > 1 and gather:                     # RCCL gather of the rendered views to rank 0
             work = views.gather_views_async(color, depth, alpha, gather_buf, dst=0)
         torch.autograd.backward([color, depth, alpha], gout)
         if work is not None:
@@ -210,7 +210,7 @@ def main():
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(a.steps):
-            step()
+            step(gather=False)                       # rank 0 only: no collective in this pass
         torch.cuda.synchronize()
         dt_prof = time.perf_counter() - t1
         _lib.profile_enable(False)
