@@ -80,7 +80,7 @@ int launch_status(bool debug, hipStream_t stream, const char* name) {
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 struct GeomLayout {
-    size_t recs, emit, tile_count, cursor, tile_off, tile_seg, tile_order, counters, total;
+    size_t recs, emit, tile_count, cursor, tile_last, tile_off, tile_seg, tile_order, plan_off, counters, total;
     int nTiles;
 };
 GeomLayout geom_layout(int N, int H, int W) {
@@ -92,16 +92,18 @@ GeomLayout geom_layout(int N, int H, int W) {
     L.emit = o; o += align_up((size_t)N * sizeof(EmitRec));
     L.tile_count = o; o += align_up((size_t)L.nTiles * 4);
     L.cursor = o; o += align_up((size_t)L.nTiles * 4);
+    L.tile_last = o; o += align_up((size_t)L.nTiles * 4);
     L.counters = o; o += align_up(8 * 8);
     L.tile_off = o; o += align_up((size_t)(L.nTiles + 1) * 4);
     L.tile_seg = o; o += align_up((size_t)(L.nTiles + 1) * 4);
     L.tile_order = o; o += align_up((size_t)L.nTiles * 4);
+    L.plan_off = o; o += align_up((size_t)L.nTiles * 4);
     L.total = o;
     return L;
 }
 int seg_shift();
-struct BinLayout { size_t entries, recs, ckpt, total; };
-BinLayout bin_layout(size_t M, bool copy) {
+struct BinLayout { size_t entries, recs, ckpt, plan_tile, plan_cap, total; };
+BinLayout bin_layout(size_t M, bool copy, int nTiles) {
     BinLayout L;
     size_t o = 0;
     // first: the sorted list (64-byte records, or 4-byte Gaussian indices) -- the backward finds
@@ -110,6 +112,9 @@ BinLayout bin_layout(size_t M, bool copy) {
     L.entries = o; o += align_up(M * 8);
     // backward checkpoints: sum over tiles of floor((n_t-1) >> seg_shift) <= (M >> seg_shift) slots
     L.ckpt = o; o += align_up(((M >> seg_shift()) + 1) * (size_t)GSR_CKPT_FLOATS * 4);
+    // backward work list: sum over tiles of ceil(last_t / 2^shift) <= (M >> shift) + nTiles entries
+    L.plan_cap = (M >> seg_shift()) + (size_t)nTiles + 1;
+    L.plan_tile = o; o += align_up(L.plan_cap * 4);
     L.total = o < 256 ? 256 : o;
     return L;
 }
@@ -282,6 +287,7 @@ extern "C" int gsr_forward(const GsrView* view, int32_t N, int32_t K,
     uint32_t* cursor = (uint32_t*)(gbuf + GL.cursor);
     uint32_t* tile_off = (uint32_t*)(gbuf + GL.tile_off);
     uint32_t* tile_seg = (uint32_t*)(gbuf + GL.tile_seg);
+    uint32_t* tile_last = (uint32_t*)(gbuf + GL.tile_last);
     uint32_t* tile_order = nullptr;
     unsigned long long* counters = (unsigned long long*)(gbuf + GL.counters);
     float* final_T = (float*)ibuf;
@@ -326,7 +332,7 @@ extern "C" int gsr_forward(const GsrView* view, int32_t N, int32_t K,
     if (M >= 0xfffffff0ull) return fail(-5, "too many tile instances (%s%lld)", "", (long long)M);
 
     const bool copy = use_record_copy();
-    const BinLayout BL = bin_layout((size_t)M, copy);
+    const BinLayout BL = bin_layout((size_t)M, copy, T);
     char* bbuf = (char*)bin.resize(bin.ctx, BL.total);
     if (!bbuf) return fail(-4, "bin scratch allocation failed%s", "");
     unsigned long long* entries = (unsigned long long*)(bbuf + BL.entries);
@@ -389,7 +395,7 @@ extern "C" int gsr_forward(const GsrView* view, int32_t N, int32_t K,
     else {
 #define GSR_LAUNCH_FWD(B, S, RECS, IDS)                                                              \
         hipLaunchKernelGGL((gsr_render_fwd<B, S>), dim3(T), dim3(256), 0, stream, tile_off, RECS, IDS, view->bg, W, H, vc.gx, \
-                           out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, tile_order, cull_mode(true), seg_shift())
+                           out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, tile_order, cull_mode(true), seg_shift(), tile_last)
         const bool sched = use_fwd_sched();
         if (copy) { if (sched) GSR_LAUNCH_FWD(false, true, srecs, (const uint32_t*)nullptr); else GSR_LAUNCH_FWD(false, false, srecs, (const uint32_t*)nullptr); }
         else { if (sched) GSR_LAUNCH_FWD(true, true, recs, sorted_ids); else GSR_LAUNCH_FWD(true, false, recs, sorted_ids); }
@@ -441,6 +447,7 @@ extern "C" int gsr_backward(const GsrView* view, int32_t N, int32_t K,
         HIP_TRY(hipStreamSynchronize(stream));
         M = h[2]; maxc = h[3];
     }
+    (void)maxc;
     const SplatRec* srecs = (const SplatRec*)bin;          // BinLayout.recs == 0
 
     float* g2d = (float*)tmp.resize(tmp.ctx, align_up((size_t)N * GSR_G2D_STRIDE * 4));
@@ -462,14 +469,26 @@ extern "C" int gsr_backward(const GsrView* view, int32_t N, int32_t K,
                                final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, g2d);
     } else if (M > 0) {
         const bool copy = use_record_copy();
-        const float* ckpt = (const float*)((const char*)bin + bin_layout((size_t)M, copy).ckpt);
-        const unsigned segs = (unsigned)((maxc + (1ull << seg_shift()) - 1) >> seg_shift());
+        const BinLayout BL = bin_layout((size_t)M, copy, T);
+        const float* ckpt = (const float*)((const char*)bin + BL.ckpt);
+        // scratch of the matching forward, written here: the backward work list
+        uint32_t* plan_tile = (uint32_t*)((char*)const_cast<void*>(bin) + BL.plan_tile);
+        uint32_t* plan_off = (uint32_t*)(const_cast<char*>(gbuf) + GL.plan_off);
+        unsigned long long* plan_total = const_cast<unsigned long long*>(counters) + 4;
+        const uint32_t* tile_last = (const uint32_t*)(gbuf + GL.tile_last);
+        hipLaunchKernelGGL(gsr_bwd_plan, dim3(1), dim3(1024), 0, stream, tile_last, T, seg_shift(), (uint32_t)BL.plan_cap,
+                           plan_off, plan_tile, plan_total);
+        LAUNCH_CHECK(view, stream, "bwd_plan");
+        prof_begin(stream);
+        const unsigned grid = (unsigned)BL.plan_cap;
         if (copy)
-            hipLaunchKernelGGL(gsr_render_bwd_f2b<false>, dim3(T, segs), dim3(256), 0, stream, tile_off, srecs, (const uint32_t*)nullptr, view->bg, W, H, vc.gx,
-                               final_T, n_contrib, totals, ckpt, tile_seg, dL_dcolor, dL_ddepth, dL_dalpha, g2d, cull_mode(false), seg_shift());
+            hipLaunchKernelGGL(gsr_render_bwd_f2b<false>, dim3(grid), dim3(256), 0, stream, tile_off, srecs, (const uint32_t*)nullptr, view->bg, W, H, vc.gx,
+                               final_T, n_contrib, totals, ckpt, tile_seg, dL_dcolor, dL_ddepth, dL_dalpha, g2d, cull_mode(false), seg_shift(),
+                               plan_tile, plan_off, plan_total);
         else
-            hipLaunchKernelGGL(gsr_render_bwd_f2b<true>, dim3(T, segs), dim3(256), 0, stream, tile_off, recs, (const uint32_t*)bin, view->bg, W, H, vc.gx,
-                               final_T, n_contrib, totals, ckpt, tile_seg, dL_dcolor, dL_ddepth, dL_dalpha, g2d, cull_mode(false), seg_shift());
+            hipLaunchKernelGGL(gsr_render_bwd_f2b<true>, dim3(grid), dim3(256), 0, stream, tile_off, recs, (const uint32_t*)bin, view->bg, W, H, vc.gx,
+                               final_T, n_contrib, totals, ckpt, tile_seg, dL_dcolor, dL_ddepth, dL_dalpha, g2d, cull_mode(false), seg_shift(),
+                               plan_tile, plan_off, plan_total);
     }
     LAUNCH_CHECK(view, stream, "render_bwd");
 

@@ -182,6 +182,40 @@ gsr_tile_order(const uint32_t* __restrict__ tile_count, int T, const unsigned lo
     }
 }
 
+// Work list of the segmented backward: one entry per (tile, segment) whose segment starts before
+// the tile's deepest blended list position (tile_last, written by the forward). A 2-D grid
+// (tiles x longest list) would launch ~6x more workgroups than have work, and at 128-entry
+// segments the wave launch rate, not the math, bounded the kernel.
+// plan_off[t] = first entry of tile t; plan_tile[b] = tile of entry b; total[0] = entries.
+extern "C" __global__ void __launch_bounds__(1024)
+gsr_bwd_plan(const uint32_t* __restrict__ tile_last, int T, int seg_shift, uint32_t capacity,
+             uint32_t* __restrict__ plan_off, uint32_t* __restrict__ plan_tile,
+             unsigned long long* __restrict__ total) {
+    __shared__ uint32_t wsum[16];
+    const int per = (T + 1023) / 1024;
+    const int beg = min((int)threadIdx.x * per, T), end = min(beg + per, T);
+    const uint32_t round = (1u << seg_shift) - 1u;
+    uint32_t local = 0;
+    for (int i = beg; i < end; ++i) local += (tile_last[i] + round) >> seg_shift;
+    uint32_t incl = local;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    uint32_t run = base + incl - local;
+    for (int i = beg; i < end; ++i) {
+        const uint32_t segs = (tile_last[i] + round) >> seg_shift;
+        plan_off[i] = run;
+        for (uint32_t k = 0; k < segs; ++k)
+            if (run + k < capacity) plan_tile[run + k] = (uint32_t)i;
+        run += segs;
+    }
+    if (threadIdx.x == 1023) total[0] = min(base + incl, capacity);
+}
+
 // write the tile's records in sorted order: 4 lanes move one 64-byte record
 __device__ __forceinline__ void gather_records(const unsigned long long* keys, uint32_t n,
                                                const SplatRec* __restrict__ geom,

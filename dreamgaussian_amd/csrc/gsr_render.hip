@@ -192,7 +192,7 @@ gsr_render_fwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict
                uint32_t* __restrict__ n_contrib, float* __restrict__ totals /*[5][H*W]*/,
                float* __restrict__ ckpt, const uint32_t* __restrict__ tile_seg,
                const uint32_t* __restrict__ tile_order /* heaviest tile first, or NULL */, int exact_cull,
-               int seg_shift) {
+               int seg_shift, uint32_t* __restrict__ tile_last /* max list position blended in the tile */) {
     __shared__ float4 stage[4][3][GSR_RB + 2];             // 12.4 KiB: [wave][field group][slot (+2 pad)]
     const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -302,6 +302,10 @@ gsr_render_fwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict
         ra = na; rb = nb; rc = nc; id_next = id_next2;
     }
 #undef GSR_FWD_ENTRY
+    {   // how deep the backward has to walk this tile's list
+        const uint32_t wl = wave_max_u32(last);
+        if (lane == 0 && wl != 0u) atomicMax(&tile_last[tile], wl);
+    }
     if (inside) {
         const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
         final_T[pix] = T;
@@ -454,7 +458,7 @@ gsr_render_bwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict
 #undef GSR_BWD_ENTRY
 }
 
-#define GSR_FWD_INST(B, S) template __global__ void gsr_render_fwd<B, S>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, float*, float*, float*, float*, uint32_t*, float*, float*, const uint32_t*, const uint32_t*, int, int);
+#define GSR_FWD_INST(B, S) template __global__ void gsr_render_fwd<B, S>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, float*, float*, float*, float*, uint32_t*, float*, float*, const uint32_t*, const uint32_t*, int, int, uint32_t*);
 GSR_FWD_INST(false, false) GSR_FWD_INST(true, false) GSR_FWD_INST(false, true) GSR_FWD_INST(true, true)
 #undef GSR_FWD_INST
 template __global__ void gsr_render_bwd<false>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, const float*, const uint32_t*, const float*, const float*, const float*, float*);
@@ -482,10 +486,14 @@ gsr_render_bwd_f2b(const uint32_t* __restrict__ tile_off, const SplatRec* __rest
                    const float* __restrict__ totals, const float* __restrict__ ckpt,
                    const uint32_t* __restrict__ tile_seg,
                    const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
-                   const float* __restrict__ dL_dalpha, float* __restrict__ g2d, int exact_cull, int seg_shift) {
+                   const float* __restrict__ dL_dalpha, float* __restrict__ g2d, int exact_cull, int seg_shift,
+                   const uint32_t* __restrict__ plan_tile, const uint32_t* __restrict__ plan_off,
+                   const unsigned long long* __restrict__ plan_total) {
     __shared__ float4 stage[4][4][GSR_RB + 2];             // 16.5 KiB (+2 pad slots)
-    const int tile = blockIdx.x;
-    const uint32_t seg = blockIdx.y;
+    // work list built by gsr_bwd_plan: entry b = (tile, segment) with at least one blended position
+    if (blockIdx.x >= (uint32_t)plan_total[0]) return;
+    const int tile = (int)plan_tile[blockIdx.x];
+    const uint32_t seg = blockIdx.x - plan_off[tile];
     const uint32_t start = tile_off[tile];
     const uint32_t n = tile_off[tile + 1] - start;
     const uint32_t seg_lo = seg << seg_shift;              // this workgroup: list positions (seg_lo, seg_hi]
@@ -618,5 +626,5 @@ gsr_render_bwd_f2b(const uint32_t* __restrict__ tile_off, const SplatRec* __rest
 #undef GSR_F2B_ENTRY
 }
 
-template __global__ void gsr_render_bwd_f2b<false>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, const float*, const uint32_t*, const float*, const float*, const uint32_t*, const float*, const float*, const float*, float*, int, int);
-template __global__ void gsr_render_bwd_f2b<true>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, const float*, const uint32_t*, const float*, const float*, const uint32_t*, const float*, const float*, const float*, float*, int, int);
+template __global__ void gsr_render_bwd_f2b<false>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, const float*, const uint32_t*, const float*, const float*, const uint32_t*, const float*, const float*, const float*, float*, int, int, const uint32_t*, const uint32_t*, const unsigned long long*);
+template __global__ void gsr_render_bwd_f2b<true>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, const float*, const uint32_t*, const float*, const float*, const uint32_t*, const float*, const float*, const float*, float*, int, int, const uint32_t*, const uint32_t*, const unsigned long long*);
