@@ -9,7 +9,8 @@ import threading
 import torch  # imported first so that libgsr.so binds to the HIP runtime torch already loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgsr.so")
+# GSR_LIB=<path> loads another build of the same ABI (A/B measurements of two source revisions)
+LIB_PATH = os.environ.get("GSR_LIB") or os.path.join(_HERE, "libgsr.so")
 
 EXPORTS = ("gsr_forward", "gsr_backward", "gsr_mark_visible", "gsr_dist2",
            "gsr_profile_enable", "gsr_profile_read", "gsr_profile_reset",
