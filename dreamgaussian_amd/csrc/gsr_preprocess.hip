@@ -209,7 +209,7 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
                    SplatRec* __restrict__ recs, EmitRec* __restrict__ emit,
                    int32_t* __restrict__ radii, uint32_t* __restrict__ tile_count,
                    unsigned long long* __restrict__ counters /*[0]=M_ref [1]=V*/,
-                   int hist_in_lds, int sh_direct, uint8_t* __restrict__ flags8 /* colour-clamp bits for K6 */) {
+                   int hist_in_lds, int sh_direct) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int nTiles = vc.gx * vc.gy;
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem_raw);
@@ -396,7 +396,6 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
             }
         }
         radii[idx] = radius_out;
-        flags8[idx] = (uint8_t)rec.flags;
         reinterpret_cast<uint4*>(recs + idx)[0] = reinterpret_cast<uint4*>(&rec)[0];
         reinterpret_cast<uint4*>(recs + idx)[1] = reinterpret_cast<uint4*>(&rec)[1];
         reinterpret_cast<uint4*>(recs + idx)[2] = reinterpret_cast<uint4*>(&rec)[2];
@@ -434,7 +433,7 @@ gsr_preprocess_bwd(ViewConst vc, int N, int K,
                    const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
                    const float* __restrict__ scales, const float* __restrict__ rotations,
                    const float* __restrict__ cov3D_precomp, const int32_t* __restrict__ radii,
-                   const uint8_t* __restrict__ flags8, const float* __restrict__ g2d,
+                   const SplatRec* __restrict__ recs, const float* __restrict__ g2d,
                    float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
                    float* __restrict__ dL_dshs, float* __restrict__ dL_dcolors,
                    float* __restrict__ dL_dopac, float* __restrict__ dL_dscales,
@@ -465,7 +464,7 @@ gsr_preprocess_bwd(ViewConst vc, int N, int K,
 
         if (live) {
             const float* g = g2d + (size_t)idx * GSR_G2D_STRIDE;
-            const uint32_t flags = flags8[idx];       // 1 B instead of touching the 64-byte record
+            const uint32_t flags = recs[idx].flags;
             const float mx = means3D[3 * idx], my = means3D[3 * idx + 1], mz = means3D[3 * idx + 2];
             float3 pv;
             pv.x = V[0] * mx + V[4] * my + V[8] * mz + V[12];
@@ -476,6 +475,35 @@ gsr_preprocess_bwd(ViewConst vc, int N, int K,
             const float hw = P[3] * mx + P[7] * my + P[11] * mz + P[15];
             const float m_w = 1.0f / (hw + 0.0000001f);
 
+            // ---- forward intermediates: Sigma, 2D covariance, conic ---------------------------
+            Cov3 S;
+            float R[9];
+            float3 s = make_float3(0.f, 0.f, 0.f);
+            float4 q = make_float4(1.f, 0.f, 0.f, 0.f);
+            if (cov3D_precomp) {
+                const float* c = cov3D_precomp + 6 * (size_t)idx;
+                S.c0 = c[0]; S.c1 = c[1]; S.c2 = c[2]; S.c3 = c[3]; S.c4 = c[4]; S.c5 = c[5];
+            } else {
+                q = reinterpret_cast<const float4*>(rotations)[idx];
+                s.x = vc.scale_modifier * scales[3 * idx];
+                s.y = vc.scale_modifier * scales[3 * idx + 1];
+                s.z = vc.scale_modifier * scales[3 * idx + 2];
+                quat_to_R(q, R);
+                S = cov3d_from_scale_rot(s, R);
+            }
+            const Proj2D pj = project_cov(vc, V, pv, S);
+            const float a = pj.a, b = pj.b, c = pj.c;
+            const float det = a * c - b * b;
+            const float det_inv = 1.f / det;
+            const float cA = c * det_inv, cB = -b * det_inv, cC = a * det_inv;   // conic, as in K1
+            // ---- screen-space mean: raw moments -> dL/d(mean2D) in pixels -> NDC -------------
+            const float gmx = -(cA * g[0] + cB * g[1]) * (0.5f * vc.W);          // dL/d ndc.x
+            const float gmy = -(cC * g[1] + cB * g[0]) * (0.5f * vc.H);
+            dm2[0] = gmx; dm2[1] = gmy;
+            const float mul1 = hx * m_w * m_w, mul2 = hy * m_w * m_w;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                dm[k] = (P[4 * k] * m_w - P[4 * k + 3] * mul1) * gmx + (P[4 * k + 1] * m_w - P[4 * k + 3] * mul2) * gmy;
             // ---- depth ------------------------------------------------------------------
             const float gdepth = g[9];
             dm[0] += V[2] * gdepth; dm[1] += V[6] * gdepth; dm[2] += V[10] * gdepth;
@@ -542,34 +570,6 @@ gsr_preprocess_bwd(ViewConst vc, int N, int K,
             }
 
             // ---- conic -> cov2D -> (Sigma, t) -------------------------------------------
-            Cov3 S;
-            float R[9];
-            float3 s = make_float3(0.f, 0.f, 0.f);
-            float4 q = make_float4(1.f, 0.f, 0.f, 0.f);
-            if (cov3D_precomp) {
-                const float* c = cov3D_precomp + 6 * (size_t)idx;
-                S.c0 = c[0]; S.c1 = c[1]; S.c2 = c[2]; S.c3 = c[3]; S.c4 = c[4]; S.c5 = c[5];
-            } else {
-                q = reinterpret_cast<const float4*>(rotations)[idx];
-                s.x = vc.scale_modifier * scales[3 * idx];
-                s.y = vc.scale_modifier * scales[3 * idx + 1];
-                s.z = vc.scale_modifier * scales[3 * idx + 2];
-                quat_to_R(q, R);
-                S = cov3d_from_scale_rot(s, R);
-            }
-            const Proj2D pj = project_cov(vc, V, pv, S);
-            const float a = pj.a, b = pj.b, c = pj.c;
-            const float det = a * c - b * b;
-            const float det_inv = 1.f / det;
-            const float cA = c * det_inv, cB = -b * det_inv, cC = a * det_inv;   // conic, as in K1
-            // ---- screen-space mean: raw moments -> dL/d(mean2D) in pixels -> NDC -------------
-            const float gmx = -(cA * g[0] + cB * g[1]) * (0.5f * vc.W);          // dL/d ndc.x
-            const float gmy = -(cC * g[1] + cB * g[0]) * (0.5f * vc.H);
-            dm2[0] = gmx; dm2[1] = gmy;
-            const float mul1 = hx * m_w * m_w, mul2 = hy * m_w * m_w;
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-                dm[k] += (P[4 * k] * m_w - P[4 * k + 3] * mul1) * gmx + (P[4 * k + 1] * m_w - P[4 * k + 3] * mul2) * gmy;
             const float d2i = 1.f / (det * det);
             const float gA = -0.5f * g[2], gB = -g[3], gC = -0.5f * g[4];      // dL/d(conic A,B,C) from S_xx, S_xy, S_yy
             const float dLa = d2i * (-c * c * gA + b * c * gB - b * b * gC);
