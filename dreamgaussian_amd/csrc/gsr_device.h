@@ -43,12 +43,10 @@ struct __attribute__((aligned(16))) EmitRec {
 };
 #define GSR_EMIT_MASK_TILES 32
 
-// screen-space gradient accumulators written by render_bwd (atomics), read by preprocess_bwd.
-// With m = dL/d(exponent of the Gaussian) per blended pixel and d = mean2D - pixel:
-// [0] S_x = sum m dx   [1] S_y = sum m dy   [2] S_xx = sum m dx^2   [3] S_xy = sum m dx dy
-// [4] S_yy = sum m dy^2   [5] S_0 = sum m   (conic A,B,C: dL/dmean2D = -(A S_x + B S_y, C S_y + B S_x),
-// dL/dA = -S_xx/2, dL/dB = -S_xy, dL/dC = -S_yy/2, dL/dopacity = S_0/opacity -- applied once per
-// Gaussian in K6 instead of once per (pixel, Gaussian) pair)
+// screen-space gradient accumulators written by render_bwd (atomics), read by preprocess_bwd
+// [0] sum dL/dG*G*(2qa dx + qb dy)   -> mean2D.x   (times ln2 * 0.5 W later)
+// [1] sum dL/dG*G*(2qc dy + qb dx)   -> mean2D.y
+// [2] dL/dA  [3] dL/dB  [4] dL/dC  (true conic)   [5] dL/dopacity
 // [6..8] dL/drgb  [9] dL/ddepth  [10..11] pad
 #define GSR_G2D_STRIDE 12
 

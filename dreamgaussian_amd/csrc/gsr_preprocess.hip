@@ -475,30 +475,9 @@ gsr_preprocess_bwd(ViewConst vc, int N, int K,
             const float hw = P[3] * mx + P[7] * my + P[11] * mz + P[15];
             const float m_w = 1.0f / (hw + 0.0000001f);
 
-            // ---- forward intermediates: Sigma, 2D covariance, conic ---------------------------
-            Cov3 S;
-            float R[9];
-            float3 s = make_float3(0.f, 0.f, 0.f);
-            float4 q = make_float4(1.f, 0.f, 0.f, 0.f);
-            if (cov3D_precomp) {
-                const float* c = cov3D_precomp + 6 * (size_t)idx;
-                S.c0 = c[0]; S.c1 = c[1]; S.c2 = c[2]; S.c3 = c[3]; S.c4 = c[4]; S.c5 = c[5];
-            } else {
-                q = reinterpret_cast<const float4*>(rotations)[idx];
-                s.x = vc.scale_modifier * scales[3 * idx];
-                s.y = vc.scale_modifier * scales[3 * idx + 1];
-                s.z = vc.scale_modifier * scales[3 * idx + 2];
-                quat_to_R(q, R);
-                S = cov3d_from_scale_rot(s, R);
-            }
-            const Proj2D pj = project_cov(vc, V, pv, S);
-            const float a = pj.a, b = pj.b, c = pj.c;
-            const float det = a * c - b * b;
-            const float det_inv = 1.f / det;
-            const float cA = c * det_inv, cB = -b * det_inv, cC = a * det_inv;   // conic, as in K1
-            // ---- screen-space mean: raw moments -> dL/d(mean2D) in pixels -> NDC -------------
-            const float gmx = -(cA * g[0] + cB * g[1]) * (0.5f * vc.W);          // dL/d ndc.x
-            const float gmy = -(cC * g[1] + cB * g[0]) * (0.5f * vc.H);
+            // ---- screen-space mean ------------------------------------------------------
+            const float gmx = g[0] * (GSR_LN2 * 0.5f * vc.W);   // dL/d ndc.x
+            const float gmy = g[1] * (GSR_LN2 * 0.5f * vc.H);
             dm2[0] = gmx; dm2[1] = gmy;
             const float mul1 = hx * m_w * m_w, mul2 = hy * m_w * m_w;
 #pragma unroll
@@ -508,7 +487,7 @@ gsr_preprocess_bwd(ViewConst vc, int N, int K,
             const float gdepth = g[9];
             dm[0] += V[2] * gdepth; dm[1] += V[6] * gdepth; dm[2] += V[10] * gdepth;
             // ---- opacity ----------------------------------------------------------------
-            { const float op = opacities[idx]; dop = op != 0.f ? g[5] / op : 0.f; }   // S_0 / opacity
+            dop = g[5];
 
             // ---- colour -----------------------------------------------------------------
             float gr = g[6], gg = g[7], gb = g[8];
@@ -570,8 +549,26 @@ gsr_preprocess_bwd(ViewConst vc, int N, int K,
             }
 
             // ---- conic -> cov2D -> (Sigma, t) -------------------------------------------
+            Cov3 S;
+            float R[9];
+            float3 s = make_float3(0.f, 0.f, 0.f);
+            float4 q = make_float4(1.f, 0.f, 0.f, 0.f);
+            if (cov3D_precomp) {
+                const float* c = cov3D_precomp + 6 * (size_t)idx;
+                S.c0 = c[0]; S.c1 = c[1]; S.c2 = c[2]; S.c3 = c[3]; S.c4 = c[4]; S.c5 = c[5];
+            } else {
+                q = reinterpret_cast<const float4*>(rotations)[idx];
+                s.x = vc.scale_modifier * scales[3 * idx];
+                s.y = vc.scale_modifier * scales[3 * idx + 1];
+                s.z = vc.scale_modifier * scales[3 * idx + 2];
+                quat_to_R(q, R);
+                S = cov3d_from_scale_rot(s, R);
+            }
+            const Proj2D pj = project_cov(vc, V, pv, S);
+            const float a = pj.a, b = pj.b, c = pj.c;
+            const float det = a * c - b * b;
             const float d2i = 1.f / (det * det);
-            const float gA = -0.5f * g[2], gB = -g[3], gC = -0.5f * g[4];      // dL/d(conic A,B,C) from S_xx, S_xy, S_yy
+            const float gA = g[2], gB = g[3], gC = g[4];
             const float dLa = d2i * (-c * c * gA + b * c * gB - b * b * gC);
             const float dLb = d2i * (2.f * b * c * gA - (a * c + b * b) * gB + 2.f * a * b * gC);
             const float dLc = d2i * (-b * b * gA + a * b * gB - a * a * gC);

@@ -133,12 +133,15 @@ gsr_render_bwd_v0(const uint32_t* __restrict__ tile_off, const SplatRec* __restr
             dL_dal *= T;
             last_alpha = alpha;
             dL_dal += (-T_final * oma_inv) * bg_dot;
-            const float m = (g->opac * dL_dal) * G;       // dL/d(exponent): raw moments, K6 applies the conic
+            const float dL_dG = g->opac * dL_dal;
+            const float gdx = G * dx, gdy = G * dy;
             // mean2D: dG/ddx = -G (A dx + B dy) = ln2 * G (2 qa dx + qb dy); ln2 and 0.5*W applied in K6
-            const float mdx = m * dx, mdy = m * dy;
-            v0 = mdx; v1 = mdy;                           // S_x, S_y
-            v2 = mdx * dx; v3 = mdx * dy; v4 = mdy * dy;  // S_xx, S_xy, S_yy
-            v5 = m;                                       // S_0 (dL/dopacity = S_0 / opacity)
+            v0 = dL_dG * (2.f * g->qa * gdx + g->qb * gdy);
+            v1 = dL_dG * (2.f * g->qc * gdy + g->qb * gdx);
+            v2 = -0.5f * gdx * dx * dL_dG;                // dL/dA
+            v3 = -gdx * dy * dL_dG;                       // dL/dB (full derivative of -B dx dy)
+            v4 = -0.5f * gdy * dy * dL_dG;                // dL/dC
+            v5 = G * dL_dal;                              // dL/dopacity
             v6 = w * gC0; v7 = w * gC1; v8 = w * gC2;     // dL/drgb
             v9 = w * gD;                                  // dL/ddepth
         }
@@ -398,10 +401,14 @@ gsr_render_bwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict
                 dL_dal += (-T_final * oma_inv) * bg_dot;                                         \
             }                                                                                    \
             const float Gm = ok ? G : 0.f;                /* G may be inf where power > 0 */      \
-            /* raw moments of m = dL/d(exponent); K6 turns them into mean / conic / opacity grads */ \
-            const float v5 = (opac * dL_dal) * Gm;                 /* S_0  */                    \
-            const float v0 = v5 * dx, v1 = v5 * dy;                /* S_x, S_y */                \
-            const float v2 = v0 * dx, v3 = v0 * dy, v4 = v1 * dy;  /* S_xx, S_xy, S_yy */        \
+            const float dL_dG = opac * dL_dal;                                                   \
+            const float gdx = Gm * dx, gdy = Gm * dy;                                            \
+            const float v0 = dL_dG * (2.f * qa * gdx + qb * gdy);  /* mean2D.x (ln2*0.5W in K6) */ \
+            const float v1 = dL_dG * (2.f * qc * gdy + qb * gdx);  /* mean2D.y */                \
+            const float v2 = -0.5f * gdx * dx * dL_dG;             /* dL/dA */                   \
+            const float v3 = -gdx * dy * dL_dG;                    /* dL/dB */                   \
+            const float v4 = -0.5f * gdy * dy * dL_dG;             /* dL/dC */                   \
+            const float v5 = Gm * dL_dal;                          /* dL/dopacity */             \
             const float v6 = w * gC0, v7 = w * gC1, v8 = w * gC2;  /* dL/drgb */                 \
             const float v9 = w * gD;                               /* dL/ddepth */               \
             const float t0 = row_sum16(red16(red32(v0, v5), red32(v1, v6)));                     \
@@ -555,10 +562,14 @@ gsr_render_bwd_f2b(const uint32_t* __restrict__ tile_off, const SplatRec* __rest
                 T *= oma;                                                                        \
             }                                                                                    \
             const float Gm = ok ? G : 0.f;                /* G may be inf where power > 0 */      \
-            /* raw moments of m = dL/d(exponent); K6 turns them into mean / conic / opacity grads */ \
-            const float v5 = (opac * dL_dal) * Gm;                 /* S_0  */                    \
-            const float v0 = v5 * dx, v1 = v5 * dy;                /* S_x, S_y */                \
-            const float v2 = v0 * dx, v3 = v0 * dy, v4 = v1 * dy;  /* S_xx, S_xy, S_yy */        \
+            const float dL_dG = opac * dL_dal;                                                   \
+            const float gdx = Gm * dx, gdy = Gm * dy;                                            \
+            const float v0 = dL_dG * (2.f * qa * gdx + qb * gdy);  /* mean2D.x (ln2*0.5W in K6) */ \
+            const float v1 = dL_dG * (2.f * qc * gdy + qb * gdx);  /* mean2D.y */                \
+            const float v2 = -0.5f * gdx * dx * dL_dG;             /* dL/dA */                   \
+            const float v3 = -gdx * dy * dL_dG;                    /* dL/dB */                   \
+            const float v4 = -0.5f * gdy * dy * dL_dG;             /* dL/dC */                   \
+            const float v5 = Gm * dL_dal;                          /* dL/dopacity */             \
             const float v6 = w * gC0, v7 = w * gC1, v8 = w * gC2;  /* dL/drgb */                 \
             const float v9 = w * gD;                               /* dL/ddepth */               \
             const float t0 = row_sum16(red16(red32(v0, v5), red32(v1, v6)));                     \
