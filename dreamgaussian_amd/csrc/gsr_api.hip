@@ -201,7 +201,8 @@ int cull_mode(bool fwd) {
         if (strcmp(e, "bwd") == 0) return 2;
         return 0;
     }();
-    return fwd ? (v & 1) : ((v >> 1) & 1);
+    static const int noatomic = [] { const char* e = getenv("GSR_DEBUG_NOATOMIC"); return (e && e[0] == '1') ? 2 : 0; }();
+    return fwd ? (v & 1) : (((v >> 1) & 1) | noatomic);   // bit 1 (backward only): skip atomics, WRONG results, timing only
 }
 // GSR_SEG_SHIFT: log2 of the backward segment length in list positions (default 10).
 int seg_shift() {

@@ -427,7 +427,7 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
 // forward intermediates from the inputs instead of re-reading saved state.
 // dynamic LDS: blockDim.x * (3K+1) floats when shs (used for SH in, then dSH out).
 // ---------------------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(256, 3)   // <= 168 VGPRs: 3 blocks (50 KiB LDS each) per CU
+extern "C" __global__ void __launch_bounds__(256)
 gsr_preprocess_bwd(ViewConst vc, int N, int K,
                    const float* __restrict__ means3D, const float* __restrict__ shs,
                    const float* __restrict__ colors_precomp, const float* __restrict__ opacities,

@@ -575,7 +575,7 @@ gsr_render_bwd_f2b(const uint32_t* __restrict__ tile_off, const SplatRec* __rest
             const float t0 = row_sum16(red16(red32(v0, v5), red32(v1, v6)));                     \
             const float t1 = row_sum16(red16(red32(v2, v7), red32(v3, v8)));                     \
             const float t2 = row_sum16(red16(red32(v4, v9), 0.f));                               \
-            if (row_leader) {                                                                    \
+            if (row_leader && !(exact_cull & 2)) {   /* bit 1: timing experiment, atomics off */   \
                 const uint32_t gid = __builtin_amdgcn_readfirstlane(__float_as_uint(ed.x));      \
                 float* dst = g2d + (size_t)gid * GSR_G2D_STRIDE;                                 \
                 atomicAdd(dst + slot0, t0);                                                      \
@@ -595,7 +595,7 @@ gsr_render_bwd_f2b(const uint32_t* __restrict__ tile_off, const SplatRec* __rest
         if (i < seg_hi) {
             const float4* __restrict__ p = list_record<BY_ID>(recs, ids, start + i);
             ra = p[0]; rb = p[1]; rc = p[2]; rd = p[3];
-            if (exact_cull) {
+            if (exact_cull & 1) {
                 hit = rect_max_power(ra.x, ra.y, ra.z, ra.w, rb.x, (float)bx, (float)(bx + 7), (float)by, (float)(by + 7))
                       >= min_visible_power(rb.y);
             } else {
