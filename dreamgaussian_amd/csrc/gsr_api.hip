@@ -201,8 +201,12 @@ int cull_mode(bool fwd) {
         if (strcmp(e, "bwd") == 0) return 2;
         return 0;
     }();
-    static const int noatomic = [] { const char* e = getenv("GSR_DEBUG_NOATOMIC"); return (e && e[0] == '1') ? 2 : 0; }();
-    return fwd ? (v & 1) : (((v >> 1) & 1) | noatomic);   // bit 1 (backward only): skip atomics, WRONG results, timing only
+    return fwd ? (v & 1) : ((v >> 1) & 1);
+}
+// GSR_BWD_ACC=global: per-(block, Gaussian) global atomics instead of the per-workgroup LDS table.
+bool use_bwd_acc_lds() {
+    static const bool v = [] { const char* e = getenv("GSR_BWD_ACC"); return !(e && strcmp(e, "global") == 0); }();
+    return v && seg_shift() <= 8;   // table = 48 B << shift of LDS
 }
 // GSR_SEG_SHIFT: log2 of the backward segment length in list positions (default 10).
 int seg_shift() {
@@ -482,14 +486,16 @@ extern "C" int gsr_backward(const GsrView* view, int32_t N, int32_t K,
         LAUNCH_CHECK(view, stream, "bwd_plan");
         prof_begin(stream);
         const unsigned grid = (unsigned)BL.plan_cap;
+        const int acc_lds = use_bwd_acc_lds() ? 1 : 0;
+        const size_t dyn = acc_lds ? ((size_t)GSR_G2D_STRIDE * 4) << seg_shift() : 0;
         if (copy)
-            hipLaunchKernelGGL(gsr_render_bwd_f2b<false>, dim3(grid), dim3(256), 0, stream, tile_off, srecs, (const uint32_t*)nullptr, view->bg, W, H, vc.gx,
+            hipLaunchKernelGGL(gsr_render_bwd_f2b<false>, dim3(grid), dim3(256), dyn, stream, tile_off, srecs, (const uint32_t*)nullptr, view->bg, W, H, vc.gx,
                                final_T, n_contrib, totals, ckpt, tile_seg, dL_dcolor, dL_ddepth, dL_dalpha, g2d, cull_mode(false), seg_shift(),
-                               plan_tile, plan_off, plan_total);
+                               plan_tile, plan_off, plan_total, acc_lds);
         else
-            hipLaunchKernelGGL(gsr_render_bwd_f2b<true>, dim3(grid), dim3(256), 0, stream, tile_off, recs, (const uint32_t*)bin, view->bg, W, H, vc.gx,
+            hipLaunchKernelGGL(gsr_render_bwd_f2b<true>, dim3(grid), dim3(256), dyn, stream, tile_off, recs, (const uint32_t*)bin, view->bg, W, H, vc.gx,
                                final_T, n_contrib, totals, ckpt, tile_seg, dL_dcolor, dL_ddepth, dL_dalpha, g2d, cull_mode(false), seg_shift(),
-                               plan_tile, plan_off, plan_total);
+                               plan_tile, plan_off, plan_total, acc_lds);
     }
     LAUNCH_CHECK(view, stream, "render_bwd");
 

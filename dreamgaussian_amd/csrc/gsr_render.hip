@@ -488,8 +488,14 @@ gsr_render_bwd_f2b(const uint32_t* __restrict__ tile_off, const SplatRec* __rest
                    const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
                    const float* __restrict__ dL_dalpha, float* __restrict__ g2d, int exact_cull, int seg_shift,
                    const uint32_t* __restrict__ plan_tile, const uint32_t* __restrict__ plan_off,
-                   const unsigned long long* __restrict__ plan_total) {
+                   const unsigned long long* __restrict__ plan_total, int acc_lds) {
     __shared__ float4 stage[4][4][GSR_RB + 2];             // 16.5 KiB (+2 pad slots)
+    // acc_lds: the four waves of the workgroup first add their per-Gaussian sums into an LDS table
+    // [segment position][12] and the table is flushed with coalesced global atomics at the end --
+    // one memory-side atomic request per (segment, Gaussian) cache line instead of three per
+    // (8x8 block, Gaussian). Measured: the global atomics were 26% of this kernel (agent-scope
+    // float atomics execute at the memory side on the multi-XCD part).
+    extern __shared__ __attribute__((aligned(16))) float acc[];   // [(1 << seg_shift) * GSR_G2D_STRIDE] when acc_lds
     // work list built by gsr_bwd_plan: entry b = (tile, segment) with at least one blended position
     if (blockIdx.x >= (uint32_t)plan_total[0]) return;
     const int tile = (int)plan_tile[blockIdx.x];
@@ -497,12 +503,16 @@ gsr_render_bwd_f2b(const uint32_t* __restrict__ tile_off, const SplatRec* __rest
     const uint32_t start = tile_off[tile];
     const uint32_t n = tile_off[tile + 1] - start;
     const uint32_t seg_lo = seg << seg_shift;              // this workgroup: list positions (seg_lo, seg_hi]
-    if (seg_lo >= n) return;
+    if (seg_lo >= n) return;                              // (block-uniform)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int bx = (tile % gx) * GSR_TILE + (wave & 1) * 8;
     const int by = (tile / gx) * GSR_TILE + (wave >> 1) * 8;
-    if (bx >= W || by >= H) return;
+    if (acc_lds) {
+        for (int q = threadIdx.x; q < (GSR_G2D_STRIDE << seg_shift); q += 256) acc[q] = 0.f;
+        __syncthreads();
+    }
+    bool active = (bx < W) && (by < H);                   // wave-uniform; no early return: barrier below
     const int px = bx + (lane & 7), py = by + (lane >> 3);
     const bool inside = (px < W) && (py < H);
     const float pxf = (float)px, pyf = (float)py;
@@ -523,8 +533,8 @@ gsr_render_bwd_f2b(const uint32_t* __restrict__ tile_off, const SplatRec* __rest
                  + totals[3 * HW + pix] * gD + totals[4 * HW + pix] * gA;
     }
     const uint32_t wave_last = __builtin_amdgcn_readfirstlane(wave_max_u32(last_contrib));
-    if (wave_last <= seg_lo) return;                      // nothing in this segment was blended here
-    const uint32_t seg_hi = min(seg_lo + (1u << seg_shift), wave_last);
+    active = active && (wave_last > seg_lo);              // else nothing in this segment was blended here
+    const uint32_t seg_hi = active ? min(seg_lo + (1u << seg_shift), wave_last) : seg_lo;
     // everything behind entry i: (total + T_final bg.g) - prefix_i - w_i (c_i.g)
     const float Cg_behind0 = Cg_total + T_final * (bg[0] * gC0 + bg[1] * gC1 + bg[2] * gC2);
 
@@ -539,6 +549,10 @@ gsr_render_bwd_f2b(const uint32_t* __restrict__ tile_off, const SplatRec* __rest
     const uint32_t slot1 = tag16(tag32(2u, 7u), tag32(3u, 8u));
     const uint32_t slot2 = tag16(tag32(4u, 9u), tag32(10u, 11u));   // 10, 11: padding slots (zeros)
     const bool row_leader = (lane & 15) == 0;
+    // LDS path: lanes 0,1,2 of every 16-lane row carry t0,t1,t2 -> one ds_add for all ten sums
+    const uint32_t l15 = (uint32_t)lane & 15u;
+    const uint32_t myslot = l15 == 0u ? slot0 : (l15 == 1u ? slot1 : slot2);
+    const bool lds_lane = (l15 < 3u) && (myslot < 10u);
 
     // ea = x y qa qb | eb = qc opac r g | ec = b depth pos - | ed = id - - -
 #define GSR_F2B_ENTRY(ea, eb, ec, ed, valid)                                                     \
@@ -575,7 +589,10 @@ gsr_render_bwd_f2b(const uint32_t* __restrict__ tile_off, const SplatRec* __rest
             const float t0 = row_sum16(red16(red32(v0, v5), red32(v1, v6)));                     \
             const float t1 = row_sum16(red16(red32(v2, v7), red32(v3, v8)));                     \
             const float t2 = row_sum16(red16(red32(v4, v9), 0.f));                               \
-            if (row_leader && !(exact_cull & 2)) {   /* bit 1: timing experiment, atomics off */   \
+            if (acc_lds) {                                                                       \
+                const float tv = l15 == 0u ? t0 : (l15 == 1u ? t1 : t2);                          \
+                if (lds_lane) atomicAdd(&acc[(kpos - 1u - seg_lo) * GSR_G2D_STRIDE + myslot], tv); \
+            } else if (row_leader) {                                                             \
                 const uint32_t gid = __builtin_amdgcn_readfirstlane(__float_as_uint(ed.x));      \
                 float* dst = g2d + (size_t)gid * GSR_G2D_STRIDE;                                 \
                 atomicAdd(dst + slot0, t0);                                                      \
@@ -595,7 +612,7 @@ gsr_render_bwd_f2b(const uint32_t* __restrict__ tile_off, const SplatRec* __rest
         if (i < seg_hi) {
             const float4* __restrict__ p = list_record<BY_ID>(recs, ids, start + i);
             ra = p[0]; rb = p[1]; rc = p[2]; rd = p[3];
-            if (exact_cull & 1) {
+            if (exact_cull) {
                 hit = rect_max_power(ra.x, ra.y, ra.z, ra.w, rb.x, (float)bx, (float)(bx + 7), (float)by, (float)(by + 7))
                       >= min_visible_power(rb.y);
             } else {
@@ -624,7 +641,21 @@ gsr_render_bwd_f2b(const uint32_t* __restrict__ tile_off, const SplatRec* __rest
         }
     }
 #undef GSR_F2B_ENTRY
+    if (acc_lds) {
+        __syncthreads();
+        // flush: consecutive threads = consecutive slots of consecutive list positions
+        const uint32_t len = min(1u << seg_shift, n - seg_lo);
+        for (uint32_t e = threadIdx.x; e < len * GSR_G2D_STRIDE; e += 256) {
+            const float v = acc[e];
+            if (v != 0.f) {
+                const uint32_t r = e / GSR_G2D_STRIDE, slot = e - r * GSR_G2D_STRIDE;
+                const uint32_t li = start + seg_lo + r;
+                const uint32_t gid = BY_ID ? ids[li] : recs[li].id;
+                atomicAdd(g2d + (size_t)gid * GSR_G2D_STRIDE + slot, v);
+            }
+        }
+    }
 }
 
-template __global__ void gsr_render_bwd_f2b<false>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, const float*, const uint32_t*, const float*, const float*, const uint32_t*, const float*, const float*, const float*, float*, int, int, const uint32_t*, const uint32_t*, const unsigned long long*);
-template __global__ void gsr_render_bwd_f2b<true>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, const float*, const uint32_t*, const float*, const float*, const uint32_t*, const float*, const float*, const float*, float*, int, int, const uint32_t*, const uint32_t*, const unsigned long long*);
+template __global__ void gsr_render_bwd_f2b<false>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, const float*, const uint32_t*, const float*, const float*, const uint32_t*, const float*, const float*, const float*, float*, int, int, const uint32_t*, const uint32_t*, const unsigned long long*, int);
+template __global__ void gsr_render_bwd_f2b<true>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, const float*, const uint32_t*, const float*, const float*, const uint32_t*, const float*, const float*, const float*, float*, int, int, const uint32_t*, const uint32_t*, const unsigned long long*, int);
