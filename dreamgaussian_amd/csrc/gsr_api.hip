@@ -488,14 +488,13 @@ extern "C" int gsr_backward(const GsrView* view, int32_t N, int32_t K,
         const unsigned grid = (unsigned)BL.plan_cap;
         const int acc_lds = use_bwd_acc_lds() ? 1 : 0;
         const size_t dyn = acc_lds ? ((size_t)GSR_G2D_STRIDE * 4) << seg_shift() : 0;
-        if (copy)
-            hipLaunchKernelGGL(gsr_render_bwd_f2b<false>, dim3(grid), dim3(256), dyn, stream, tile_off, srecs, (const uint32_t*)nullptr, view->bg, W, H, vc.gx,
-                               final_T, n_contrib, totals, ckpt, tile_seg, dL_dcolor, dL_ddepth, dL_dalpha, g2d, cull_mode(false), seg_shift(),
-                               plan_tile, plan_off, plan_total, acc_lds);
-        else
-            hipLaunchKernelGGL(gsr_render_bwd_f2b<true>, dim3(grid), dim3(256), dyn, stream, tile_off, recs, (const uint32_t*)bin, view->bg, W, H, vc.gx,
-                               final_T, n_contrib, totals, ckpt, tile_seg, dL_dcolor, dL_ddepth, dL_dalpha, g2d, cull_mode(false), seg_shift(),
-                               plan_tile, plan_off, plan_total, acc_lds);
+#define GSR_LAUNCH_F2B(B, A, RECS, IDS)                                                                \
+        hipLaunchKernelGGL((gsr_render_bwd_f2b<B, A>), dim3(grid), dim3(256), dyn, stream, tile_off, RECS, IDS, view->bg, W, H, vc.gx, \
+                           final_T, n_contrib, totals, ckpt, tile_seg, dL_dcolor, dL_ddepth, dL_dalpha, g2d, cull_mode(false), seg_shift(), \
+                           plan_tile, plan_off, plan_total)
+        if (copy) { if (acc_lds) GSR_LAUNCH_F2B(false, true, srecs, (const uint32_t*)nullptr); else GSR_LAUNCH_F2B(false, false, srecs, (const uint32_t*)nullptr); }
+        else { if (acc_lds) GSR_LAUNCH_F2B(true, true, recs, (const uint32_t*)bin); else GSR_LAUNCH_F2B(true, false, recs, (const uint32_t*)bin); }
+#undef GSR_LAUNCH_F2B
     }
     LAUNCH_CHECK(view, stream, "render_bwd");
 

@@ -477,7 +477,7 @@ template __global__ void gsr_render_bwd<true>(const uint32_t*, const SplatRec*, 
 // 2^seg_shift-th list position, and workgroup (tile, s) starts from checkpoint s. The longest
 // sequential walk drops from the tile's whole list (8.5k entries at 1M Gaussians) to one segment.
 // =========================================================================================
-template <bool BY_ID>
+template <bool BY_ID, bool ACC_LDS>
 __global__ void __launch_bounds__(256, 8)   // <= 64 VGPRs: the kernel leans on 8 waves/SIMD to cover its cross-lane chains
 gsr_render_bwd_f2b(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict__ recs,
                    const uint32_t* __restrict__ ids,
@@ -488,7 +488,8 @@ gsr_render_bwd_f2b(const uint32_t* __restrict__ tile_off, const SplatRec* __rest
                    const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
                    const float* __restrict__ dL_dalpha, float* __restrict__ g2d, int exact_cull, int seg_shift,
                    const uint32_t* __restrict__ plan_tile, const uint32_t* __restrict__ plan_off,
-                   const unsigned long long* __restrict__ plan_total, int acc_lds) {
+                   const unsigned long long* __restrict__ plan_total) {
+    constexpr bool acc_lds = ACC_LDS;
     __shared__ float4 stage[4][4][GSR_RB + 2];             // 16.5 KiB (+2 pad slots)
     // acc_lds: the four waves of the workgroup first add their per-Gaussian sums into an LDS table
     // [segment position][12] and the table is flushed with coalesced global atomics at the end --
@@ -576,14 +577,22 @@ gsr_render_bwd_f2b(const uint32_t* __restrict__ tile_off, const SplatRec* __rest
                 T *= oma;                                                                        \
             }                                                                                    \
             const float Gm = ok ? G : 0.f;                /* G may be inf where power > 0 */      \
-            const float dL_dG = opac * dL_dal;                                                   \
-            const float gdx = Gm * dx, gdy = Gm * dy;                                            \
-            const float v0 = dL_dG * (2.f * qa * gdx + qb * gdy);  /* mean2D.x (ln2*0.5W in K6) */ \
-            const float v1 = dL_dG * (2.f * qc * gdy + qb * gdx);  /* mean2D.y */                \
-            const float v2 = -0.5f * gdx * dx * dL_dG;             /* dL/dA */                   \
-            const float v3 = -gdx * dy * dL_dG;                    /* dL/dB */                   \
-            const float v4 = -0.5f * gdy * dy * dL_dG;             /* dL/dC */                   \
-            const float v5 = Gm * dL_dal;                          /* dL/dopacity */             \
+            float v0, v1, v2, v3, v4, v5;                                                        \
+            if constexpr (ACC_LDS) {   /* raw moments of m = dL/d(exponent); converted once per    \
+                                          (segment, Gaussian) before the flush */                \
+                v5 = (opac * dL_dal) * Gm;                         /* S_0 */                     \
+                v0 = v5 * dx; v1 = v5 * dy;                        /* S_x, S_y */                \
+                v2 = v0 * dx; v3 = v0 * dy; v4 = v1 * dy;          /* S_xx, S_xy, S_yy */        \
+            } else {                                                                             \
+                const float dL_dG = opac * dL_dal;                                               \
+                const float gdx = Gm * dx, gdy = Gm * dy;                                        \
+                v0 = dL_dG * (2.f * qa * gdx + qb * gdy);          /* mean2D.x (ln2*0.5W in K6) */ \
+                v1 = dL_dG * (2.f * qc * gdy + qb * gdx);          /* mean2D.y */                \
+                v2 = -0.5f * gdx * dx * dL_dG;                     /* dL/dA */                   \
+                v3 = -gdx * dy * dL_dG;                            /* dL/dB */                   \
+                v4 = -0.5f * gdy * dy * dL_dG;                     /* dL/dC */                   \
+                v5 = Gm * dL_dal;                                  /* dL/dopacity */             \
+            }                                                                                    \
             const float v6 = w * gC0, v7 = w * gC1, v8 = w * gC2;  /* dL/drgb */                 \
             const float v9 = w * gD;                               /* dL/ddepth */               \
             const float t0 = row_sum16(red16(red32(v0, v5), red32(v1, v6)));                     \
@@ -643,8 +652,24 @@ gsr_render_bwd_f2b(const uint32_t* __restrict__ tile_off, const SplatRec* __rest
 #undef GSR_F2B_ENTRY
     if (acc_lds) {
         __syncthreads();
-        // flush: consecutive threads = consecutive slots of consecutive list positions
         const uint32_t len = min(1u << seg_shift, n - seg_lo);
+        // raw moments -> the accumulator layout K6 reads (gsr_device.h), once per list position
+        for (uint32_t r = threadIdx.x; r < len; r += 256) {
+            float* a = acc + r * GSR_G2D_STRIDE;
+            const float S0 = a[5];
+            if (S0 != 0.f || a[0] != 0.f || a[1] != 0.f || a[2] != 0.f || a[3] != 0.f || a[4] != 0.f) {
+                const uint32_t li = start + seg_lo + r;
+                const SplatRec* __restrict__ g = BY_ID ? recs + ids[li] : recs + li;
+                const float qa = g->qa, qb = g->qb, qc = g->qc, op = g->opac;
+                const float Sx = a[0], Sy = a[1];
+                a[0] = 2.f * qa * Sx + qb * Sy;
+                a[1] = 2.f * qc * Sy + qb * Sx;
+                a[2] *= -0.5f; a[3] = -a[3]; a[4] *= -0.5f;
+                a[5] = op != 0.f ? S0 / op : 0.f;
+            }
+        }
+        __syncthreads();
+        // flush: consecutive threads = consecutive slots of consecutive list positions
         for (uint32_t e = threadIdx.x; e < len * GSR_G2D_STRIDE; e += 256) {
             const float v = acc[e];
             if (v != 0.f) {
@@ -657,5 +682,6 @@ gsr_render_bwd_f2b(const uint32_t* __restrict__ tile_off, const SplatRec* __rest
     }
 }
 
-template __global__ void gsr_render_bwd_f2b<false>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, const float*, const uint32_t*, const float*, const float*, const uint32_t*, const float*, const float*, const float*, float*, int, int, const uint32_t*, const uint32_t*, const unsigned long long*, int);
-template __global__ void gsr_render_bwd_f2b<true>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, const float*, const uint32_t*, const float*, const float*, const uint32_t*, const float*, const float*, const float*, float*, int, int, const uint32_t*, const uint32_t*, const unsigned long long*, int);
+#define GSR_F2B_INST(B, A) template __global__ void gsr_render_bwd_f2b<B, A>(const uint32_t*, const SplatRec*, const uint32_t*, const float*, int, int, int, const float*, const uint32_t*, const float*, const float*, const uint32_t*, const float*, const float*, const float*, float*, int, int, const uint32_t*, const uint32_t*, const unsigned long long*);
+GSR_F2B_INST(false, false) GSR_F2B_INST(true, false) GSR_F2B_INST(false, true) GSR_F2B_INST(true, true)
+#undef GSR_F2B_INST
