@@ -233,20 +233,6 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
     float4 pf[STAGE_PF];
     if (pipelined && (int)(blockIdx.x * blockDim.x) < N)
         stage_issue(shs + (size_t)(blockIdx.x * blockDim.x) * rowlen, min((int)blockDim.x, N - (int)(blockIdx.x * blockDim.x)), rowlen, pf);
-    // The per-Gaussian inputs travel one batch ahead as well: loads return in order, so inputs
-    // issued behind the 48 KiB SH prefetch would otherwise wait for all of it before the math starts.
-    const bool in_pf = pipelined && (scales != nullptr);
-    float n_m[3] = {0.f, 0.f, 0.f}, n_s[3] = {0.f, 0.f, 0.f}, n_op = 0.f;
-    float4 n_q = make_float4(1.f, 0.f, 0.f, 0.f);
-    auto issue_inputs = [&](int i) {
-        if (i < N) {
-            n_m[0] = means3D[3 * i]; n_m[1] = means3D[3 * i + 1]; n_m[2] = means3D[3 * i + 2];
-            n_s[0] = scales[3 * i]; n_s[1] = scales[3 * i + 1]; n_s[2] = scales[3 * i + 2];
-            n_q = reinterpret_cast<const float4*>(rotations)[i];
-            n_op = opacities[i];
-        }
-    };
-    if (in_pf) issue_inputs((int)(blockIdx.x * blockDim.x + threadIdx.x));
 
     for (int base = blockIdx.x * blockDim.x; base < N; base += gridDim.x * blockDim.x) {
         const int cnt = min((int)blockDim.x, N - base);
@@ -262,10 +248,6 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
             __syncthreads();
         }
         const int idx = base + threadIdx.x;
-        // this batch's inputs (prefetched during the previous batch), then the next batch's go out
-        const float c_m0 = n_m[0], c_m1 = n_m[1], c_m2 = n_m[2], c_s0 = n_s[0], c_s1 = n_s[1], c_s2 = n_s[2], c_op = n_op;
-        const float4 c_q = n_q;
-        if (in_pf) issue_inputs(idx + (int)(gridDim.x * blockDim.x));
         if (idx >= N) continue;
 
         SplatRec rec;
@@ -275,8 +257,7 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
         EmitRec em; em.rectx = 0; em.recty = 0; em.depth_bits = 0; em.mask = 0;
         int32_t radius_out = 0;
 
-        const float mx = in_pf ? c_m0 : means3D[3 * idx], my = in_pf ? c_m1 : means3D[3 * idx + 1],
-                    mz = in_pf ? c_m2 : means3D[3 * idx + 2];
+        const float mx = means3D[3 * idx], my = means3D[3 * idx + 1], mz = means3D[3 * idx + 2];
         float3 pv;
         pv.x = V[0] * mx + V[4] * my + V[8] * mz + V[12];
         pv.y = V[1] * mx + V[5] * my + V[9] * mz + V[13];
@@ -293,11 +274,11 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
                 const float* c = cov3D_precomp + 6 * (size_t)idx;
                 S.c0 = c[0]; S.c1 = c[1]; S.c2 = c[2]; S.c3 = c[3]; S.c4 = c[4]; S.c5 = c[5];
             } else {
-                const float4 q = in_pf ? c_q : reinterpret_cast<const float4*>(rotations)[idx];
+                const float4 q = reinterpret_cast<const float4*>(rotations)[idx];
                 float3 s;
-                s.x = vc.scale_modifier * (in_pf ? c_s0 : scales[3 * idx]);
-                s.y = vc.scale_modifier * (in_pf ? c_s1 : scales[3 * idx + 1]);
-                s.z = vc.scale_modifier * (in_pf ? c_s2 : scales[3 * idx + 2]);
+                s.x = vc.scale_modifier * scales[3 * idx];
+                s.y = vc.scale_modifier * scales[3 * idx + 1];
+                s.z = vc.scale_modifier * scales[3 * idx + 2];
                 float R[9];
                 quat_to_R(q, R);
                 S = cov3d_from_scale_rot(s, R);
@@ -359,7 +340,7 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
                         if (cg < 0.f) { flags |= 2u; cg = 0.f; }
                         if (cb < 0.f) { flags |= 4u; cb = 0.f; }
                     }
-                    const float op = in_pf ? c_op : opacities[idx];
+                    const float op = opacities[idx];
                     rec.x = px; rec.y = py;
                     rec.qa = -0.5f * cA * GSR_LOG2E; rec.qb = -cB * GSR_LOG2E; rec.qc = -0.5f * cC * GSR_LOG2E;
                     rec.opac = op; rec.r = cr; rec.g = cg; rec.b = cb; rec.depth = pv.z;
