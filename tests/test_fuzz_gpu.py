@@ -1,0 +1,52 @@
+"""Seeded fuzz of the HIP path against the oracle: random sizes that are not
+multiples of the 16-pixel tile, random cameras, active SH degree below the stored one, degenerate
+and huge scales, Gaussians behind / beside the camera, opacity extremes, scale_modifier, random
+background. Same tolerances as test_parity_gpu.py."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import gs_oracle as O
+from util import run_hip, run_oracle, weights_for, assert_forward_close, assert_grads_close, grad_floors
+
+pytestmark = pytest.mark.gpu
+
+
+def fuzz_case(seed):
+    rs = np.random.RandomState(1000 + seed)
+    N = int(rs.randint(1, 1500))
+    W, H = int(rs.randint(17, 200)), int(rs.randint(17, 200))
+    deg_max = int(rs.randint(0, 4))
+    deg = int(rs.randint(0, deg_max + 1))                       # active degree <= stored degree
+    kind = "trained" if rs.rand() < 0.7 else "blob"
+    sc = O.make_scene(N, deg_max, seed, kind)
+    g = torch.Generator().manual_seed(seed)
+    n_bad = max(1, N // 10)
+    idx = torch.randperm(N, generator=g)
+    sc["means3D"][idx[:n_bad], 2] += 3.0 + 3.0 * torch.rand(n_bad, generator=g)      # behind a z=+r camera
+    sc["means3D"][idx[n_bad:2 * n_bad], 0] += 2.5                                      # far to the side
+    sc["scales"][idx[2 * n_bad:3 * n_bad]] = 1e-6                                      # degenerate: 0.3 px floor
+    sc["scales"][idx[3 * n_bad:3 * n_bad + 3]] = 0.6                                   # splats larger than the frame
+    op = sc["opacities"]
+    op[idx[4 * n_bad:5 * n_bad]] = 0.0
+    op[idx[5 * n_bad:6 * n_bad]] = 1e-4
+    op[idx[6 * n_bad:7 * n_bad]] = 0.999
+    el, az, r = rs.uniform(-60, 60), rs.uniform(-180, 180), rs.uniform(1.2, 3.0)
+    S = O.make_settings(O.orbit_pose(el, az, r), W, H, fovy_deg=float(rs.uniform(30, 70)), sh_degree=deg,
+                        bg=tuple(rs.rand(3)), scale_modifier=float(rs.choice([1.0, 0.5, 1.7])))
+    return sc, S, W, H
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz(gpu, seed):
+    sc, S, W, H = fuzz_case(seed)
+    w = weights_for(H, W, seed=seed)
+    ho, hg, st = run_hip(sc, S, gpu, w)
+    oo, og, aux = run_oracle(sc, S, w, torch.float64)
+    assert st["V"] == aux["V"]
+    assert_forward_close(ho, oo, aux)
+    assert_grads_close(hg, og, aux, floors=grad_floors(sc, og))
+    for k in hg:
+        assert torch.isfinite(hg[k]).all(), k
