@@ -112,17 +112,17 @@ __device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, flo
 }
 
 // Stage `cnt` SH rows (each 3K floats, contiguous in HBM) into LDS with pitch 3K+1.
-template <int STAGE_U = 12>
 __device__ __forceinline__ void stage_rows_in(const float* __restrict__ src, float* lds,
-                                              int cnt, int rowlen, int tid, int nthr) {
+                                              int cnt, int rowlen) {
     const int total = cnt * rowlen;
     const int pitch = rowlen + 1;
     if ((rowlen & 3) == 0) {
         // all of a thread's loads are issued before the first LDS write: one HBM round trip per
         // batch of STAGE_U loads instead of one per load (the simple loop waits on every load)
+        constexpr int STAGE_U = 12;
         const float4* s4 = reinterpret_cast<const float4*>(src);
-        const int nvec = total / 4, stride = nthr;
-        for (int i0 = tid; i0 < nvec; i0 += stride * STAGE_U) {
+        const int nvec = total / 4, stride = blockDim.x;
+        for (int i0 = threadIdx.x; i0 < nvec; i0 += stride * STAGE_U) {
             float4 v[STAGE_U];
 #pragma unroll
             for (int u = 0; u < STAGE_U; ++u) {
@@ -140,35 +140,33 @@ __device__ __forceinline__ void stage_rows_in(const float* __restrict__ src, flo
             }
         }
     } else {
-        for (int e = tid; e < total; e += nthr) {
+        for (int e = threadIdx.x; e < total; e += blockDim.x) {
             const int row = e / rowlen, col = e - row * rowlen;
             lds[row * pitch + col] = src[e];
         }
     }
 }
 
-// Software-pipelined, PER-WAVE variant of stage_rows_in for rows of <= 48 floats (K <= 16): every
-// wave owns a stream of 64-Gaussian batches and a private LDS region, so there is no workgroup
-// barrier in the loop (a wave held back by a divergent tile loop no longer stalls its three
-// neighbours); the loads of batch i+1 are issued into registers before batch i is computed and
+// Software-pipelined variant of stage_rows_in for 256-thread blocks and rows of <= 48 floats
+// (K <= 16): the loads of batch i+1 are issued into registers before batch i is computed and
 // are committed to LDS one iteration later, so the HBM round trip hides behind the math.
-constexpr int STAGE_PF = 12;   // 16-byte loads per lane per batch (64 lanes x 12 x 16 B = 12 KiB)
-__device__ __forceinline__ void stage_issue(const float* __restrict__ src, int cnt, int rowlen, float4 (&v)[STAGE_PF], int lane) {
+constexpr int STAGE_PF = 12;   // 16-byte loads per thread per batch (256 threads x 12 x 16 B = 48 KiB)
+__device__ __forceinline__ void stage_issue(const float* __restrict__ src, int cnt, int rowlen, float4 (&v)[STAGE_PF]) {
     const float4* s4 = reinterpret_cast<const float4*>(src);
     const int nvec = (cnt * rowlen) >> 2;
 #pragma unroll
     for (int u = 0; u < STAGE_PF; ++u) {
-        const int i = lane + u * 64;
+        const int i = threadIdx.x + u * 256;
         if (i < nvec) v[u] = s4[i];
     }
 }
 template <int RL>   // RL > 0: compile-time row length (48 = SH degree 3), 0: runtime
-__device__ __forceinline__ void stage_commit(float* lds, int cnt, int rowlen_rt, const float4 (&v)[STAGE_PF], int lane) {
+__device__ __forceinline__ void stage_commit(float* lds, int cnt, int rowlen_rt, const float4 (&v)[STAGE_PF]) {
     const int rowlen = RL > 0 ? RL : rowlen_rt;
     const int nvec = (cnt * rowlen) >> 2, pitch = rowlen + 1;
 #pragma unroll
     for (int u = 0; u < STAGE_PF; ++u) {
-        const int i = lane + u * 64;
+        const int i = threadIdx.x + u * 256;
         if (i < nvec) {
             const int e = 4 * i, row = e / rowlen, col = e - row * rowlen;
             float* d = lds + row * pitch + col;
@@ -178,18 +176,18 @@ __device__ __forceinline__ void stage_commit(float* lds, int cnt, int rowlen_rt,
 }
 
 __device__ __forceinline__ void stage_rows_out(float* __restrict__ dst, const float* lds,
-                                               int cnt, int rowlen, int tid, int nthr) {
+                                               int cnt, int rowlen) {
     const int total = cnt * rowlen;
     const int pitch = rowlen + 1;
     if ((rowlen & 3) == 0) {
         float4* d4 = reinterpret_cast<float4*>(dst);
-        for (int i = tid; i < total / 4; i += nthr) {
+        for (int i = threadIdx.x; i < total / 4; i += blockDim.x) {
             const int e = 4 * i, row = e / rowlen, col = e - row * rowlen;
             const float* s = lds + row * pitch + col;
             d4[i] = make_float4(s[0], s[1], s[2], s[3]);
         }
     } else {
-        for (int e = tid; e < total; e += nthr) {
+        for (int e = threadIdx.x; e < total; e += blockDim.x) {
             const int row = e / rowlen, col = e - row * rowlen;
             dst[e] = lds[row * pitch + col];
         }
@@ -231,34 +229,25 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
     const float* __restrict__ P = vc.proj;
     unsigned long long my_ref = 0, my_vis = 0;
 
-    // Work unit: one WAVE (64 Gaussians, private LDS rows, no workgroup barrier) when the SH rows
-    // can be software-pipelined, otherwise the whole workgroup (256 Gaussians, block barriers).
     const bool pipelined = stage && (rowlen & 3) == 0 && rowlen <= 4 * STAGE_PF && blockDim.x == 256;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int unit = pipelined ? 64 : (int)blockDim.x;
-    const int utid = pipelined ? lane : (int)threadIdx.x;
-    const int ubase0 = pipelined ? (int)(blockIdx.x * 4 + wave) * 64 : (int)(blockIdx.x * blockDim.x);
-    const int ustride = pipelined ? (int)gridDim.x * 256 : (int)(gridDim.x * blockDim.x);
-    float* ulds = pipelined ? shbuf + wave * 64 * (rowlen + 1) : shbuf;
     float4 pf[STAGE_PF];
-    if (pipelined && ubase0 < N) stage_issue(shs + (size_t)ubase0 * rowlen, min(64, N - ubase0), rowlen, pf, lane);
+    if (pipelined && (int)(blockIdx.x * blockDim.x) < N)
+        stage_issue(shs + (size_t)(blockIdx.x * blockDim.x) * rowlen, min((int)blockDim.x, N - (int)(blockIdx.x * blockDim.x)), rowlen, pf);
 
-    for (int base = ubase0; base < N; base += ustride) {
-        const int cnt = min(unit, N - base);
+    for (int base = blockIdx.x * blockDim.x; base < N; base += gridDim.x * blockDim.x) {
+        const int cnt = min((int)blockDim.x, N - base);
         if (stage) {
+            __syncthreads();   // previous batch's readers are done
             if (pipelined) {
-                wave_lds_handoff();   // this wave's readers of the previous batch are done
-                if (rowlen == 48) stage_commit<48>(ulds, cnt, rowlen, pf, lane); else stage_commit<0>(ulds, cnt, rowlen, pf, lane);
-                const int next = base + ustride;
-                if (next < N) stage_issue(shs + (size_t)next * rowlen, min(64, N - next), rowlen, pf, lane);
-                wave_lds_handoff();
+                if (rowlen == 48) stage_commit<48>(shbuf, cnt, rowlen, pf); else stage_commit<0>(shbuf, cnt, rowlen, pf);
+                const int next = base + gridDim.x * blockDim.x;
+                if (next < N) stage_issue(shs + (size_t)next * rowlen, min((int)blockDim.x, N - next), rowlen, pf);
             } else {
-                __syncthreads();   // previous batch's readers are done
-                stage_rows_in(shs + (size_t)base * rowlen, ulds, cnt, rowlen, threadIdx.x, blockDim.x);
-                __syncthreads();
+                stage_rows_in(shs + (size_t)base * rowlen, shbuf, cnt, rowlen);
             }
+            __syncthreads();
         }
-        const int idx = base + utid;
+        const int idx = base + threadIdx.x;
         if (idx >= N) continue;
 
         SplatRec rec;
@@ -327,7 +316,7 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
                         float B[16];
                         sh_basis(vc.sh_degree, dx, dy, dz, B);
                         const int nb = (vc.sh_degree + 1) * (vc.sh_degree + 1);
-                        const float* row = stage ? (ulds + utid * (rowlen + 1)) : (shs + (size_t)idx * rowlen);
+                        const float* row = stage ? (shbuf + threadIdx.x * (rowlen + 1)) : (shs + (size_t)idx * rowlen);
                         float coef[48];
                         if (!stage && (rowlen & 3) == 0) {          // 16-byte aligned rows: wide loads
                             const float4* __restrict__ r4 = reinterpret_cast<const float4*>(row);
@@ -438,7 +427,7 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
 // forward intermediates from the inputs instead of re-reading saved state.
 // dynamic LDS: blockDim.x * (3K+1) floats when shs (used for SH in, then dSH out).
 // ---------------------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(256, 3)   // 3 workgroups (50 KiB LDS each) per CU
+extern "C" __global__ void __launch_bounds__(256)
 gsr_preprocess_bwd(ViewConst vc, int N, int K,
                    const float* __restrict__ means3D, const float* __restrict__ shs,
                    const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
@@ -457,24 +446,20 @@ gsr_preprocess_bwd(ViewConst vc, int N, int K,
     const float* __restrict__ V = vc.view;
     const float* __restrict__ P = vc.proj;
 
-    // work unit = one wave (64 Gaussians) with private LDS rows: wave-level hand-offs only, no
-    // workgroup barrier, so the load / math / store phases of the 12 waves of a CU overlap freely
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float* wlds = shbuf + wave * 64 * (rowlen + 1);
-    for (int base = (int)(blockIdx.x * (blockDim.x >> 6) + wave) * 64; base < N; base += (int)(gridDim.x * blockDim.x)) {
-        const int cnt = min(64, N - base);
+    for (int base = blockIdx.x * blockDim.x; base < N; base += gridDim.x * blockDim.x) {
+        const int cnt = min((int)blockDim.x, N - base);
         if (stage) {
-            wave_lds_handoff();
-            stage_rows_in<4>(shs + (size_t)base * rowlen, wlds, cnt, rowlen, lane, 64);
-            wave_lds_handoff();
+            __syncthreads();
+            stage_rows_in(shs + (size_t)base * rowlen, shbuf, cnt, rowlen);
+            __syncthreads();
         }
-        const int idx = base + lane;
+        const int idx = base + threadIdx.x;
         float dm[3] = {0.f, 0.f, 0.f};
         float dm2[2] = {0.f, 0.f};
         float dop = 0.f, dsc[3] = {0.f, 0.f, 0.f}, dq[4] = {0.f, 0.f, 0.f, 0.f};
         float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         float dcol[3] = {0.f, 0.f, 0.f};
-        float* myrow = wlds + lane * (rowlen + 1);
+        float* myrow = shbuf + threadIdx.x * (rowlen + 1);
         const bool live = (idx < N) && (radii[idx] > 0);
 
         if (live) {
@@ -665,8 +650,8 @@ gsr_preprocess_bwd(ViewConst vc, int N, int K,
             if (dL_drots) reinterpret_cast<float4*>(dL_drots)[idx] = make_float4(dq[0], dq[1], dq[2], dq[3]);
         }
         if (stage) {
-            wave_lds_handoff();
-            stage_rows_out(dL_dshs + (size_t)base * rowlen, wlds, cnt, rowlen, lane, 64);
+            __syncthreads();
+            stage_rows_out(dL_dshs + (size_t)base * rowlen, shbuf, cnt, rowlen);
         }
     }
 }
