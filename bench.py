@@ -132,6 +132,10 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-oracle compositing; 0 disables")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--trace-steps", action="store_true", help="print every timed step's wall time to stderr")
+    ap.add_argument("--views", type=int, default=1,
+                    help="cameras per step on each GPU (B > 1: dreamgaussian_amd.rasterize_views keeps them in flight "
+                         "together; --views-serial renders them one after the other like the reference's loop)")
+    ap.add_argument("--views-serial", action="store_true")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -161,7 +165,32 @@ def main():
     rast = D.GaussianRasterizer(raster_settings=rs)
     gather_buf = views.make_gather_buffer(world, 5, wl["H"], wl["W"], dev) if world > 1 else None
 
+    if a.views > 1:
+        from dreamgaussian_amd import synthetic as syn
+        vs = [D.GaussianRasterizationSettings(*[x.to(dev) if torch.is_tensor(x) else x for x in
+              syn.make_settings(syn.orbit_pose(0.0, azimuth + 360.0 * i / a.views, 2.0), wl["W"], wl["H"], sh_degree=wl["deg"])])
+              for i in range(a.views)]
+        m2d_b = torch.zeros(a.views, wl["N"], 3, device=dev, requires_grad=True)
+        m2d_l = [torch.zeros(wl["N"], 3, device=dev, requires_grad=True) for _ in range(a.views)]
+        rasts = [D.GaussianRasterizer(raster_settings=x) for x in vs]
+
+    def step_views():
+        for v in t.values():
+            v.grad = None
+        if a.views_serial:
+            for i in range(a.views):
+                m2d_l[i].grad = None
+                c, r, d, al = rasts[i](means3D=t["means3D"], means2D=m2d_l[i], shs=t["shs"], colors_precomp=None,
+                                       opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"], cov3D_precomp=None)
+                torch.autograd.backward([c, d, al], gout)
+        else:
+            m2d_b.grad = None
+            c, r, d, al = D.rasterize_views(t["means3D"], m2d_b, t["opacities"], vs, shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
+            torch.autograd.backward([c, d, al], [g.unsqueeze(0).expand(a.views, *g.shape).contiguous() for g in gout])
+
     def step(gather=True):
+        if a.views > 1:
+            return step_views()
         for v in t.values():
             v.grad = None
         m2d.grad = None
@@ -204,7 +233,7 @@ def main():
 
     # ---- per-kernel durations: hipEvents around every launch, same workload, K more steps ----
     kern, roof, path_roof, dt_prof = {}, None, None, None
-    if not a.no_roofline and rank == 0:
+    if not a.no_roofline and rank == 0 and a.views == 1:
         _lib.profile_reset()
         _lib.profile_enable(True)
         torch.cuda.synchronize()
@@ -253,7 +282,7 @@ def main():
         cpu["value"] = float(f"{cpu['value']:.4g}")
 
     if rank == 0:
-        rays = wl["H"] * wl["W"] * world * a.steps
+        rays = wl["H"] * wl["W"] * world * a.steps * a.views
         out = {
             "metric": "Mrays/s (fwd+bwd)", "value": round(rays / dt / 1e6, 3), "unit": "Mrays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -262,9 +291,9 @@ def main():
             "config": {"workload": f"BASELINE.json configs[{wl['cfg']}]: {wl['N']} Gaussians, SH degree "
                                    f"{wl['deg']}, {wl['W']}x{wl['H']}, fwd+bwd, scene '{a.kind}' seed 0, "
                                    f"orbit camera r=2 fovy=49.1",
-                       "views_per_step": world, "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU",
-                       "N": wl["N"], "K": K, "V": st["V"], "M": st["M_ref"], "M_emitted": st["M"],
-                       "max_tile_list": st["max_tile"]},
+                       "views_per_step": world * a.views, "views_mode": ("single" if a.views == 1 else ("serial loop" if a.views_serial else "rasterize_views")), "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU",
+                       "N": wl["N"], "K": K, "V": st.get("V"), "M": st.get("M_ref"), "M_emitted": st.get("M"),
+                       "max_tile_list": st.get("max_tile")},
             "roofline": roof, "path_roofline": path_roof, "cpu_baseline": cpu,
             "kernels_ms_per_step": {k: round(v[0] / a.steps, 4) for k, v in sorted(kern.items())},
             "ms_per_step_with_events": None if dt_prof is None else round(dt_prof / a.steps * 1e3, 4),

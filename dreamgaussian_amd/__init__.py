@@ -7,6 +7,7 @@ Public surface (mirrors what gs_renderer.py imports, gs_renderer.py:10-14):
 from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer,
                          rasterize_gaussians, last_stats)
 from .knn import distCUDA2
+from .batched import rasterize_views
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians",
-           "last_stats", "distCUDA2"]
+           "last_stats", "distCUDA2", "rasterize_views"]

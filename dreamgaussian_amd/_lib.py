@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GSR_LIB=<path> loads another build of the same ABI (A/B measurements of two source revisions)
 LIB_PATH = os.environ.get("GSR_LIB") or os.path.join(_HERE, "libgsr.so")
 
-EXPORTS = ("gsr_forward", "gsr_backward", "gsr_mark_visible", "gsr_dist2",
+EXPORTS = ("gsr_forward", "gsr_forward_begin", "gsr_forward_finish", "gsr_backward", "gsr_mark_visible", "gsr_dist2",
            "gsr_profile_enable", "gsr_profile_read", "gsr_profile_reset",
            "gsr_geom_bytes", "gsr_img_bytes", "gsr_last_error", "gsr_version")
 
@@ -60,6 +60,12 @@ def load() -> C.CDLL:
         lib.gsr_forward.restype = C.c_int
         lib.gsr_forward.argtypes = [C.POINTER(GsrView), i32, i32] + [p] * 7 + [p] * 4 + \
             [GsrAlloc, GsrAlloc, GsrAlloc, C.POINTER(GsrStats), vp]
+        lib.gsr_forward_begin.restype = C.c_int
+        lib.gsr_forward_begin.argtypes = [C.POINTER(GsrView), i32, i32] + [p] * 7 + [p] + \
+            [GsrAlloc, GsrAlloc, C.c_void_p, vp]
+        lib.gsr_forward_finish.restype = C.c_int
+        lib.gsr_forward_finish.argtypes = [C.POINTER(GsrView), i32, i32] + [p] * 3 + [p, p, GsrAlloc, C.c_void_p,
+                                                                                C.POINTER(GsrStats), vp]
         lib.gsr_backward.restype = C.c_int
         lib.gsr_backward.argtypes = [C.POINTER(GsrView), i32, i32] + [p] * 7 + [p] + [p] * 3 + \
             [p] * 3 + [C.POINTER(GsrStats)] + [p] * 8 + [GsrAlloc, vp]

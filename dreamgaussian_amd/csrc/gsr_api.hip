@@ -266,26 +266,32 @@ extern "C" size_t gsr_geom_bytes(int32_t N, int32_t H, int32_t W) { return geom_
 // final_T | n_contrib | totals[5] (the five per-pixel sums without background)
 extern "C" size_t gsr_img_bytes(int32_t H, int32_t W) { return align_up((size_t)H * W * 4) * 7; }
 
-extern "C" int gsr_forward(const GsrView* view, int32_t N, int32_t K,
-                           const float* means3D, const float* shs, const float* colors_precomp,
-                           const float* opacities, const float* scales, const float* rotations,
-                           const float* cov3D_precomp,
-                           float* out_color, float* out_depth, float* out_alpha, int32_t* radii,
-                           GsrAlloc geom, GsrAlloc bin, GsrAlloc img,
-                           GsrStats* stats, gsr_stream_t stream_) {
+// ---- forward, two phases -------------------------------------------------------------------
+// begin : per-Gaussian stage + tile scan on `stream`, then an async copy of the four counters
+//         (M_ref, V, M, longest list) to `host_counters` (caller-owned, pinned, 4 x u64).
+// finish: once the caller has waited for that copy: binning, sort, compositing.
+// gsr_forward = begin + stream synchronize + finish; callers that keep several views in flight
+// (one stream each) issue every begin first and pay the host round trip once.
+extern "C" int gsr_forward_begin(const GsrView* view, int32_t N, int32_t K,
+                                 const float* means3D, const float* shs, const float* colors_precomp,
+                                 const float* opacities, const float* scales, const float* rotations,
+                                 const float* cov3D_precomp, int32_t* radii,
+                                 GsrAlloc geom, GsrAlloc img, uint64_t* host_counters, gsr_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (int rc = check_view(view)) return rc;
     if (int rc = check_inputs(N, K, view, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp)) return rc;
-    if (!out_color || !out_depth || !out_alpha || (N > 0 && !radii)) return fail(-1, "output pointers are required%s", "");
-    if (!geom.resize || !bin.resize || !img.resize) return fail(-1, "scratch allocators are required%s", "");
+    if (N > 0 && !radii) return fail(-1, "radii is required%s", "");
+    if (!geom.resize || !img.resize || !host_counters) return fail(-1, "scratch allocators and host_counters are required%s", "");
+    const ViewConst vc0 = make_view(view);
+    const GeomLayout GL0 = geom_layout(N, vc0.H, vc0.W);
+    char* gbuf = (char*)geom.resize(geom.ctx, GL0.total);
+    char* ibuf = (char*)img.resize(img.ctx, gsr_img_bytes(vc0.H, vc0.W));
+    if (!gbuf || !ibuf) return fail(-4, "scratch allocation failed%s", "");
     const ViewConst vc = make_view(view);
     const int H = vc.H, W = vc.W;
     const GeomLayout GL = geom_layout(N, H, W);
     const int T = GL.nTiles;
 
-    char* gbuf = (char*)geom.resize(geom.ctx, GL.total);
-    char* ibuf = (char*)img.resize(img.ctx, gsr_img_bytes(H, W));
-    if (!gbuf || !ibuf) return fail(-4, "scratch allocation failed%s", "");
     SplatRec* recs = (SplatRec*)(gbuf + GL.recs);
     EmitRec* emit = (EmitRec*)(gbuf + GL.emit);
     uint32_t* tile_count = (uint32_t*)(gbuf + GL.tile_count);
@@ -293,20 +299,21 @@ extern "C" int gsr_forward(const GsrView* view, int32_t N, int32_t K,
     uint32_t* tile_off = (uint32_t*)(gbuf + GL.tile_off);
     uint32_t* tile_seg = (uint32_t*)(gbuf + GL.tile_seg);
     uint32_t* tile_last = (uint32_t*)(gbuf + GL.tile_last);
-    uint32_t* tile_order = nullptr;
+    uint32_t* tile_order = use_tile_order_off() ? nullptr : (uint32_t*)(gbuf + GL.tile_order);
     unsigned long long* counters = (unsigned long long*)(gbuf + GL.counters);
     float* final_T = (float*)ibuf;
     uint32_t* n_contrib = (uint32_t*)(ibuf + align_up((size_t)H * W * 4));
     float* totals = (float*)(ibuf + 2 * align_up((size_t)H * W * 4));
 
+    const int hist_in_lds = T <= kHistLdsMaxTiles;
+    const int grid_n = N > 0 ? (int)fmin((double)((N + 255) / 256), 512.0) : 0;
+    (void)cursor; (void)final_T; (void)n_contrib; (void)totals; (void)tile_last; (void)grid_n;
     // tile_count | cursor | counters are contiguous: one memset
     prof_begin(stream);
     HIP_TRY(hipMemsetAsync(gbuf + GL.tile_count, 0, GL.tile_off - GL.tile_count, stream));
     prof_end(stream, "memset_fwd");
 
-    const int hist_in_lds = T <= kHistLdsMaxTiles;
     const int sh_direct = use_sh_stage() ? 0 : 1;
-    const int grid_n = N > 0 ? (int)fmin((double)((N + 255) / 256), 512.0) : 0;
     const int grid_pre = N > 0 ? (int)fmin((double)((N + 255) / 256), sh_direct ? 2048.0 : 512.0) : 0;
     if (N > 0) {
         const size_t hist_bytes = hist_in_lds ? (((size_t)T * 4 + 15) & ~(size_t)15) : 0;
@@ -323,16 +330,47 @@ extern "C" int gsr_forward(const GsrView* view, int32_t N, int32_t K,
     prof_begin(stream); hipLaunchKernelGGL(gsr_tile_scan, dim3(1), dim3(1024), 0, stream, tile_count, tile_off, T, counters, tile_seg, seg_shift());
     LAUNCH_CHECK(view, stream, "tile_scan");
     if (!use_tile_order_off()) {                          // heaviest tiles first
-        tile_order = (uint32_t*)(gbuf + GL.tile_order);
         prof_begin(stream); hipLaunchKernelGGL(gsr_tile_order, dim3(1), dim3(1024), 0, stream, tile_count, T, counters, tile_order);
         LAUNCH_CHECK(view, stream, "tile_order");
     }
 
-    // the one host round trip of the forward: how many (tile,Gaussian) instances to allocate
-    if (!g_pinned) HIP_TRY(hipHostMalloc((void**)&g_pinned, 8 * sizeof(unsigned long long), hipHostMallocDefault));
-    HIP_TRY(hipMemcpyAsync(g_pinned, counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    const unsigned long long M_ref = g_pinned[0], V = g_pinned[1], M = g_pinned[2], maxc = g_pinned[3];
+    HIP_TRY(hipMemcpyAsync(host_counters, counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    return 0;
+}
+
+extern "C" int gsr_forward_finish(const GsrView* view, int32_t N, int32_t K,
+                                  float* out_color, float* out_depth, float* out_alpha,
+                                  void* geom_ptr, void* img_ptr, GsrAlloc bin,
+                                  const uint64_t* host_counters, GsrStats* stats, gsr_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (int rc = check_view(view)) return rc;
+    if (!out_color || !out_depth || !out_alpha) return fail(-1, "output pointers are required%s", "");
+    if (!geom_ptr || !img_ptr || !bin.resize || !host_counters) return fail(-1, "forward_begin state is required%s", "");
+    char* gbuf = (char*)geom_ptr;
+    char* ibuf = (char*)img_ptr;
+    (void)K;
+    const ViewConst vc = make_view(view);
+    const int H = vc.H, W = vc.W;
+    const GeomLayout GL = geom_layout(N, H, W);
+    const int T = GL.nTiles;
+
+    SplatRec* recs = (SplatRec*)(gbuf + GL.recs);
+    EmitRec* emit = (EmitRec*)(gbuf + GL.emit);
+    uint32_t* tile_count = (uint32_t*)(gbuf + GL.tile_count);
+    uint32_t* cursor = (uint32_t*)(gbuf + GL.cursor);
+    uint32_t* tile_off = (uint32_t*)(gbuf + GL.tile_off);
+    uint32_t* tile_seg = (uint32_t*)(gbuf + GL.tile_seg);
+    uint32_t* tile_last = (uint32_t*)(gbuf + GL.tile_last);
+    uint32_t* tile_order = use_tile_order_off() ? nullptr : (uint32_t*)(gbuf + GL.tile_order);
+    unsigned long long* counters = (unsigned long long*)(gbuf + GL.counters);
+    float* final_T = (float*)ibuf;
+    uint32_t* n_contrib = (uint32_t*)(ibuf + align_up((size_t)H * W * 4));
+    float* totals = (float*)(ibuf + 2 * align_up((size_t)H * W * 4));
+
+    const int hist_in_lds = T <= kHistLdsMaxTiles;
+    const int grid_n = N > 0 ? (int)fmin((double)((N + 255) / 256), 512.0) : 0;
+    (void)emit; (void)tile_count; (void)counters;
+    const unsigned long long M_ref = host_counters[0], V = host_counters[1], M = host_counters[2], maxc = host_counters[3];
     if (stats) { stats->num_instances = (int64_t)M; stats->num_instances_ref = (int64_t)M_ref; stats->num_visible = (int64_t)V; stats->max_tile_count = (int64_t)maxc; }
     if (M >= 0xfffffff0ull) return fail(-5, "too many tile instances (%s%lld)", "", (long long)M);
 
@@ -408,6 +446,30 @@ extern "C" int gsr_forward(const GsrView* view, int32_t N, int32_t K,
     }
     LAUNCH_CHECK(view, stream, "render_fwd");
     return 0;
+}
+
+
+extern "C" int gsr_forward(const GsrView* view, int32_t N, int32_t K,
+                           const float* means3D, const float* shs, const float* colors_precomp,
+                           const float* opacities, const float* scales, const float* rotations,
+                           const float* cov3D_precomp,
+                           float* out_color, float* out_depth, float* out_alpha, int32_t* radii,
+                           GsrAlloc geom, GsrAlloc bin, GsrAlloc img,
+                           GsrStats* stats, gsr_stream_t stream_) {
+    if (int rc = check_view(view)) return rc;
+    if (int rc = check_inputs(N, K, view, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp)) return rc;
+    if (!out_color || !out_depth || !out_alpha || (N > 0 && !radii)) return fail(-1, "output pointers are required%s", "");
+    if (!geom.resize || !bin.resize || !img.resize) return fail(-1, "scratch allocators are required%s", "");
+    // the one host round trip of the forward: how many (tile,Gaussian) instances to allocate
+    if (!g_pinned) HIP_TRY(hipHostMalloc((void**)&g_pinned, 8 * sizeof(unsigned long long), hipHostMallocDefault));
+    struct Capture { GsrAlloc inner; void* ptr; };
+    Capture cg{geom, nullptr}, ci{img, nullptr};
+    auto tramp = [](void* ctx, size_t bytes) -> void* { Capture* c = (Capture*)ctx; c->ptr = c->inner.resize(c->inner.ctx, bytes); return c->ptr; };
+    GsrAlloc ag{&cg, tramp}, ai{&ci, tramp};
+    if (int rc = gsr_forward_begin(view, N, K, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                   radii, ag, ai, (uint64_t*)g_pinned, stream_)) return rc;
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream_));
+    return gsr_forward_finish(view, N, K, out_color, out_depth, out_alpha, cg.ptr, ci.ptr, bin, (const uint64_t*)g_pinned, stats, stream_);
 }
 
 extern "C" int gsr_backward(const GsrView* view, int32_t N, int32_t K,

@@ -12,6 +12,7 @@
  * Reference interfaces each entry point replaces (file:line in /root/reference):
  *   gsr_forward       <- GaussianRasterizer(raster_settings)(means3D, means2D, shs, ...)
  *                        gs_renderer.py:760,800-809  (ext: _C.rasterize_gaussians)
+ *   gsr_forward_begin / _finish <- the serial per-view render loop main.py:219-255 (several views in flight)
  *   gsr_backward      <- loss.backward() through that call, main.py:273
  *                        (ext: _C.rasterize_gaussians_backward)
  *   gsr_mark_visible  <- GaussianRasterizer.markVisible (ext: _C.mark_visible; never called
@@ -82,6 +83,25 @@ int gsr_forward(const GsrView* view, int32_t N, int32_t K,
                 float* out_color, float* out_depth, float* out_alpha, int32_t* radii,
                 GsrAlloc geom, GsrAlloc bin, GsrAlloc img,
                 GsrStats* stats, gsr_stream_t stream);
+
+/* The forward in two phases, for callers that keep several views in flight (one stream per view):
+ *   gsr_forward_begin   per-Gaussian stage + tile scan, then an async copy of four counters
+ *                       (M_ref, V, M, longest list) into host_counters (pinned, 4 x uint64, caller-owned);
+ *                       geom / img scratch are obtained through the callbacks as in gsr_forward
+ *   gsr_forward_finish  after the caller has waited for `stream` (or an event recorded behind
+ *                       begin): binning, sort, compositing; geom_ptr / img_ptr are the buffers the
+ *                       callbacks returned in begin
+ * gsr_forward == begin + stream synchronise + finish. Issuing every view's begin before the first
+ * finish pays the host round trip once per batch of views instead of once per view. */
+int gsr_forward_begin(const GsrView* view, int32_t N, int32_t K,
+                      const float* means3D, const float* shs, const float* colors_precomp,
+                      const float* opacities, const float* scales, const float* rotations,
+                      const float* cov3D_precomp, int32_t* radii,
+                      GsrAlloc geom, GsrAlloc img, uint64_t* host_counters, gsr_stream_t stream);
+int gsr_forward_finish(const GsrView* view, int32_t N, int32_t K,
+                       float* out_color, float* out_depth, float* out_alpha,
+                       void* geom_ptr, void* img_ptr, GsrAlloc bin,
+                       const uint64_t* host_counters, GsrStats* stats, gsr_stream_t stream);
 
 /* Backward. Same inputs as the forward plus the incoming gradients
  *   dL_dcolor [3,H,W]  dL_ddepth [H,W]  dL_dalpha [H,W]

@@ -1,0 +1,66 @@
+"""rasterize_views (several cameras in flight on one GPU, two-phase C ABI) must equal B single-view
+calls: forward bit for bit, gradients of the shared Gaussians = sum over views."""
+import pytest
+import torch
+
+from oracle import gs_oracle as O
+from util import settings_to, weights_for
+import dreamgaussian_amd as D
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("deg,N,size", [(0, 3000, 128), (3, 1500, 96)])
+def test_batched_views_equal_serial(gpu, deg, N, size):
+    sc = O.make_scene(N, deg, 0, "trained")
+    azs = [0.0, 70.0, 160.0, -95.0, 33.0]
+    S = [settings_to(O.make_settings(O.orbit_pose(-10.0 + 7 * i, az, 2.0 + 0.1 * i), size, size, sh_degree=deg), gpu)
+         for i, az in enumerate(azs)]
+    B = len(S)
+    w = [[x.to(gpu) for x in weights_for(size, size, seed=10 + i)] for i in range(B)]
+
+    def leaves():
+        return {k: v.to(gpu).requires_grad_(True) for k, v in sc.items()}
+
+    # serial: the reference's loop (main.py:219-255)
+    t = leaves()
+    m2 = [torch.zeros(N, 3, device=gpu, requires_grad=True) for _ in range(B)]
+    outs = []
+    for i in range(B):
+        c, r, d, a = D.GaussianRasterizer(raster_settings=S[i])(
+            means3D=t["means3D"], means2D=m2[i], shs=t["shs"], colors_precomp=None, opacities=t["opacities"],
+            scales=t["scales"], rotations=t["rotations"], cov3D_precomp=None)
+        outs.append((c, r, d, a))
+    loss = sum((w[i][0] * outs[i][0]).sum() + (w[i][1] * outs[i][2]).sum() + (w[i][2] * outs[i][3]).sum() for i in range(B))
+    loss.backward()
+    ref = {k: v.grad.clone() for k, v in t.items()}
+
+    # batched
+    t2 = leaves()
+    m2b = torch.zeros(B, N, 3, device=gpu, requires_grad=True)
+    color, radii, depth, alpha = D.rasterize_views(t2["means3D"], m2b, t2["opacities"], S, shs=t2["shs"],
+                                                   scales=t2["scales"], rotations=t2["rotations"])
+    assert color.shape == (B, 3, size, size) and radii.shape == (B, N) and depth.shape == (B, 1, size, size)
+    for i in range(B):
+        assert torch.equal(color[i], outs[i][0]) and torch.equal(radii[i], outs[i][1])
+        assert torch.equal(depth[i], outs[i][2]) and torch.equal(alpha[i], outs[i][3])
+    lossb = sum((w[i][0] * color[i]).sum() + (w[i][1] * depth[i]).sum() + (w[i][2] * alpha[i]).sum() for i in range(B))
+    lossb.backward()
+    for k in ref:
+        scale = ref[k].abs().max().item() + 1e-12
+        assert (t2[k].grad - ref[k]).abs().max().item() <= 2e-5 * scale, k
+    for i in range(B):
+        scale = m2[i].grad.abs().max().item() + 1e-12
+        assert (m2b.grad[i] - m2[i].grad).abs().max().item() <= 2e-5 * scale
+
+
+def test_batched_views_argument_errors(gpu):
+    sc = {k: v.to(gpu) for k, v in O.make_scene(50, 0, 0, "blob").items()}
+    S = [settings_to(O.make_settings(O.orbit_pose(0, 0, 2.0), 32, 32), gpu),
+         settings_to(O.make_settings(O.orbit_pose(0, 90, 2.0), 48, 32), gpu)]
+    with pytest.raises(RuntimeError, match="one image size"):
+        D.rasterize_views(sc["means3D"], torch.zeros(2, 50, 3, device=gpu), sc["opacities"], S, shs=sc["shs"],
+                          scales=sc["scales"], rotations=sc["rotations"])
+    with pytest.raises(RuntimeError, match="num_views"):
+        D.rasterize_views(sc["means3D"], torch.zeros(50, 3, device=gpu), sc["opacities"], S[:1], shs=sc["shs"],
+                          scales=sc["scales"], rotations=sc["rotations"])

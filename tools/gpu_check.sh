@@ -34,6 +34,14 @@ ab)
       echo "== variant [$v] bench 1M trained"; env $v timeout 300 python bench.py --cpu-budget 0 --kind trained 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['config']['M'], d['config']['M_emitted'], d['kernels_ms_per_step'])"
     fi
   done;;
+views)
+  echo "== batched views on one GPU (BASELINE configs[3] scene: 250k, 512^2, 8 cameras)"
+  for m in "--views 8 --views-serial" "--views 8"; do
+    timeout 300 python bench.py --workload 250k-512-sh0 --cpu-budget 0 $m 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['config']['views_mode'], d['value'], 'Mrays/s', d['ms_per_step'], 'ms per 8 views')"
+  done
+  for m in "--views 8 --views-serial" "--views 8"; do
+    timeout 300 python bench.py --workload 5k-256-sh0 --cpu-budget 0 $m 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('5k', d['config']['views_mode'], d['value'], 'Mrays/s', d['ms_per_step'], 'ms per 8 views')"
+  done;;
 pmc)
   echo "== rocprofv3 PMC passes (1M)"
   for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE SQ_INSTS_VMEM SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_VMEM"; do
