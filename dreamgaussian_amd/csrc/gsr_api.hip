@@ -217,6 +217,10 @@ int seg_shift() {
     }();
     return v;
 }
+int k1_dbg() {   // GSR_K1_DBG: timing experiments on K1 (WRONG results)
+    static const int v = [] { const char* e = getenv("GSR_K1_DBG"); return e ? atoi(e) : 0; }();
+    return v;
+}
 bool use_bwd_b2f() {
     static const bool v = [] { const char* e = getenv("GSR_BWD"); return e && strcmp(e, "b2f") == 0; }();
     return v;
@@ -324,7 +328,7 @@ extern "C" int gsr_forward_begin(const GsrView* view, int32_t N, int32_t K,
             HIP_TRY(hipFuncSetAttribute((const void*)gsr_preprocess_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         prof_begin(stream); hipLaunchKernelGGL(gsr_preprocess_fwd, dim3(grid_pre), dim3(256), lds, stream, vc, N, K, means3D, shs,
                            colors_precomp, opacities, scales, rotations, cov3D_precomp, recs, emit, radii,
-                           tile_count, counters, hist_in_lds, sh_direct);
+                           tile_count, counters, hist_in_lds, sh_direct, k1_dbg());
         LAUNCH_CHECK(view, stream, "preprocess_fwd");
     }
     prof_begin(stream); hipLaunchKernelGGL(gsr_tile_scan, dim3(1), dim3(1024), 0, stream, tile_count, tile_off, T, counters, tile_seg, seg_shift());

@@ -209,7 +209,7 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
                    SplatRec* __restrict__ recs, EmitRec* __restrict__ emit,
                    int32_t* __restrict__ radii, uint32_t* __restrict__ tile_count,
                    unsigned long long* __restrict__ counters /*[0]=M_ref [1]=V*/,
-                   int hist_in_lds, int sh_direct) {
+                   int hist_in_lds, int sh_direct, int dbg /* timing experiments: 1 no tile loop, 2 no stores, 4 no colour */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int nTiles = vc.gx * vc.gy;
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem_raw);
@@ -315,7 +315,7 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
                         dx *= inv; dy *= inv; dz *= inv;
                         float B[16];
                         sh_basis(vc.sh_degree, dx, dy, dz, B);
-                        const int nb = (vc.sh_degree + 1) * (vc.sh_degree + 1);
+                        const int nb = (dbg & 4) ? 0 : (vc.sh_degree + 1) * (vc.sh_degree + 1);
                         const float* row = stage ? (shbuf + threadIdx.x * (rowlen + 1)) : (shs + (size_t)idx * rowlen);
                         float coef[48];
                         if (!stage && (rowlen & 3) == 0) {          // 16-byte aligned rows: wide loads
@@ -365,7 +365,7 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
                             ey1 = min(ry1, min(iby1, vc.H - 1) / GSR_TILE + 1);
                         }
                     }
-                    if (ex1 > ex0 && ey1 > ey0) {
+                    if (ex1 > ex0 && ey1 > ey0 && !(dbg & 1)) {
                         // tile-exact emission for small rects: keep a tile only if alpha can reach
                         // 1/255 on one of its pixels (bit mask travels to the scatter kernel)
                         const bool masked = (ex1 - ex0) * (ey1 - ey0) <= GSR_EMIT_MASK_TILES;
@@ -396,6 +396,7 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
             }
         }
         radii[idx] = radius_out;
+        if (dbg & 2) { if (rec.x == 12345.678f) radii[idx] = 7; continue; }
         reinterpret_cast<uint4*>(recs + idx)[0] = reinterpret_cast<uint4*>(&rec)[0];
         reinterpret_cast<uint4*>(recs + idx)[1] = reinterpret_cast<uint4*>(&rec)[1];
         reinterpret_cast<uint4*>(recs + idx)[2] = reinterpret_cast<uint4*>(&rec)[2];
