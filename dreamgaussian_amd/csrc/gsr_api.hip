@@ -318,7 +318,8 @@ extern "C" int gsr_forward_begin(const GsrView* view, int32_t N, int32_t K,
     prof_end(stream, "memset_fwd");
 
     const int sh_direct = use_sh_stage() ? 0 : 1;
-    const int grid_pre = N > 0 ? (int)fmin((double)((N + 255) / 256), sh_direct ? 2048.0 : 512.0) : 0;
+    static const int k1_grid = [] { const char* e = getenv("GSR_K1_GRID"); return e ? atoi(e) : 512; }();
+    const int grid_pre = N > 0 ? (int)fmin((double)((N + 255) / 256), sh_direct ? 2048.0 : (double)k1_grid) : 0;
     if (N > 0) {
         const size_t hist_bytes = hist_in_lds ? (((size_t)T * 4 + 15) & ~(size_t)15) : 0;
         const size_t sh_bytes = (shs && K > 1 && !sh_direct) ? (size_t)256 * (3 * K + 1) * 4 : 0;

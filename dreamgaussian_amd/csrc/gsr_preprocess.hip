@@ -218,7 +218,7 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
     // sh_direct: every lane reads its own SH row with 16-byte loads (no LDS transpose): LDS then
     // only holds the tile histogram and ~4x more waves fit on a CU -- the kernel is latency-bound
     // (PMC: 79% of wave cycles waiting at 2 waves/SIMD with the 50 KiB staging buffer).
-    const bool stage = (shs != nullptr) && (K > 1) && !sh_direct;
+    const bool stage = (shs != nullptr) && (K > 1) && !sh_direct && !(dbg & 8);   // dbg 8: no SH traffic at all
 
     if (hist_in_lds) {
         for (int t = threadIdx.x; t < nTiles; t += blockDim.x) hist[t] = 0;
@@ -315,7 +315,7 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
                         dx *= inv; dy *= inv; dz *= inv;
                         float B[16];
                         sh_basis(vc.sh_degree, dx, dy, dz, B);
-                        const int nb = (dbg & 4) ? 0 : (vc.sh_degree + 1) * (vc.sh_degree + 1);
+                        const int nb = (dbg & 12) ? 0 : (vc.sh_degree + 1) * (vc.sh_degree + 1);
                         const float* row = stage ? (shbuf + threadIdx.x * (rowlen + 1)) : (shs + (size_t)idx * rowlen);
                         float coef[48];
                         if (!stage && (rowlen & 3) == 0) {          // 16-byte aligned rows: wide loads
