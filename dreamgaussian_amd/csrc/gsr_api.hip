@@ -80,7 +80,7 @@ int launch_status(bool debug, hipStream_t stream, const char* name) {
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 struct GeomLayout {
-    size_t recs, emit, tile_count, cursor, tile_last, tile_off, tile_seg, tile_order, plan_off, counters, total;
+    size_t recs, emit, block_stats, tile_count, cursor, tile_last, tile_off, tile_seg, tile_order, plan_off, counters, total;
     int nTiles;
 };
 GeomLayout geom_layout(int N, int H, int W) {
@@ -90,6 +90,7 @@ GeomLayout geom_layout(int N, int H, int W) {
     size_t o = 0;
     L.recs = o; o += align_up((size_t)N * sizeof(SplatRec));
     L.emit = o; o += align_up((size_t)N * sizeof(EmitRec));
+    L.block_stats = o; o += align_up(2048 * 2 * 8);       // K1 grid <= 2048 workgroups
     L.tile_count = o; o += align_up((size_t)L.nTiles * 4);
     L.cursor = o; o += align_up((size_t)L.nTiles * 4);
     L.tile_last = o; o += align_up((size_t)L.nTiles * 4);
@@ -329,10 +330,11 @@ extern "C" int gsr_forward_begin(const GsrView* view, int32_t N, int32_t K,
             HIP_TRY(hipFuncSetAttribute((const void*)gsr_preprocess_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         prof_begin(stream); hipLaunchKernelGGL(gsr_preprocess_fwd, dim3(grid_pre), dim3(256), lds, stream, vc, N, K, means3D, shs,
                            colors_precomp, opacities, scales, rotations, cov3D_precomp, recs, emit, radii,
-                           tile_count, counters, hist_in_lds, sh_direct, k1_dbg());
+                           tile_count, (unsigned long long*)(gbuf + GL.block_stats), hist_in_lds, sh_direct, k1_dbg());
         LAUNCH_CHECK(view, stream, "preprocess_fwd");
     }
-    prof_begin(stream); hipLaunchKernelGGL(gsr_tile_scan, dim3(1), dim3(1024), 0, stream, tile_count, tile_off, T, counters, tile_seg, seg_shift());
+    prof_begin(stream); hipLaunchKernelGGL(gsr_tile_scan, dim3(1), dim3(1024), 0, stream, tile_count, tile_off, T, counters, tile_seg, seg_shift(),
+                       (const unsigned long long*)(gbuf + GL.block_stats), N > 0 ? grid_pre : 0);
     LAUNCH_CHECK(view, stream, "tile_scan");
     if (!use_tile_order_off()) {                          // heaviest tiles first
         prof_begin(stream); hipLaunchKernelGGL(gsr_tile_order, dim3(1), dim3(1024), 0, stream, tile_count, T, counters, tile_order);

@@ -18,7 +18,8 @@
 // ---------------------------------------------------------------------------------------
 extern "C" __global__ void __launch_bounds__(1024)
 gsr_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_off, int T,
-              unsigned long long* __restrict__ counters, uint32_t* __restrict__ tile_seg, int seg_shift) {
+              unsigned long long* __restrict__ counters, uint32_t* __restrict__ tile_seg, int seg_shift,
+              const unsigned long long* __restrict__ block_stats, int nblocks) {
     // tile_seg[t] = index of tile t's first checkpoint slot = exclusive scan of floor((n_t-1) >> seg_shift)
     __shared__ unsigned long long wsum[16];
     __shared__ uint32_t wsegs[16];
@@ -55,6 +56,11 @@ gsr_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ ti
         tile_off[i] = (uint32_t)run; run += c;
         tile_seg[i] = srun; srun += c ? (c - 1) >> seg_shift : 0u;
     }
+    if (threadIdx.x < 2) {                                // K1's per-workgroup statistics: M_ref, V
+        unsigned long long sum = 0;
+        for (int b = 0; b < nblocks; ++b) sum += block_stats[2 * b + threadIdx.x];
+        counters[threadIdx.x] = sum;
+    }
     if (threadIdx.x == 1023) {
         tile_off[T] = (uint32_t)(wave_base + incl);
         counters[2] = wave_base + incl;
@@ -87,7 +93,9 @@ gsr_scatter(int N, const EmitRec* __restrict__ emit, const uint32_t* __restrict_
                     if (!masked || (em.w & bit)) atomicAdd(&hist[ty * gx + tx], 1u);
         }
         __syncthreads();
-        for (int t = threadIdx.x; t < nTiles; t += blockDim.x) {
+        const int t0 = (int)((blockIdx.x * 67u) % (unsigned)nTiles);   // staggered: see K1's flush
+        for (int i = threadIdx.x; i < nTiles; i += blockDim.x) {
+            int t = t0 + i; if (t >= nTiles) t -= nTiles;
             const uint32_t c = hist[t];
             hist[t] = c ? (tile_off[t] + atomicAdd(&cursor[t], c)) : 0u;
         }

@@ -208,7 +208,7 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
                    const float* __restrict__ cov3D_precomp,
                    SplatRec* __restrict__ recs, EmitRec* __restrict__ emit,
                    int32_t* __restrict__ radii, uint32_t* __restrict__ tile_count,
-                   unsigned long long* __restrict__ counters /*[0]=M_ref [1]=V*/,
+                   unsigned long long* __restrict__ block_stats /*[grid][2]: M_ref, V per workgroup*/,
                    int hist_in_lds, int sh_direct, int dbg /* timing experiments: 1 no tile loop, 2 no stores, 4 no colour */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int nTiles = vc.gx * vc.gy;
@@ -404,19 +404,27 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
         reinterpret_cast<uint4*>(emit)[idx] = *reinterpret_cast<uint4*>(&em);
     }
 
-    // statistics (wave-aggregated)
+    // statistics: wave -> workgroup in LDS -> one plain store per workgroup (summed by tile_scan).
+    // Same-address global atomics execute one after the other at the memory side: 2 per wave to two
+    // shared counters was ~40 us of serialised tail at 2048 waves.
+    __shared__ unsigned long long wstat[2][16];
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         my_ref += __shfl_xor(my_ref, off, 64);
         my_vis += __shfl_xor(my_vis, off, 64);
     }
-    if ((threadIdx.x & 63) == 0) {
-        if (my_ref) atomicAdd(&counters[0], my_ref);
-        if (my_vis) atomicAdd(&counters[1], my_vis);
+    if ((threadIdx.x & 63) == 0) { wstat[0][threadIdx.x >> 6] = my_ref; wstat[1][threadIdx.x >> 6] = my_vis; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        unsigned long long sum = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sum += wstat[threadIdx.x][w];
+        block_stats[2 * blockIdx.x + threadIdx.x] = sum;
     }
     if (hist_in_lds) {
-        __syncthreads();
-        for (int t = threadIdx.x; t < nTiles; t += blockDim.x) {
+        // every workgroup starts its flush at a different tile: no burst of atomics on one address
+        const int t0 = (int)((blockIdx.x * 67u) % (unsigned)nTiles);
+        for (int i = threadIdx.x; i < nTiles; i += blockDim.x) {
+            int t = t0 + i; if (t >= nTiles) t -= nTiles;
             const uint32_t c = hist[t];
             if (c) atomicAdd(&tile_count[t], c);
         }
