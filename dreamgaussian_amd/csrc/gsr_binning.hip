@@ -56,10 +56,19 @@ gsr_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ ti
         tile_off[i] = (uint32_t)run; run += c;
         tile_seg[i] = srun; srun += c ? (c - 1) >> seg_shift : 0u;
     }
-    if (threadIdx.x < 2) {                                // K1's per-workgroup statistics: M_ref, V
-        unsigned long long sum = 0;
-        for (int b = 0; b < nblocks; ++b) sum += block_stats[2 * b + threadIdx.x];
-        counters[threadIdx.x] = sum;
+    {   // K1's per-workgroup statistics (M_ref, V): parallel sum over the workgroups
+        __shared__ unsigned long long sref[16], svis[16];
+        unsigned long long a = 0, b = 0;
+        for (int i = threadIdx.x; i < nblocks; i += 1024) { a += block_stats[2 * i]; b += block_stats[2 * i + 1]; }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
+        if (lane == 0) { sref[wave] = a; svis[wave] = b; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long ta = 0, tb = 0;
+            for (int w = 0; w < 16; ++w) { ta += sref[w]; tb += svis[w]; }
+            counters[0] = ta; counters[1] = tb;
+        }
     }
     if (threadIdx.x == 1023) {
         tile_off[T] = (uint32_t)(wave_base + incl);
