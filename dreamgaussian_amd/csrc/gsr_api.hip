@@ -80,7 +80,7 @@ int launch_status(bool debug, hipStream_t stream, const char* name) {
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 struct GeomLayout {
-    size_t recs, emit, block_stats, tile_count, cursor, tile_last, tile_off, tile_seg, tile_order, plan_off, counters, total;
+    size_t recs, emit, flags8, block_stats, tile_count, cursor, tile_last, tile_off, tile_seg, tile_order, plan_off, counters, total;
     int nTiles;
 };
 GeomLayout geom_layout(int N, int H, int W) {
@@ -90,6 +90,7 @@ GeomLayout geom_layout(int N, int H, int W) {
     size_t o = 0;
     L.recs = o; o += align_up((size_t)N * sizeof(SplatRec));
     L.emit = o; o += align_up((size_t)N * sizeof(EmitRec));
+    L.flags8 = o; o += align_up((size_t)N);
     L.block_stats = o; o += align_up(2048 * 2 * 8);       // K1 grid <= 2048 workgroups
     L.tile_count = o; o += align_up((size_t)L.nTiles * 4);
     L.cursor = o; o += align_up((size_t)L.nTiles * 4);
@@ -330,7 +331,7 @@ extern "C" int gsr_forward_begin(const GsrView* view, int32_t N, int32_t K,
             HIP_TRY(hipFuncSetAttribute((const void*)gsr_preprocess_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         prof_begin(stream); hipLaunchKernelGGL(gsr_preprocess_fwd, dim3(grid_pre), dim3(256), lds, stream, vc, N, K, means3D, shs,
                            colors_precomp, opacities, scales, rotations, cov3D_precomp, recs, emit, radii,
-                           tile_count, (unsigned long long*)(gbuf + GL.block_stats), hist_in_lds, sh_direct, k1_dbg());
+                           tile_count, (unsigned long long*)(gbuf + GL.block_stats), hist_in_lds, sh_direct, k1_dbg(), (uint8_t*)(gbuf + GL.flags8));
         LAUNCH_CHECK(view, stream, "preprocess_fwd");
     }
     prof_begin(stream); hipLaunchKernelGGL(gsr_tile_scan, dim3(1), dim3(1024), 0, stream, tile_count, tile_off, T, counters, tile_seg, seg_shift(),
@@ -573,7 +574,7 @@ extern "C" int gsr_backward(const GsrView* view, int32_t N, int32_t K,
     if (lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void*)gsr_preprocess_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     prof_begin(stream); hipLaunchKernelGGL(gsr_preprocess_bwd, dim3(grid_n), dim3(256), lds, stream, vc, N, K, means3D, shs,
-                       colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, recs, g2d,
+                       colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, (const uint8_t*)(gbuf + GL.flags8), g2d,
                        dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacities, dL_dscales,
                        dL_drotations, dL_dcov3D);
     LAUNCH_CHECK(view, stream, "preprocess_bwd");
@@ -625,7 +626,7 @@ extern "C" int gsr_dist2(int32_t P, const float* points, float* out, GsrAlloc tm
     HIP_TRY(hipMemsetAsync(cnt, 0, o_off - o_cnt, stream));   // cnt | cur
     const int grid_p = (int)fmin((double)((P + 255) / 256), 2048.0);
     GsrView dbg; memset(&dbg, 0, sizeof(dbg));
-    prof_begin(stream); hipLaunchKernelGGL(gsr_knn_bbox, dim3(grid_p), dim3(256), 0, stream, P, points, bbox);
+    prof_begin(stream); hipLaunchKernelGGL(gsr_knn_bbox, dim3(grid_p < 256 ? grid_p : 256), dim3(256), 0, stream, P, points, bbox);
     LAUNCH_CHECK(&dbg, stream, "knn_bbox");
     prof_begin(stream); hipLaunchKernelGGL(gsr_knn_grid_setup, dim3(1), dim3(64), 0, stream, bbox, G, grid);
     LAUNCH_CHECK(&dbg, stream, "knn_grid_setup");

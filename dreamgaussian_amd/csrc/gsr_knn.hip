@@ -54,9 +54,19 @@ gsr_knn_bbox(int P, const float* __restrict__ pts, uint32_t* __restrict__ bbox) 
             mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off, 64));
         }
     }
+    // wave -> workgroup in LDS, then ONE atomic per workgroup and bound (same-address global atomics
+    // serialise at the memory side; the grid of this kernel is kept small for the same reason)
+    __shared__ float smn[3][4], smx[3][4];
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int a = 0; a < 3; ++a) { atomicMin(&bbox[a], f2ord(mn[a])); atomicMax(&bbox[3 + a], f2ord(mx[a])); }
+        for (int a = 0; a < 3; ++a) { smn[a][threadIdx.x >> 6] = mn[a]; smx[a][threadIdx.x >> 6] = mx[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int a = threadIdx.x;
+        float lo = smn[a][0], hi = smx[a][0];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { lo = fminf(lo, smn[a][w]); hi = fmaxf(hi, smx[a][w]); }
+        atomicMin(&bbox[a], f2ord(lo)); atomicMax(&bbox[3 + a], f2ord(hi));
     }
 }
 

@@ -209,7 +209,8 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
                    SplatRec* __restrict__ recs, EmitRec* __restrict__ emit,
                    int32_t* __restrict__ radii, uint32_t* __restrict__ tile_count,
                    unsigned long long* __restrict__ block_stats /*[grid][2]: M_ref, V per workgroup*/,
-                   int hist_in_lds, int sh_direct, int dbg /* timing experiments: 1 no tile loop, 2 no stores, 4 no colour */) {
+                   int hist_in_lds, int sh_direct, int dbg /* timing experiments: 1 no tile loop, 2 no stores, 4 no colour */,
+                   uint8_t* __restrict__ flags8 /* colour-clamp bits for K6: 1 B instead of a 64-B record line */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int nTiles = vc.gx * vc.gy;
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem_raw);
@@ -396,6 +397,7 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
             }
         }
         radii[idx] = radius_out;
+        flags8[idx] = (uint8_t)rec.flags;
         if (dbg & 2) { if (rec.x == 12345.678f) radii[idx] = 7; continue; }
         reinterpret_cast<uint4*>(recs + idx)[0] = reinterpret_cast<uint4*>(&rec)[0];
         reinterpret_cast<uint4*>(recs + idx)[1] = reinterpret_cast<uint4*>(&rec)[1];
@@ -442,7 +444,7 @@ gsr_preprocess_bwd(ViewConst vc, int N, int K,
                    const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
                    const float* __restrict__ scales, const float* __restrict__ rotations,
                    const float* __restrict__ cov3D_precomp, const int32_t* __restrict__ radii,
-                   const SplatRec* __restrict__ recs, const float* __restrict__ g2d,
+                   const uint8_t* __restrict__ flags8, const float* __restrict__ g2d,
                    float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
                    float* __restrict__ dL_dshs, float* __restrict__ dL_dcolors,
                    float* __restrict__ dL_dopac, float* __restrict__ dL_dscales,
@@ -473,7 +475,7 @@ gsr_preprocess_bwd(ViewConst vc, int N, int K,
 
         if (live) {
             const float* g = g2d + (size_t)idx * GSR_G2D_STRIDE;
-            const uint32_t flags = recs[idx].flags;
+            const uint32_t flags = flags8[idx];
             const float mx = means3D[3 * idx], my = means3D[3 * idx + 1], mz = means3D[3 * idx + 2];
             float3 pv;
             pv.x = V[0] * mx + V[4] * my + V[8] * mz + V[12];
