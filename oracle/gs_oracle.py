@@ -37,8 +37,17 @@ import torch
 import time
 
 TIMERS = {"composite_fwd": 0.0, "composite_bwd": 0.0}   # seconds spent compositing (bench.py's cpu_baseline)
-FRAGILE_ALPHA_REL = 2e-5    # |alpha*255 - 1| below this: the alpha >= 1/255 decision is within fp32 noise
-FRAGILE_T_REL = 1e-4        # |T(1-alpha)/1e-4 - 1| below this: the termination decision is within fp32 noise
+# Ambiguity bands of the discrete per-pair decisions. Any fp32 implementation (this one, the CUDA
+# reference) projects the mean to pixels in fp32: an absolute position error of a few ulp of the
+# image size (FRAGILE_PX_PER_PIXEL * max(W,H) pixels; 2e-4 px at 800). Through the exponent's
+# gradient |Sigma'^-1 d| that becomes a RELATIVE alpha error of up to ~2.5e-4 for small splats, on top
+# of the ~1e-6 of exp itself; the transmittance inherits the (partly cancelling) alpha errors of
+# every Gaussian in front. A decision inside its band may legitimately fall either way.
+FRAGILE_ALPHA_REL = 2e-5         # floor of the alpha >= 1/255 band (exp, conic rounding)
+FRAGILE_PX_PER_PIXEL = 2.5e-7    # position uncertainty per pixel of image extent
+FRAGILE_T_REL_AT_800 = 2.5e-4    # T(1-alpha) >= 1e-4 band at an 800-pixel frame (scales with the extent)
+FRAGILE_PX = [2e-4]              # set per render by rasterize()
+FRAGILE_T_REL = [2.5e-4]
 COMPOSITE_INFO = {}
 LAST_FRAGILE = {}           # of the last full forward: "pixels" [H,W] bool, "gaussians" [N] bool         # side channel of composite_tile (last call): fragile pixel / Gaussian masks
 
@@ -267,8 +276,10 @@ def composite_tile(pix, xy, conic, opac, color, depth, bg):
         # decide these differently; the parity tests compare those pixels / Gaussians with the
         # documented relaxed bound instead of the strict one (tests/util.py).
         alive = torch.cat([torch.ones_like(T_after[:1]), T_after[:-1]], 0) >= 1e-4 * (1 - 1e-3)
-        frag = (power <= 1e-6) & ((alpha_raw.clamp_max(0.99) * 255.0 - 1.0).abs() < FRAGILE_ALPHA_REL)
-        frag = frag | (ok & ((T_after * 1e4 - 1.0).abs() < FRAGILE_T_REL)) | (power.abs() < 1e-6)
+        gpow = torch.sqrt((conic[:, 0:1] * dx + conic[:, 1:2] * dy) ** 2 + (conic[:, 2:3] * dy + conic[:, 1:2] * dx) ** 2)
+        band = FRAGILE_ALPHA_REL + gpow * FRAGILE_PX[0]          # relative alpha uncertainty of this pair
+        frag = (power <= 1e-6) & ((alpha_raw.clamp_max(0.99) * 255.0 - 1.0).abs() < band)
+        frag = frag | (ok & ((T_after * 1e4 - 1.0).abs() < FRAGILE_T_REL[0])) | (power.abs() < 1e-6)
         frag = frag & alive
         COMPOSITE_INFO["fragile_pix"] = frag.any(0)
         COMPOSITE_INFO["fragile_gauss"] = frag.any(1)
@@ -364,6 +375,9 @@ def rasterize(means3D, means2D, opacities, S: Settings, shs=None, colors_precomp
     `tiles` (optional list of tile ids) restricts compositing to those 16x16 tiles (all other
     pixels keep the background): bench.py's bounded CPU-baseline sample."""
     assert means3D.device.type == "cpu", "the oracle is a CPU checker"
+    extent = float(max(int(S.image_height), int(S.image_width)))
+    FRAGILE_PX[0] = FRAGILE_PX_PER_PIXEL * extent
+    FRAGILE_T_REL[0] = max(1e-4, FRAGILE_T_REL_AT_800 * extent / 800.0)
     pre = preprocess(means3D, means2D, opacities, shs, colors_precomp, scales, rotations,
                      cov3D_precomp, S)
     ids, ranges, M = build_tile_lists(pre)

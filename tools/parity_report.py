@@ -41,6 +41,10 @@ if __name__ == "__main__":
     oo, og, aux = util.run_oracle(sc, S, w, torch.float64 if a.f64 else torch.float32)
     print(f"oracle ({'f64' if a.f64 else 'f32'}, {torch.get_num_threads()} threads): {time.time() - t0:.0f} s; M {aux['M']} V {aux['V']}; "
           f"fragile pixels {int(aux['fragile_pixels'].sum())}, fragile Gaussians {int(aux['fragile_gaussians'].sum())}")
+    for n, i in (("color", 0), ("alpha", 3)):
+        err = (ho[i].double() - oo[i].double()).abs().amax(0)
+        bad = err > util.FWD_ATOL
+        print(f"  {n}: pixels above {util.FWD_ATOL:g}: {int(bad.sum())} ({int((bad & ~aux['fragile_pixels']).sum())} outside the fragile set)")
     print("radii mismatches:", int((ho[1].long() != oo[1].long()).sum()), "of", a.n)
     fp = aux["fragile_pixels"]
     for n, i in (("color", 0), ("depth", 2), ("alpha", 3)):
