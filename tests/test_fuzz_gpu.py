@@ -50,3 +50,30 @@ def test_fuzz(gpu, seed):
     assert_grads_close(hg, og, aux, floors=grad_floors(sc, og))
     for k in hg:
         assert torch.isfinite(hg[k]).all(), k
+
+
+def test_large_frame_global_histogram_path(gpu):
+    """More than 16384 tiles: the per-tile counters no longer fit the LDS histogram and K1 / K3
+    fall back to global atomics (gsr_api.hip kHistLdsMaxTiles)."""
+    W = H = 2100                                     # 132 x 132 = 17424 tiles
+    sc = O.make_scene(60, 1, 5, "trained")
+    sc["scales"] *= 0.4
+    S = O.make_settings(O.orbit_pose(10.0, 40.0, 3.5), W, H, sh_degree=1)
+    w = weights_for(H, W, seed=2)
+    ho, hg, st = run_hip(sc, S, gpu, w)
+    oo, og, aux = run_oracle(sc, S, w, torch.float64)
+    assert_forward_close(ho, oo, aux)
+    assert_grads_close(hg, og, aux, floors=grad_floors(sc, og))
+
+
+def test_stored_degree_4_coefficients(gpu):
+    """shs with 25 stored coefficients per Gaussian (rows of 75 floats: not 16-byte multiples, the
+    generic staging path) and active degree 3."""
+    sc = O.make_scene(900, 4, 3, "trained")
+    S = O.make_settings(O.orbit_pose(-5.0, -30.0, 2.0), 150, 110, sh_degree=3)
+    w = weights_for(110, 150, seed=4)
+    ho, hg, st = run_hip(sc, S, gpu, w)
+    oo, og, aux = run_oracle(sc, S, w, torch.float64)
+    assert og["shs"][:, 16:].abs().max() == 0 and hg["shs"][:, 16:].abs().max() == 0
+    assert_forward_close(ho, oo, aux)
+    assert_grads_close(hg, og, aux, floors=grad_floors(sc, og))
