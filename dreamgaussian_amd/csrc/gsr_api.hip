@@ -80,19 +80,9 @@ int launch_status(bool debug, hipStream_t stream, const char* name) {
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 struct GeomLayout {
-    size_t recs, emit, flags8, block_stats, block_hist, tile_count, cursor, tile_last, tile_off, tile_seg, tile_order, plan_off, counters, total;
+    size_t recs, emit, flags8, block_stats, tile_count, cursor, tile_last, tile_off, tile_seg, tile_order, plan_off, counters, total;
     int nTiles;
 };
-bool use_sh_stage();
-// K1 and K3 share one workgroup -> Gaussian assignment (K3 consumes K1's per-workgroup histograms)
-int k1_grid_for(int N) {
-    static const int k1_grid = [] { const char* e = getenv("GSR_K1_GRID"); return e ? atoi(e) : 512; }();
-    if (N <= 0) return 0;
-    const int cap = use_sh_stage() ? k1_grid : 2048;
-    const int blocks = (N + 255) / 256;
-    return blocks < cap ? blocks : cap;
-}
-constexpr int kHistLdsMaxTilesDecl = 16384;
 GeomLayout geom_layout(int N, int H, int W) {
     GeomLayout L;
     const int gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE;
@@ -102,8 +92,6 @@ GeomLayout geom_layout(int N, int H, int W) {
     L.emit = o; o += align_up((size_t)N * sizeof(EmitRec));
     L.flags8 = o; o += align_up((size_t)N);
     L.block_stats = o; o += align_up(2048 * 2 * 8);       // K1 grid <= 2048 workgroups
-    L.block_hist = o;                                      // [K1 workgroups][tiles] when the histogram lives in LDS
-    if (L.nTiles <= kHistLdsMaxTilesDecl) o += align_up((size_t)k1_grid_for(N) * L.nTiles * 4);
     L.tile_count = o; o += align_up((size_t)L.nTiles * 4);
     L.cursor = o; o += align_up((size_t)L.nTiles * 4);
     L.tile_last = o; o += align_up((size_t)L.nTiles * 4);
@@ -332,8 +320,8 @@ extern "C" int gsr_forward_begin(const GsrView* view, int32_t N, int32_t K,
     prof_end(stream, "memset_fwd");
 
     const int sh_direct = use_sh_stage() ? 0 : 1;
-    const int grid_pre = k1_grid_for(N);
-    uint32_t* block_hist = hist_in_lds ? (uint32_t*)(gbuf + GL.block_hist) : nullptr;
+    static const int k1_grid = [] { const char* e = getenv("GSR_K1_GRID"); return e ? atoi(e) : 512; }();
+    const int grid_pre = N > 0 ? (int)fmin((double)((N + 255) / 256), sh_direct ? 2048.0 : (double)k1_grid) : 0;
     if (N > 0) {
         const size_t hist_bytes = hist_in_lds ? (((size_t)T * 4 + 15) & ~(size_t)15) : 0;
         const size_t sh_bytes = (shs && K > 1 && !sh_direct) ? (size_t)256 * (3 * K + 1) * 4 : 0;
@@ -343,12 +331,8 @@ extern "C" int gsr_forward_begin(const GsrView* view, int32_t N, int32_t K,
             HIP_TRY(hipFuncSetAttribute((const void*)gsr_preprocess_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         prof_begin(stream); hipLaunchKernelGGL(gsr_preprocess_fwd, dim3(grid_pre), dim3(256), lds, stream, vc, N, K, means3D, shs,
                            colors_precomp, opacities, scales, rotations, cov3D_precomp, recs, emit, radii,
-                           tile_count, (unsigned long long*)(gbuf + GL.block_stats), hist_in_lds, sh_direct, k1_dbg(), (uint8_t*)(gbuf + GL.flags8), block_hist);
+                           tile_count, (unsigned long long*)(gbuf + GL.block_stats), hist_in_lds, sh_direct, k1_dbg(), (uint8_t*)(gbuf + GL.flags8));
         LAUNCH_CHECK(view, stream, "preprocess_fwd");
-        if (block_hist) {   // per-workgroup histograms -> per-workgroup offsets + per-tile totals
-            prof_begin(stream); hipLaunchKernelGGL(gsr_tile_prefix, dim3((T + 31) / 32), dim3(256), 0, stream, block_hist, grid_pre, T, tile_count);
-            LAUNCH_CHECK(view, stream, "tile_prefix");
-        }
     }
     prof_begin(stream); hipLaunchKernelGGL(gsr_tile_scan, dim3(1), dim3(1024), 0, stream, tile_count, tile_off, T, counters, tile_seg, seg_shift(),
                        (const unsigned long long*)(gbuf + GL.block_stats), N > 0 ? grid_pre : 0);
@@ -411,10 +395,8 @@ extern "C" int gsr_forward_finish(const GsrView* view, int32_t N, int32_t K,
         const size_t lds = hist_in_lds ? (size_t)T * 4 : 0;
         if (lds > 48 * 1024)
             HIP_TRY(hipFuncSetAttribute((const void*)gsr_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        // same grid as K1: workgroup b scatters exactly the Gaussians whose histogram it wrote
-        const uint32_t* block_hist = hist_in_lds ? (const uint32_t*)(gbuf + GL.block_hist) : nullptr;
-        prof_begin(stream); hipLaunchKernelGGL(gsr_scatter, dim3(block_hist ? k1_grid_for(N) : grid_n), dim3(256), lds, stream, N, emit, tile_off, cursor, entries,
-                           vc.gx, T, hist_in_lds, (uint32_t)M, block_hist);
+        prof_begin(stream); hipLaunchKernelGGL(gsr_scatter, dim3(grid_n), dim3(256), lds, stream, N, emit, tile_off, cursor, entries,
+                           vc.gx, T, hist_in_lds, (uint32_t)M);
         LAUNCH_CHECK(view, stream, "scatter");
         // per-tile sort, size classes by list length
         SplatRec* out_recs = copy ? srecs : nullptr;

@@ -80,51 +80,16 @@ gsr_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ ti
 }
 
 // ---------------------------------------------------------------------------------------
-// K2a: per-tile exclusive prefix over K1's per-workgroup histograms. In place:
-// block_hist[b][t] becomes the offset of workgroup b inside tile t's segment; tile_count[t] the total.
-// 256 threads = 32 tiles x 8 chunks of workgroups (two passes over the chunk: sum, then prefix).
-// ---------------------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(256)
-gsr_tile_prefix(uint32_t* __restrict__ block_hist, int nblocks, int T, uint32_t* __restrict__ tile_count) {
-    __shared__ uint32_t sums[8][32];
-    const int tl = threadIdx.x & 31, ch = threadIdx.x >> 5;
-    const int t = blockIdx.x * 32 + tl;
-    const int per = (nblocks + 7) / 8;
-    const int b0 = min(ch * per, nblocks), b1 = min(b0 + per, nblocks);
-    uint32_t s = 0;
-    if (t < T) for (int b = b0; b < b1; ++b) s += block_hist[(size_t)b * T + t];
-    sums[ch][tl] = s;
-    __syncthreads();
-    uint32_t run = 0;
-    for (int c = 0; c < ch; ++c) run += sums[c][tl];
-    if (t < T) {
-        for (int b = b0; b < b1; ++b) {
-            uint32_t* p = block_hist + (size_t)b * T + t;
-            const uint32_t v = *p;
-            *p = run;
-            run += v;
-        }
-        if (ch == 7) tile_count[t] = run;
-    }
-}
-
-// ---------------------------------------------------------------------------------------
 // K3: scatter (depth bits, id) keys into the tile segments.
 // dynamic LDS: nTiles uint32 when hist_in_lds.
 // ---------------------------------------------------------------------------------------
 extern "C" __global__ void __launch_bounds__(256)
 gsr_scatter(int N, const EmitRec* __restrict__ emit, const uint32_t* __restrict__ tile_off,
             uint32_t* __restrict__ cursor, unsigned long long* __restrict__ entries,
-            int gx, int nTiles, int hist_in_lds, uint32_t capacity,
-            const uint32_t* __restrict__ block_hist /* per-workgroup offsets from gsr_tile_prefix, or NULL */) {
+            int gx, int nTiles, int hist_in_lds, uint32_t capacity) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem_raw);
-    if (hist_in_lds && block_hist) {
-        // same workgroup -> Gaussian assignment as K1: the write cursors are the prefix table
-        const uint32_t* mine = block_hist + (size_t)blockIdx.x * nTiles;
-        for (int t = threadIdx.x; t < nTiles; t += blockDim.x) hist[t] = tile_off[t] + mine[t];
-        __syncthreads();
-    } else if (hist_in_lds) {
+    if (hist_in_lds) {
         for (int t = threadIdx.x; t < nTiles; t += blockDim.x) hist[t] = 0;
         __syncthreads();
         for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < N; idx += gridDim.x * blockDim.x) {
@@ -137,7 +102,7 @@ gsr_scatter(int N, const EmitRec* __restrict__ emit, const uint32_t* __restrict_
                     if (!masked || (em.w & bit)) atomicAdd(&hist[ty * gx + tx], 1u);
         }
         __syncthreads();
-        const int t0 = (int)((blockIdx.x * 67u) % (unsigned)nTiles);   // staggered start
+        const int t0 = (int)((blockIdx.x * 67u) % (unsigned)nTiles);   // staggered: see K1's flush
         for (int i = threadIdx.x; i < nTiles; i += blockDim.x) {
             int t = t0 + i; if (t >= nTiles) t -= nTiles;
             const uint32_t c = hist[t];

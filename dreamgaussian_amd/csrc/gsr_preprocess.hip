@@ -210,8 +210,7 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
                    int32_t* __restrict__ radii, uint32_t* __restrict__ tile_count,
                    unsigned long long* __restrict__ block_stats /*[grid][2]: M_ref, V per workgroup*/,
                    int hist_in_lds, int sh_direct, int dbg /* timing experiments: 1 no tile loop, 2 no stores, 4 no colour */,
-                   uint8_t* __restrict__ flags8 /* colour-clamp bits for K6: 1 B instead of a 64-B record line */,
-                   uint32_t* __restrict__ block_hist /* [grid][nTiles] when hist_in_lds */) {
+                   uint8_t* __restrict__ flags8 /* colour-clamp bits for K6: 1 B instead of a 64-B record line */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int nTiles = vc.gx * vc.gy;
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem_raw);
@@ -424,11 +423,13 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
         block_stats[2 * blockIdx.x + threadIdx.x] = sum;
     }
     if (hist_in_lds) {
-        // this workgroup's tile histogram goes out as plain coalesced stores; gsr_tile_prefix turns
-        // the [workgroup][tile] table into per-workgroup write offsets for K3 (no atomics: 512
-        // workgroups adding into the same 2500 counters serialised at the memory side)
-        uint32_t* mine = block_hist + (size_t)blockIdx.x * nTiles;
-        for (int t = threadIdx.x; t < nTiles; t += blockDim.x) mine[t] = hist[t];
+        // every workgroup starts its flush at a different tile: no burst of atomics on one address
+        const int t0 = (int)((blockIdx.x * 67u) % (unsigned)nTiles);
+        for (int i = threadIdx.x; i < nTiles; i += blockDim.x) {
+            int t = t0 + i; if (t >= nTiles) t -= nTiles;
+            const uint32_t c = hist[t];
+            if (c) atomicAdd(&tile_count[t], c);
+        }
     }
 }
 
