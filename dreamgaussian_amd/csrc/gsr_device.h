@@ -149,14 +149,6 @@ __device__ __forceinline__ float row_sum16(float v) {
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_ROW_ROR(1), 0xf, 0xf, false));
     return v;
 }
-// three of the four steps: afterwards even lanes of a row hold the sum of its even lanes, odd lanes
-// the sum of its odd lanes (the two halves are added by the LDS atomic they both feed)
-__device__ __forceinline__ float row_sum16_halves(float v) {
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_ROW_ROR(8), 0xf, 0xf, false));
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_ROW_ROR(4), 0xf, 0xf, false));
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_ROW_ROR(2), 0xf, 0xf, false));
-    return v;
-}
 // number of set bits of `mask` below this lane
 __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));

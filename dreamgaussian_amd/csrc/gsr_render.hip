@@ -281,7 +281,6 @@ gsr_render_fwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict
                 rc.z = __uint_as_float(i - start + 1);    // 1-based list position replaces the box
                 sa[pos] = ra; sb[pos] = rb; sc[pos] = rc;
             }
-            if (lane == 0) { sa[n] = make_float4(0.f, 0.f, 0.f, 0.f); sb[n] = sa[n]; }   // odd tail: opacity 0 never blends
             wave_lds_handoff();
             float4 e0a = sa[0], e0b = sb[0], e0c = sc[0];
             // two entries per trip, both unconditional (the second is masked off on an odd tail) so
@@ -290,7 +289,7 @@ gsr_render_fwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict
                 const float4 e1a = sa[j + 1], e1b = sb[j + 1], e1c = sc[j + 1];   // in flight during entry j
                 GSR_FWD_ENTRY(e0a, e0b, e0c, true)
                 e0a = sa[j + 2]; e0b = sb[j + 2]; e0c = sc[j + 2];               // in flight during entry j+1
-                GSR_FWD_ENTRY(e1a, e1b, e1c, true)
+                GSR_FWD_ENTRY(e1a, e1b, e1c, j + 1 < n)
                 if constexpr (SCHED) {   // pin the interleave: reads j+1 | math j | reads j+2 | math j+1
                     __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
                     __builtin_amdgcn_sched_group_barrier(0x002, 22, 0);
@@ -551,11 +550,10 @@ gsr_render_bwd_f2b(const uint32_t* __restrict__ tile_off, const SplatRec* __rest
     const uint32_t slot1 = tag16(tag32(2u, 7u), tag32(3u, 8u));
     const uint32_t slot2 = tag16(tag32(4u, 9u), tag32(10u, 11u));   // 10, 11: padding slots (zeros)
     const bool row_leader = (lane & 15) == 0;
-    // LDS path: lanes {0,1}, {2,3}, {4,5} of every 16-lane row carry the even/odd half sums of
-    // t0, t1, t2 -> one ds_add for all ten sums (the last reduction step happens in the LDS adder)
+    // LDS path: lanes 0,1,2 of every 16-lane row carry t0,t1,t2 -> one ds_add for all ten sums
     const uint32_t l15 = (uint32_t)lane & 15u;
-    const uint32_t myslot = l15 < 2u ? slot0 : (l15 < 4u ? slot1 : slot2);
-    const bool lds_lane = (l15 < 6u) && (myslot < 10u);
+    const uint32_t myslot = l15 == 0u ? slot0 : (l15 == 1u ? slot1 : slot2);
+    const bool lds_lane = (l15 < 3u) && (myslot < 10u);
 
     // ea = x y qa qb | eb = qc opac r g | ec = b depth pos - | ed = id - - -
 #define GSR_F2B_ENTRY(ea, eb, ec, ed, valid)                                                     \
@@ -597,14 +595,11 @@ gsr_render_bwd_f2b(const uint32_t* __restrict__ tile_off, const SplatRec* __rest
             }                                                                                    \
             const float v6 = w * gC0, v7 = w * gC1, v8 = w * gC2;  /* dL/drgb */                 \
             const float v9 = w * gD;                               /* dL/ddepth */               \
-            const float r0 = red16(red32(v0, v5), red32(v1, v6));                                \
-            const float r1 = red16(red32(v2, v7), red32(v3, v8));                                \
-            const float r2 = red16(red32(v4, v9), 0.f);                                          \
-            const float t0 = ACC_LDS ? row_sum16_halves(r0) : row_sum16(r0);                     \
-            const float t1 = ACC_LDS ? row_sum16_halves(r1) : row_sum16(r1);                     \
-            const float t2 = ACC_LDS ? row_sum16_halves(r2) : row_sum16(r2);                     \
+            const float t0 = row_sum16(red16(red32(v0, v5), red32(v1, v6)));                     \
+            const float t1 = row_sum16(red16(red32(v2, v7), red32(v3, v8)));                     \
+            const float t2 = row_sum16(red16(red32(v4, v9), 0.f));                               \
             if (acc_lds) {                                                                       \
-                const float tv = l15 < 2u ? t0 : (l15 < 4u ? t1 : t2);                            \
+                const float tv = l15 == 0u ? t0 : (l15 == 1u ? t1 : t2);                          \
                 if (lds_lane) atomicAdd(&acc[(kpos - 1u - seg_lo) * GSR_G2D_STRIDE + myslot], tv); \
             } else if (row_leader) {                                                             \
                 const uint32_t gid = __builtin_amdgcn_readfirstlane(__float_as_uint(ed.x));      \
@@ -643,14 +638,13 @@ gsr_render_bwd_f2b(const uint32_t* __restrict__ tile_off, const SplatRec* __rest
                 rc.z = __uint_as_float(i + 1u);           // 1-based list position
                 sa[pos] = ra; sb[pos] = rb; sc[pos] = rc; sd[pos] = rd;
             }
-            if (lane == 0) sc[cnt] = make_float4(0.f, 0.f, __uint_as_float(0xffffffffu), 0.f);   // odd tail: position beyond every n_contrib
             wave_lds_handoff();
             float4 e0a = sa[0], e0b = sb[0], e0c = sc[0], e0d = sd[0];
             for (int j = 0; j < cnt; j += 2) {            // slots cnt, cnt+1 are padding: read, never used
                 const float4 e1a = sa[j + 1], e1b = sb[j + 1], e1c = sc[j + 1], e1d = sd[j + 1];
                 GSR_F2B_ENTRY(e0a, e0b, e0c, e0d, true)
                 e0a = sa[j + 2]; e0b = sb[j + 2]; e0c = sc[j + 2]; e0d = sd[j + 2];
-                GSR_F2B_ENTRY(e1a, e1b, e1c, e1d, true)
+                GSR_F2B_ENTRY(e1a, e1b, e1c, e1d, j + 1 < cnt)
             }
             wave_lds_handoff();
         }
