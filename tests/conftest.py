@@ -13,6 +13,11 @@ def pytest_configure(config):
     import torch
     # the GPU box has 256 host cores; torch's CPU ops (the oracle) crawl with that many threads
     torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    # the tests load the in-tree HIP library; (re)build it when it is missing or older than its
+    # sources (hipcc cross-compiles gfx950 without a GPU, ~10 s). The product itself never builds
+    # on import: it fails loudly when libgsr.so is absent.
+    from dreamgaussian_amd import build as _build
+    _build.build(verbose=False)
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` on the GPU box)")
 
 
