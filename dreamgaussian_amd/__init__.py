@@ -5,9 +5,9 @@ Public surface (mirrors what gs_renderer.py imports, gs_renderer.py:10-14):
     distCUDA2                                           (package `simple_knn._C`)
 """
 from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer,
-                         rasterize_gaussians, last_stats)
+                         rasterize_gaussians, rasterize_gaussians_raw, last_stats)
 from .knn import distCUDA2
 from .batched import rasterize_views
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians",
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_gaussians_raw",
            "last_stats", "distCUDA2", "rasterize_views"]

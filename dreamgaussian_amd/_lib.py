@@ -23,7 +23,8 @@ class GsrView(C.Structure):
                 ("scale_modifier", C.c_float), ("sh_degree", C.c_int32),
                 ("prefiltered", C.c_int32), ("debug", C.c_int32),
                 ("bg", C.c_void_p), ("viewmatrix", C.c_void_p),
-                ("projmatrix", C.c_void_p), ("campos", C.c_void_p)]
+                ("projmatrix", C.c_void_p), ("campos", C.c_void_p),
+                ("raw_activations", C.c_int32), ("reserved", C.c_int32)]
 
 
 RESIZE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)

@@ -128,6 +128,7 @@ ViewConst make_view(const GsrView* v) {
     c.tanfovx = v->tanfovx; c.tanfovy = v->tanfovy;
     c.focal_x = c.W / (2.0f * v->tanfovx); c.focal_y = c.H / (2.0f * v->tanfovy);
     c.scale_modifier = v->scale_modifier; c.sh_degree = v->sh_degree;
+    c.raw_act = v->raw_activations != 0;
     c.bg = v->bg; c.view = v->viewmatrix; c.proj = v->projmatrix; c.campos = v->campos;
     return c;
 }
@@ -327,9 +328,10 @@ extern "C" int gsr_forward_begin(const GsrView* view, int32_t N, int32_t K,
         const size_t sh_bytes = (shs && K > 1 && !sh_direct) ? (size_t)256 * (3 * K + 1) * 4 : 0;
         const size_t lds = hist_bytes + sh_bytes;
         if (lds > 160 * 1024) return fail(-1, "preprocess needs more than 160 KiB of LDS%s", "");
+        auto k1 = vc.raw_act ? gsr_preprocess_fwd<true> : gsr_preprocess_fwd<false>;
         if (lds > 48 * 1024)
-            HIP_TRY(hipFuncSetAttribute((const void*)gsr_preprocess_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        prof_begin(stream); hipLaunchKernelGGL(gsr_preprocess_fwd, dim3(grid_pre), dim3(256), lds, stream, vc, N, K, means3D, shs,
+            HIP_TRY(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        prof_begin(stream); hipLaunchKernelGGL(k1, dim3(grid_pre), dim3(256), lds, stream, vc, N, K, means3D, shs,
                            colors_precomp, opacities, scales, rotations, cov3D_precomp, recs, emit, radii,
                            tile_count, (unsigned long long*)(gbuf + GL.block_stats), hist_in_lds, sh_direct, k1_dbg(), (uint8_t*)(gbuf + GL.flags8));
         LAUNCH_CHECK(view, stream, "preprocess_fwd");
@@ -571,12 +573,21 @@ extern "C" int gsr_backward(const GsrView* view, int32_t N, int32_t K,
     const int grid_n = (int)fmin((double)((N + 255) / 256), 2048.0);
     const size_t lds = (shs && K > 1) ? (size_t)256 * (3 * K + 1) * 4 : 0;
     if (lds > 160 * 1024) return fail(-1, "preprocess_bwd needs more than 160 KiB of LDS%s", "");
-    if (lds > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void*)gsr_preprocess_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    prof_begin(stream); hipLaunchKernelGGL(gsr_preprocess_bwd, dim3(grid_n), dim3(256), lds, stream, vc, N, K, means3D, shs,
-                       colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, (const uint8_t*)(gbuf + GL.flags8), g2d,
-                       dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacities, dL_dscales,
-                       dL_drotations, dL_dcov3D);
+    if (lds > 48 * 1024) {
+        HIP_TRY(hipFuncSetAttribute((const void*)gsr_preprocess_bwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)gsr_preprocess_bwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    prof_begin(stream);
+    if (vc.raw_act)
+        hipLaunchKernelGGL(gsr_preprocess_bwd<true>, dim3(grid_n), dim3(256), lds, stream, vc, N, K, means3D, shs,
+                           colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, (const uint8_t*)(gbuf + GL.flags8), g2d,
+                           dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacities, dL_dscales,
+                           dL_drotations, dL_dcov3D);
+    else
+        hipLaunchKernelGGL(gsr_preprocess_bwd<false>, dim3(grid_n), dim3(256), lds, stream, vc, N, K, means3D, shs,
+                           colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, (const uint8_t*)(gbuf + GL.flags8), g2d,
+                           dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacities, dL_dscales,
+                           dL_drotations, dL_dcov3D);
     LAUNCH_CHECK(view, stream, "preprocess_bwd");
     return 0;
 }

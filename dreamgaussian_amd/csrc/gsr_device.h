@@ -55,6 +55,7 @@ struct ViewConst {           // by-value kernel argument (scalar registers)
     float tanfovx, tanfovy, focal_x, focal_y;
     float scale_modifier;
     int sh_degree;
+    int raw_act;             // inputs are the raw parameters: opacity = sigmoid, scale = exp, rotation = normalise here
     const float* bg;
     const float* view;
     const float* proj;

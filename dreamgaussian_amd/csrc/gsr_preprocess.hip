@@ -28,6 +28,14 @@ __device__ __forceinline__ float view_depth(const float* __restrict__ V, float x
     return __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(V[2], x), __fmul_rn(V[6], y)), __fmul_rn(V[10], z)), V[14]);
 }
 
+// DreamGaussian's parameter activations (gs_renderer.py:134-142), fused when ViewConst.raw_act
+__device__ __forceinline__ float act_sigmoid(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float4 act_normalize(float4 q, float* inv_norm) {
+    const float inv = 1.f / sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    *inv_norm = inv;
+    return make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
+}
+
 struct Cov3 { float c0, c1, c2, c3, c4, c5; };   // S00 S01 S02 S11 S12 S22
 
 __device__ __forceinline__ void quat_to_R(const float4 q, float R[9]) {
@@ -200,7 +208,8 @@ __device__ __forceinline__ void stage_rows_out(float* __restrict__ dst, const fl
 // K1: preprocess forward.  grid-stride over batches of blockDim.x Gaussians.
 // dynamic LDS: [hist: nTilesLds ints][sh stage: blockDim.x * (3K+1) floats if shs]
 // ---------------------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(256)
+template <bool RAW>      // RAW: the inputs are DreamGaussian's raw parameters, activations fused (ViewConst.raw_act)
+__global__ void __launch_bounds__(256)
 gsr_preprocess_fwd(ViewConst vc, int N, int K,
                    const float* __restrict__ means3D, const float* __restrict__ shs,
                    const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
@@ -211,10 +220,10 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
                    unsigned long long* __restrict__ block_stats /*[grid][2]: M_ref, V per workgroup*/,
                    int hist_in_lds, int sh_direct, int dbg /* timing experiments: 1 no tile loop, 2 no stores, 4 no colour */,
                    uint8_t* __restrict__ flags8 /* colour-clamp bits for K6: 1 B instead of a 64-B record line */) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_pp[];
     const int nTiles = vc.gx * vc.gy;
-    uint32_t* hist = reinterpret_cast<uint32_t*>(smem_raw);
-    float* shbuf = reinterpret_cast<float*>(smem_raw + (hist_in_lds ? ((nTiles * 4 + 15) & ~15) : 0));
+    uint32_t* hist = reinterpret_cast<uint32_t*>(smem_pp);
+    float* shbuf = reinterpret_cast<float*>(smem_pp + (hist_in_lds ? ((nTiles * 4 + 15) & ~15) : 0));
     const int rowlen = 3 * K;
     // sh_direct: every lane reads its own SH row with 16-byte loads (no LDS transpose): LDS then
     // only holds the tile histogram and ~4x more waves fit on a CU -- the kernel is latency-bound
@@ -275,11 +284,11 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
                 const float* c = cov3D_precomp + 6 * (size_t)idx;
                 S.c0 = c[0]; S.c1 = c[1]; S.c2 = c[2]; S.c3 = c[3]; S.c4 = c[4]; S.c5 = c[5];
             } else {
-                const float4 q = reinterpret_cast<const float4*>(rotations)[idx];
+                float4 q = reinterpret_cast<const float4*>(rotations)[idx];
                 float3 s;
-                s.x = vc.scale_modifier * scales[3 * idx];
-                s.y = vc.scale_modifier * scales[3 * idx + 1];
-                s.z = vc.scale_modifier * scales[3 * idx + 2];
+                s.x = scales[3 * idx]; s.y = scales[3 * idx + 1]; s.z = scales[3 * idx + 2];
+                if (RAW) { float inv; q = act_normalize(q, &inv); s.x = __expf(s.x); s.y = __expf(s.y); s.z = __expf(s.z); }
+                s.x *= vc.scale_modifier; s.y *= vc.scale_modifier; s.z *= vc.scale_modifier;
                 float R[9];
                 quat_to_R(q, R);
                 S = cov3d_from_scale_rot(s, R);
@@ -341,7 +350,7 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
                         if (cg < 0.f) { flags |= 2u; cg = 0.f; }
                         if (cb < 0.f) { flags |= 4u; cb = 0.f; }
                     }
-                    const float op = opacities[idx];
+                    const float op = RAW ? act_sigmoid(opacities[idx]) : opacities[idx];
                     rec.x = px; rec.y = py;
                     rec.qa = -0.5f * cA * GSR_LOG2E; rec.qb = -cB * GSR_LOG2E; rec.qc = -0.5f * cC * GSR_LOG2E;
                     rec.opac = op; rec.r = cr; rec.g = cg; rec.b = cb; rec.depth = pv.z;
@@ -438,7 +447,8 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
 // forward intermediates from the inputs instead of re-reading saved state.
 // dynamic LDS: blockDim.x * (3K+1) floats when shs (used for SH in, then dSH out).
 // ---------------------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(256)
+template <bool RAW>   // RAW: inputs are the raw parameters (fused sigmoid / exp / normalise backward)
+__global__ void __launch_bounds__(256)
 gsr_preprocess_bwd(ViewConst vc, int N, int K,
                    const float* __restrict__ means3D, const float* __restrict__ shs,
                    const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
@@ -449,8 +459,8 @@ gsr_preprocess_bwd(ViewConst vc, int N, int K,
                    float* __restrict__ dL_dshs, float* __restrict__ dL_dcolors,
                    float* __restrict__ dL_dopac, float* __restrict__ dL_dscales,
                    float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float* shbuf = reinterpret_cast<float*>(smem_raw);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_pp[];
+    float* shbuf = reinterpret_cast<float*>(smem_pp);
     const int rowlen = 3 * K;
     const bool use_sh = (shs != nullptr);
     const bool stage = use_sh && (K > 1);
@@ -499,6 +509,7 @@ gsr_preprocess_bwd(ViewConst vc, int N, int K,
             dm[0] += V[2] * gdepth; dm[1] += V[6] * gdepth; dm[2] += V[10] * gdepth;
             // ---- opacity ----------------------------------------------------------------
             dop = g[5];
+            if (RAW) { const float o = act_sigmoid(opacities[idx]); dop *= o * (1.f - o); }   // d sigmoid
 
             // ---- colour -----------------------------------------------------------------
             float gr = g[6], gg = g[7], gb = g[8];
@@ -564,14 +575,17 @@ gsr_preprocess_bwd(ViewConst vc, int N, int K,
             float R[9];
             float3 s = make_float3(0.f, 0.f, 0.f);
             float4 q = make_float4(1.f, 0.f, 0.f, 0.f);
+            float3 s_act = make_float3(1.f, 1.f, 1.f);
+            float q_inv_norm = 1.f;
             if (cov3D_precomp) {
                 const float* c = cov3D_precomp + 6 * (size_t)idx;
                 S.c0 = c[0]; S.c1 = c[1]; S.c2 = c[2]; S.c3 = c[3]; S.c4 = c[4]; S.c5 = c[5];
             } else {
                 q = reinterpret_cast<const float4*>(rotations)[idx];
-                s.x = vc.scale_modifier * scales[3 * idx];
-                s.y = vc.scale_modifier * scales[3 * idx + 1];
-                s.z = vc.scale_modifier * scales[3 * idx + 2];
+                s.x = scales[3 * idx]; s.y = scales[3 * idx + 1]; s.z = scales[3 * idx + 2];
+                if (RAW) { q = act_normalize(q, &q_inv_norm); s.x = __expf(s.x); s.y = __expf(s.y); s.z = __expf(s.z); }
+                s_act = s;
+                s.x *= vc.scale_modifier; s.y *= vc.scale_modifier; s.z *= vc.scale_modifier;
                 quat_to_R(q, R);
                 S = cov3d_from_scale_rot(s, R);
             }
@@ -618,6 +632,12 @@ gsr_preprocess_bwd(ViewConst vc, int N, int K,
                 dq[1] = 2.f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.f * x * dR[8]);
                 dq[2] = 2.f * (-2.f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.f * y * dR[8]);
                 dq[3] = 2.f * (-2.f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
+                if (RAW) {                              // d exp and d normalise
+                    dsc[0] *= s_act.x; dsc[1] *= s_act.y; dsc[2] *= s_act.z;
+                    const float qd = q.x * dq[0] + q.y * dq[1] + q.z * dq[2] + q.w * dq[3];
+                    dq[0] = (dq[0] - q.x * qd) * q_inv_norm; dq[1] = (dq[1] - q.y * qd) * q_inv_norm;
+                    dq[2] = (dq[2] - q.z * qd) * q_inv_norm; dq[3] = (dq[3] - q.w * qd) * q_inv_norm;
+                }
             }
             // dL/dT rows: dT0 = 2 dLa Sigma T0 + dLb Sigma T1 ; dT1 = 2 dLc Sigma T1 + dLb Sigma T0
             const float u0 = S.c0 * T0[0] + S.c1 * T0[1] + S.c2 * T0[2];
@@ -666,6 +686,9 @@ gsr_preprocess_bwd(ViewConst vc, int N, int K,
         }
     }
 }
+
+template __global__ void gsr_preprocess_bwd<false>(ViewConst, int, int, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const int32_t*, const uint8_t*, const float*, float*, float*, float*, float*, float*, float*, float*, float*);
+template __global__ void gsr_preprocess_bwd<true>(ViewConst, int, int, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const int32_t*, const uint8_t*, const float*, float*, float*, float*, float*, float*, float*, float*, float*);
 
 // visible[i] = view-space z > 0.2  (frustum rule of A.3)
 extern "C" __global__ void __launch_bounds__(256)

@@ -53,7 +53,7 @@ def _f32c(t: Optional[torch.Tensor], device) -> Optional[torch.Tensor]:
     return t.detach().to(torch.float32).contiguous()
 
 
-def _view_struct(rs: GaussianRasterizationSettings, device):
+def _view_struct(rs: GaussianRasterizationSettings, device, raw: bool = False):
     keep = [torch.as_tensor(x).to(device=device, dtype=torch.float32).contiguous().reshape(-1)
             for x in (rs.bg, rs.viewmatrix, rs.projmatrix, rs.campos)]
     if keep[0].numel() != 3 or keep[1].numel() != 16 or keep[2].numel() != 16 or keep[3].numel() != 3:
@@ -61,7 +61,8 @@ def _view_struct(rs: GaussianRasterizationSettings, device):
     v = _lib.GsrView(int(rs.image_height), int(rs.image_width), float(rs.tanfovx),
                      float(rs.tanfovy), float(rs.scale_modifier), int(rs.sh_degree),
                      int(bool(rs.prefiltered)), int(bool(rs.debug)),
-                     keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(), keep[3].data_ptr())
+                     keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(), keep[3].data_ptr(),
+                     1 if raw else 0, 0)
     return v, keep
 
 
@@ -75,8 +76,9 @@ def _require_gpu(t: torch.Tensor):
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                cov3Ds_precomp, raster_settings):
+                cov3Ds_precomp, raster_settings, raw=False):
         _require_gpu(means3D)
+        ctx.raw = bool(raw)
         lib = _lib.load()
         dev = means3D.device
         rs = raster_settings
@@ -102,7 +104,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         geom, binb, img = _lib.Scratch(dev), _lib.Scratch(dev), _lib.Scratch(dev)
         stats = _lib.GsrStats()
         with torch.cuda.device(dev):
-            view, keep = _view_struct(rs, dev)
+            view, keep = _view_struct(rs, dev, ctx.raw)
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             rc = lib.gsr_forward(C.byref(view), N, K, _lib.ptr(m3), _lib.ptr(shc), _lib.ptr(col),
                                  _lib.ptr(op), _lib.ptr(sc), _lib.ptr(rot), _lib.ptr(cov),
@@ -153,7 +155,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         if N > 0:
             tmp = _lib.Scratch(dev)
             with torch.cuda.device(dev):
-                view, keep = _view_struct(rs, dev)
+                view, keep = _view_struct(rs, dev, ctx.raw)
                 stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
                 P = _lib.ptr
                 rc = lib.gsr_backward(
@@ -168,13 +170,23 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs_ = lambda g, shape: None if g is None or shape is None else g.reshape(shape)
         return (rs_(d_m3, s[0]), rs_(d_m2, s[1]) if tuple(s[1]) == (N, 3) else None, rs_(d_sh, s[2]),
                 rs_(d_col, s[3]), rs_(d_op, s[4]), rs_(d_sc, s[5]), rs_(d_rot, s[6]), rs_(d_cov, s[7]),
-                None)
+                None, None)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                         cov3Ds_precomp, raster_settings):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales,
                                      rotations, cov3Ds_precomp, raster_settings)
+
+
+def rasterize_gaussians_raw(means3D, means2D, sh, opacity_raw, scaling_raw, rotation_raw, raster_settings):
+    """Opt-in entry beside the drop-in one: takes DreamGaussian's RAW parameters
+    (`_opacity`, `_scaling`, `_rotation`, gs_renderer.py:144-160) and runs sigmoid / exp / normalise
+    (gs_renderer.py:134-142, 196-216) and their backward inside the per-Gaussian kernels -- five
+    elementwise launches and their five backward launches per render disappear. Same outputs as
+    `rasterize_gaussians(means3D, means2D, sh, None, sigmoid(o), exp(s), normalize(q), None, settings)`."""
+    return _RasterizeGaussians.apply(means3D, means2D, sh, None, opacity_raw, scaling_raw, rotation_raw,
+                                     None, raster_settings, True)
 
 
 class GaussianRasterizer(nn.Module):

@@ -49,6 +49,10 @@ typedef struct GsrView {
     const float* viewmatrix; /* [16] device */
     const float* projmatrix; /* [16] device */
     const float* campos;     /* [3]  device */
+    int32_t raw_activations; /* !=0: `opacities`, `scales`, `rotations` are DreamGaussian's RAW parameters
+                              * (_opacity, _scaling, _rotation): sigmoid / exp / normalise (gs_renderer.py:134-142,
+                              * 196-216) and their backward run inside the per-Gaussian kernels */
+    int32_t reserved;
 } GsrView;
 
 /* Scratch allocator: resize(ctx, bytes) must return a device pointer, 256-byte aligned, to

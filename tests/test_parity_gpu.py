@@ -205,3 +205,37 @@ def test_gradient_holder_protocol(gpu):
     vis = radii > 0
     assert ssp.grad is not None and ssp.grad.shape == (800, 3)
     assert ssp.grad[vis, :2].norm(dim=-1).sum() > 0 and (ssp.grad[:, 2] == 0).all()
+
+
+def test_fused_raw_activations(gpu):
+    """rasterize_gaussians_raw (raw _opacity/_scaling/_rotation in, sigmoid/exp/normalise and their
+    backward inside K1/K6) against torch's activations + autograd around the fp64 oracle."""
+    N, deg, W, H = 1800, 2, 144, 112
+    base = O.make_scene(N, deg, 11, "trained")
+    g = torch.Generator().manual_seed(3)
+    raw = dict(means3D=base["means3D"], shs=base["shs"],
+               opacity=torch.logit(base["opacities"].clamp(0.02, 0.98)),
+               scaling=torch.log(base["scales"]),
+               rotation=base["rotations"] * (0.5 + torch.rand(N, 1, generator=g) * 2.0))    # un-normalised
+    S = O.make_settings(O.orbit_pose(-12.0, 55.0, 2.0), W, H, sh_degree=deg, scale_modifier=0.8)
+    w = weights_for(H, W, seed=6)
+    # HIP, fused
+    t = {k: v.to(gpu).requires_grad_(True) for k, v in raw.items()}
+    m2d = torch.zeros(N, 3, device=gpu, requires_grad=True)
+    c, r, d, a = D.rasterize_gaussians_raw(t["means3D"], m2d, t["shs"], t["opacity"], t["scaling"], t["rotation"], settings_to(S, gpu))
+    torch.autograd.backward([c, d, a], [x.to(gpu) for x in w])
+    hg = {k: v.grad.cpu() for k, v in t.items()}
+    hg["means2D"] = m2d.grad.cpu()
+    # oracle: torch activations (gs_renderer.py:134-142) + autograd
+    o = {k: v.double().requires_grad_(True) for k, v in raw.items()}
+    om2d = torch.zeros(N, 3, dtype=torch.float64, requires_grad=True)
+    S64 = O.Settings(*[x.double() if torch.is_tensor(x) else x for x in S])
+    oc, orr, od, oa, aux = O.rasterize(o["means3D"], om2d, torch.sigmoid(o["opacity"]), S64, shs=o["shs"],
+                                       scales=torch.exp(o["scaling"]),
+                                       rotations=torch.nn.functional.normalize(o["rotation"]), return_aux=True)
+    torch.autograd.backward([oc, od, oa], [x.double() for x in w])
+    og = {k: v.grad for k, v in o.items()}
+    og["means2D"] = om2d.grad
+    assert_forward_close([c.detach().cpu(), r.cpu(), d.detach().cpu(), a.detach().cpu()], [oc.detach(), orr, od.detach(), oa.detach()], aux)
+    floors = {"rotation": (og["scaling"].abs().max()).item()}
+    assert_grads_close(hg, og, aux, floors=floors)
