@@ -3,11 +3,14 @@
 Public surface (mirrors what gs_renderer.py imports, gs_renderer.py:10-14):
     GaussianRasterizationSettings, GaussianRasterizer   (package `diff_gaussian_rasterization`)
     distCUDA2                                           (package `simple_knn._C`)
+Beside the drop-in names: rasterize_views (several cameras in flight), rasterize_gaussians_raw
+(fused activations), extract_fields (GaussianModel.extract_fields, gs_renderer.py:218-294).
 """
 from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer,
                          rasterize_gaussians, rasterize_gaussians_raw, last_stats)
 from .knn import distCUDA2
 from .batched import rasterize_views
+from .fields import extract_fields
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_gaussians_raw",
-           "last_stats", "distCUDA2", "rasterize_views"]
+           "last_stats", "distCUDA2", "rasterize_views", "extract_fields"]

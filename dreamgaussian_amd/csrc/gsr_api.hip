@@ -7,6 +7,7 @@
 #include "gsr_binning.hip"
 #include "gsr_render.hip"
 #include "gsr_knn.hip"
+#include "gsr_fields.hip"
 
 #include <stdio.h>
 #include <string.h>
@@ -601,6 +602,44 @@ extern "C" int gsr_mark_visible(const GsrView* view, int32_t N, const float* mea
     if (!means3D || !visible) return fail(-1, "means3D and visible are required%s", "");
     prof_begin(stream); hipLaunchKernelGGL(gsr_mark_visible_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, view->viewmatrix, N, means3D, visible);
     LAUNCH_CHECK(view, stream, "mark_visible");
+    return 0;
+}
+
+extern "C" int gsr_extract_fields(int32_t N, const float* xyz, const float* opacity, const float* scaling,
+                                  const float* rotation_raw, int32_t resolution, int32_t split_size,
+                                  int32_t num_chunks, const float* axis, const float* box_lo, const float* box_hi,
+                                  float* occ, float* norm_out, GsrAlloc tmp, gsr_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N <= 0) return fail(-1, "extract_fields needs at least one Gaussian%s", "");
+    if (!xyz || !opacity || !scaling || !rotation_raw) return fail(-1, "xyz, opacity, scaling and rotation_raw are required%s", "");
+    if (!axis || !box_lo || !box_hi || !occ || !norm_out) return fail(-1, "axis, box_lo, box_hi, occ and norm_out are required%s", "");
+    if (resolution < 1 || resolution > 1024) return fail(-1, "resolution must be in [1, 1024]%s", "");
+    if (split_size < 1 || num_chunks < 1 || num_chunks > 255 ||
+        (long long)split_size * num_chunks < resolution || (long long)split_size * (num_chunks - 1) >= resolution)
+        return fail(-1, "num_chunks must equal ceil(resolution / split_size) and be <= 255%s", "");
+    if (!tmp.resize) return fail(-1, "tmp allocator is required%s", "");
+    size_t o = 0;
+    const size_t o_bbox = o; o += align_up(6 * 4);
+    const size_t o_rec = o; o += align_up((size_t)N * sizeof(FieldRec));
+    const size_t o_rng = o; o += align_up((size_t)N * sizeof(uint2));
+    char* buf = (char*)tmp.resize(tmp.ctx, o);
+    if (!buf) return fail(-4, "tmp scratch allocation failed%s", "");
+    uint32_t* bbox = (uint32_t*)(buf + o_bbox);
+    FieldRec* recs = (FieldRec*)(buf + o_rec);
+    uint2* range = (uint2*)(buf + o_rng);
+    HIP_TRY(hipMemsetAsync(bbox, 0xff, 3 * 4, stream));
+    HIP_TRY(hipMemsetAsync(bbox + 3, 0, 3 * 4, stream));
+    GsrView dbg; memset(&dbg, 0, sizeof(dbg));
+    const int grid_n = (N + 255) / 256;
+    prof_begin(stream); hipLaunchKernelGGL(gsr_fields_bbox, dim3(grid_n < 256 ? grid_n : 256), dim3(256), 0, stream, N, xyz, opacity, bbox);
+    LAUNCH_CHECK(&dbg, stream, "fields_bbox");
+    prof_begin(stream); hipLaunchKernelGGL(gsr_fields_prep, dim3(grid_n), dim3(256), 0, stream, N, xyz, opacity, scaling, rotation_raw,
+                       bbox, num_chunks, box_lo, box_hi, recs, range, norm_out);
+    LAUNCH_CHECK(&dbg, stream, "fields_prep");
+    const int slots = split_size * split_size * ((split_size + 3) / 4);    // rows of 4 z-consecutive samples
+    prof_begin(stream); hipLaunchKernelGGL(gsr_fields_accumulate, dim3(num_chunks * num_chunks * num_chunks, (slots + 127) / 128), dim3(256), 0, stream,
+                       N, recs, range, resolution, num_chunks, split_size, axis, occ);
+    LAUNCH_CHECK(&dbg, stream, "fields_accumulate");
     return 0;
 }
 

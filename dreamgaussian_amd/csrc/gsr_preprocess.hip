@@ -24,8 +24,11 @@ constexpr float SH_C3_0 = -0.5900435899266435f, SH_C3_1 = 2.890611442640554f,
 
 // View-space depth in ONE pinned fp32 evaluation order (no fma contraction): it is the sort
 // key of the compositing order, so the oracle evaluates exactly this chain.
+// (HIP's __fmul_rn/__fadd_rn are plain * and + and DO contract to v_fma under hipcc's default
+// -ffp-contract=fast-honor-pragmas; the pragma is what pins the order.)
 __device__ __forceinline__ float view_depth(const float* __restrict__ V, float x, float y, float z) {
-    return __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(V[2], x), __fmul_rn(V[6], y)), __fmul_rn(V[10], z)), V[14]);
+#pragma clang fp contract(off)
+    return ((V[2] * x + V[6] * y) + V[10] * z) + V[14];
 }
 
 // DreamGaussian's parameter activations (gs_renderer.py:134-142), fused when ViewConst.raw_act

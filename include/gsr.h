@@ -137,6 +137,25 @@ int gsr_mark_visible(const GsrView* view, int32_t N, const float* means3D,
  * as in simple_knn.cu:142-182). points [P,3], out [P]. No host synchronisation. */
 int gsr_dist2(int32_t P, const float* points, float* out, GsrAlloc tmp, gsr_stream_t stream);
 
+/* Density grid of the Gaussians: GaussianModel.extract_fields (gs_renderer.py:218-294) with
+ * gaussian_3d_coeff (gs_renderer.py:64-83).
+ *   xyz [N,3], opacity [N] (activated), scaling [N,3] (activated), rotation_raw [N,4] (the raw
+ *   `_rotation`; it is normalised inside, gs_renderer.py:86-88) -- what the reference reads.
+ *   axis [resolution]     the grid coordinates: torch.linspace(-1, 1, resolution)   (:251)
+ *   split_size            samples per chunk and axis: resolution // num_blocks      (:224)
+ *   num_chunks            chunks per axis: ceil(resolution / split_size)  (<= 255)
+ *   box_lo/hi [num_chunks] chunk bounds grown by block_size * relax_ratio           (:259-262)
+ *   occ [resolution^3]    out, x-major (occ[ix][iy][iz], :286-288); every element is written
+ *   norm_out [4]          out: center.xyz and the extent max(mx - mn) of the kept means; the
+ *                         reference's `self.center`, and `self.scale` = 1.8 / extent (:237-240)
+ * All pointers are device pointers. Gaussians with opacity <= 0.005 are ignored (:230); at least
+ * one must remain (the reference fails on an empty reduction there; the caller checks).
+ * No host synchronisation. */
+int gsr_extract_fields(int32_t N, const float* xyz, const float* opacity, const float* scaling,
+                       const float* rotation_raw, int32_t resolution, int32_t split_size,
+                       int32_t num_chunks, const float* axis, const float* box_lo, const float* box_hi,
+                       float* occ, float* norm_out, GsrAlloc tmp, gsr_stream_t stream);
+
 /* Bytes of scratch the forward will request for geom / img (bin is data dependent). */
 size_t gsr_geom_bytes(int32_t N, int32_t image_height, int32_t image_width);
 size_t gsr_img_bytes(int32_t image_height, int32_t image_width);

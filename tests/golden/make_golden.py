@@ -5,6 +5,10 @@ and gs_renderer.py (with stub modules for its unrelated, uninstalled imports and
 mapped to the CPU) -- and records the outputs of the in-tree twins of the rasterizer's
 per-Gaussian math and of the camera/settings assembly. These pin the oracle's conventions.
 
+Part 3 (reference_fields.npz) runs the reference's OWN `GaussianModel.extract_fields`
+(gs_renderer.py:218-294, unmodified, on the CPU) on small seeded scenes: the density grids the
+HIP `extract_fields` and its oracle are pinned to.
+
 Part 2 (oracle_render_small.npz) is NOT reference output: it is our float64 oracle's render
 + gradients of a small scene, committed so that the GPU tests also compare the HIP path with
 a fixed vector (the reference ships no rasterizer source, tests or golden data: SURVEY 0.1/0.3).
@@ -31,6 +35,7 @@ def import_reference():
     sys.modules["plyfile"].PlyData = sys.modules["plyfile"].PlyElement = object
     sys.modules["mesh"].Mesh = object
     sys.modules["mesh_utils"].decimate_mesh = sys.modules["mesh_utils"].clean_mesh = None
+    sys.modules["kiui"].lo = lambda *a, **k: None
     torch.Tensor.cuda = lambda self, *a, **k: self
     _zeros = torch.zeros
 
@@ -95,6 +100,7 @@ def part1():
     out["cam_getProjectionMatrix"] = np.stack(Ps)
     np.savez_compressed(os.path.join(HERE, "reference_twins.npz"), **out)
     print("wrote reference_twins.npz:", sorted(out))
+    return gsr
 
 
 def part2():
@@ -121,6 +127,60 @@ def part2():
     print("wrote oracle_render_small.npz")
 
 
+def fields_scene(N, seed):
+    """Raw GaussianModel parameters (what the reference stores): anisotropic, randomly rotated,
+    un-normalised quaternions, 6% of the opacities below the 0.005 pre-filter."""
+    from dreamgaussian_amd import synthetic
+    sc = synthetic.make_scene(N, 0, seed, "trained")
+    rs = np.random.RandomState(seed + 100)
+    op = sc["opacities"].numpy().copy()
+    low = rs.rand(N) < 0.06
+    op[low, 0] = rs.uniform(1e-4, 0.0099, int(low.sum()))
+    q = sc["rotations"].numpy() * rs.uniform(0.4, 2.5, (N, 1))
+    return dict(xyz=sc["means3D"].numpy().astype(np.float32),
+                opacity_raw=np.log(op / (1 - op)).astype(np.float32),
+                scaling_raw=np.log(sc["scales"].numpy()).astype(np.float32),
+                rotation_raw=q.astype(np.float32))
+
+
+def part3(gsr):
+    import time
+    out = {}
+    cases = [("r32", 700, 5, 32, 16, 1.5), ("r64", 3000, 6, 64, 16, 1.5), ("r48nb8", 1500, 7, 48, 8, 1.0),
+             ("r128", 6000, 8, 128, 16, 1.5)]
+    out["cases"] = np.array([c[0] for c in cases])
+    for name, N, seed, R, nb, relax in cases:
+        raw = fields_scene(N, seed)
+        gm = gsr.GaussianModel(0)
+        gm._xyz = torch.from_numpy(raw["xyz"])
+        gm._opacity = torch.from_numpy(raw["opacity_raw"])
+        gm._scaling = torch.from_numpy(raw["scaling_raw"])
+        gm._rotation = torch.from_numpy(raw["rotation_raw"])
+        t0 = time.time()
+        occ = gm.extract_fields(resolution=R, num_blocks=nb, relax_ratio=relax)
+        dt = time.time() - t0
+        # the exact fp32 activated tensors the reference fed its field evaluation
+        out[f"{name}_xyz"] = raw["xyz"]
+        out[f"{name}_opacity"] = gm.get_opacity.numpy()
+        out[f"{name}_scaling"] = gm.get_scaling.numpy()
+        out[f"{name}_rotation_raw"] = raw["rotation_raw"]
+        out[f"{name}_params"] = np.array([R, nb, relax], dtype=np.float64)
+        out[f"{name}_center"] = gm.center.numpy()
+        out[f"{name}_scale"] = np.float64(gm.scale)
+        o = occ.numpy()
+        if R <= 64:
+            out[f"{name}_occ"] = o
+        else:                        # 8 MB: keep a strided sample and slab sums instead
+            out[f"{name}_occ_stride3"] = o[::3, ::3, ::3].copy()
+            out[f"{name}_occ_slab_sums"] = o.astype(np.float64).sum(axis=(1, 2))
+            out[f"{name}_occ_max"] = np.float64(o.max())
+        print(f"  {name}: N={N} R={R} nb={nb} relax={relax}  {dt:.1f}s  max={o.max():.4f} nonzero={np.count_nonzero(o) / o.size:.3f}")
+    np.savez_compressed(os.path.join(HERE, "reference_fields.npz"), **out)
+    print("wrote reference_fields.npz")
+
+
 if __name__ == "__main__":
-    part2()      # before part1: part1 monkey-patches torch
-    part1()
+    if "--fields-only" not in sys.argv:
+        part2()      # before part1: part1 monkey-patches torch
+    gsr = part1() if "--fields-only" not in sys.argv else import_reference()[2]
+    part3(gsr)
