@@ -142,6 +142,7 @@ gsr_fields_prep(int N, const float* __restrict__ xyz, const float* __restrict__ 
 // Rounds of FLD_SCAN block ranges are tested, members appended IN INDEX ORDER to an LDS ring;
 // whenever FLD_EVAL members are waiting their records are gathered into LDS once (broadcast reads).
 constexpr int FLD_PZ = 4;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 extern "C" __global__ void __launch_bounds__(256)
 gsr_fields_accumulate(int N, const FieldRec* __restrict__ recs, const uint2* __restrict__ range,
@@ -162,10 +163,9 @@ gsr_fields_accumulate(int N, const FieldRec* __restrict__ recs, const uint2* __r
 
     const int slot = blockIdx.y * 128 + ht;
     const bool has_slot = slot < nslots;
-    float px = 0.f, py = 0.f, pz[FLD_PZ], acc[FLD_PZ];
+    float px = 0.f, py = 0.f, pz[FLD_PZ] = {0.f, 0.f, 0.f, 0.f};
+    f32x2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
     int out_base = 0, nz = 0;
-#pragma unroll
-    for (int k = 0; k < FLD_PZ; ++k) { pz[k] = 0.f; acc[k] = 0.f; }
     if (has_slot) {
         const int row = slot / segs, seg = slot - row * segs, ix = row / ly, iy = row - ix * ly;
         px = axis[x0 + ix]; py = axis[y0 + iy];
@@ -174,6 +174,7 @@ gsr_fields_accumulate(int N, const FieldRec* __restrict__ recs, const uint2* __r
         for (int k = 0; k < FLD_PZ; ++k) if (k < nz) pz[k] = axis[z0 + seg * FLD_PZ + k];
         out_base = ((x0 + ix) * R + (y0 + iy)) * R + z0 + seg * FLD_PZ;
     }
+    const f32x2 pz01 = {pz[0], pz[1]}, pz23 = {pz[2], pz[3]};
     const bool wave_has_slots = (int)blockIdx.y * 128 + (wave & 1) * 64 < nslots;   // wave-uniform
 
     uint32_t head = 0, count = 0;                           // ring state, identical in every thread
@@ -226,25 +227,31 @@ gsr_fields_accumulate(int N, const FieldRec* __restrict__ recs, const uint2* __r
                 // full batches hold FLD_EVAL (even) members: half h owns the members of parity h of the block's list
                 for (uint32_t j = (uint32_t)half; j < n; j += 2) {
                     const float4 a = stage[3 * j], b = stage[3 * j + 1], c = stage[3 * j + 2];
-                    float sxy, xyb, dx, dy;
+                    f32x2 p01, p23;
                     {   // -0.5 (x^2 ia + y^2 id + z^2 if) - x y ib - x z ic - y z ie with the reference's roundings
-                        // (gs_renderer.py:79); the -0.5 is folded into b.xyz, exact because it is a power of two
+                        // (gs_renderer.py:79); the -0.5 is folded into b.xyz, exact because it is a power of two.
+                        // Two z-neighbours per packed instruction (v_pk_mul_f32 / v_pk_add_f32 round per element).
 #pragma clang fp contract(off)
-                        dx = px - a.x; dy = py - a.y;
-                        sxy = dx * dx * b.x + dy * dy * b.y;
-                        xyb = dx * dy * b.w;
+                        const float dx = px - a.x, dy = py - a.y;
+                        const float sxy = dx * dx * b.x + dy * dy * b.y;
+                        const float xyb = dx * dy * b.w;
+                        const f32x2 dz01 = pz01 - a.z, dz23 = pz23 - a.z;
+                        p01 = (((sxy + dz01 * dz01 * b.z) - xyb) - dx * dz01 * c.x) - dy * dz01 * c.y;
+                        p23 = (((sxy + dz23 * dz23 * b.z) - xyb) - dx * dz23 * c.x) - dy * dz23 * c.y;
                     }
-#pragma unroll
-                    for (int k = 0; k < FLD_PZ; ++k) {
-                        float power;
-                        {
-#pragma clang fp contract(off)
-                            const float dz = pz[k] - a.z;
-                            power = (((sxy + dz * dz * b.z) - xyb) - dx * dz * c.x) - dy * dz * c.y;
-                        }
-                        const float w = power > 0.f ? 0.f : __expf(power);   // NaN stays NaN, as in the reference
-                        acc[k] = fmaf(a.w, w, acc[k]);
+                    const f32x2 e01 = p01 * 1.44269504088896341f, e23 = p23 * 1.44269504088896341f;
+                    f32x2 w01, w23;
+                    w01.x = __builtin_amdgcn_exp2f(e01.x); w01.y = __builtin_amdgcn_exp2f(e01.y);
+                    w23.x = __builtin_amdgcn_exp2f(e23.x); w23.y = __builtin_amdgcn_exp2f(e23.y);
+                    // `power > 0 -> weight 0` (gs_renderer.py:81): abnormal and rare, so one test per four points
+                    if (fmaxf(fmaxf(p01.x, p01.y), fmaxf(p23.x, p23.y)) > 0.f) {
+                        if (p01.x > 0.f) w01.x = 0.f;
+                        if (p01.y > 0.f) w01.y = 0.f;
+                        if (p23.x > 0.f) w23.x = 0.f;
+                        if (p23.y > 0.f) w23.y = 0.f;
                     }
+                    acc01 = __builtin_elementwise_fma(f32x2{a.w, a.w}, w01, acc01);
+                    acc23 = __builtin_elementwise_fma(f32x2{a.w, a.w}, w23, acc23);
                 }
             }
             head += n;
@@ -253,11 +260,11 @@ gsr_fields_accumulate(int N, const FieldRec* __restrict__ recs, const uint2* __r
     }
     // half 1 hands its partial sums to half 0
     __syncthreads();
-    if (half == 1) stage[ht] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    if (half == 1) stage[ht] = make_float4(acc01.x, acc01.y, acc23.x, acc23.y);
     __syncthreads();
     if (half == 0 && has_slot) {
         const float4 o = stage[ht];
-        const float v[FLD_PZ] = {acc[0] + o.x, acc[1] + o.y, acc[2] + o.z, acc[3] + o.w};
+        const float v[FLD_PZ] = {acc01.x + o.x, acc01.y + o.y, acc23.x + o.z, acc23.y + o.w};
 #pragma unroll
         for (int k = 0; k < FLD_PZ; ++k) if (k < nz) occ[out_base + k] = v[k];
     }

@@ -45,6 +45,17 @@ def test_c_argument_errors_without_gpu():
     assert lib.gsr_dist2(-1, None, None, _lib.GsrAlloc(), None) == -1
     assert lib.gsr_dist2(0, None, None, _lib.GsrAlloc(), None) == 0
     assert lib.gsr_profile_read(0, None, None, None) == 0
+    a = _lib.GsrAlloc()
+    assert lib.gsr_extract_fields(0, *([None] * 4), 128, 8, 16, *([None] * 5), a, None) == -1
+    assert b"at least one Gaussian" in lib.gsr_last_error()
+    assert lib.gsr_extract_fields(5, *([None] * 4), 128, 8, 16, *([None] * 5), a, None) == -1     # NULL inputs
+    assert b"required" in lib.gsr_last_error()
+
+
+def test_extract_fields_host_errors_without_gpu():
+    import dreamgaussian_amd as D
+    with pytest.raises(RuntimeError, match="GPU only"):
+        D.extract_fields(torch.zeros(4, 3), torch.ones(4, 1), torch.ones(4, 3), torch.ones(4, 4))
 
 
 def test_dropin_package_names():
