@@ -11,6 +11,7 @@ from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer,
 from .knn import distCUDA2
 from .batched import rasterize_views
 from .fields import extract_fields
+from .densify import add_densification_stats
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_gaussians_raw",
-           "last_stats", "distCUDA2", "rasterize_views", "extract_fields"]
+           "last_stats", "distCUDA2", "rasterize_views", "extract_fields", "add_densification_stats"]

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GSR_LIB=<path> loads another build of the same ABI (A/B measurements of two source revisions)
 LIB_PATH = os.environ.get("GSR_LIB") or os.path.join(_HERE, "libgsr.so")
 
-EXPORTS = ("gsr_forward", "gsr_forward_begin", "gsr_forward_finish", "gsr_backward", "gsr_mark_visible", "gsr_dist2", "gsr_extract_fields",
+EXPORTS = ("gsr_forward", "gsr_forward_begin", "gsr_forward_finish", "gsr_backward", "gsr_mark_visible", "gsr_dist2", "gsr_extract_fields", "gsr_densify_stats",
            "gsr_profile_enable", "gsr_profile_read", "gsr_profile_reset",
            "gsr_geom_bytes", "gsr_img_bytes", "gsr_last_error", "gsr_version")
 
@@ -74,6 +74,8 @@ def load() -> C.CDLL:
         lib.gsr_mark_visible.argtypes = [C.POINTER(GsrView), i32, p, p, vp]
         lib.gsr_dist2.restype = C.c_int
         lib.gsr_dist2.argtypes = [i32, p, p, GsrAlloc, vp]
+        lib.gsr_densify_stats.restype = C.c_int
+        lib.gsr_densify_stats.argtypes = [i32, p, p, p, p, p, vp]
         lib.gsr_extract_fields.restype = C.c_int
         lib.gsr_extract_fields.argtypes = [i32, p, p, p, p, i32, i32, i32, p, p, p, p, p, GsrAlloc, vp]
         lib.gsr_geom_bytes.restype = C.c_size_t

@@ -8,6 +8,7 @@
 #include "gsr_render.hip"
 #include "gsr_knn.hip"
 #include "gsr_fields.hip"
+#include "gsr_densify.hip"
 
 #include <stdio.h>
 #include <string.h>
@@ -640,6 +641,20 @@ extern "C" int gsr_extract_fields(int32_t N, const float* xyz, const float* opac
     prof_begin(stream); hipLaunchKernelGGL(gsr_fields_accumulate, dim3(num_chunks * num_chunks * num_chunks, (slots + 127) / 128), dim3(256), 0, stream,
                        N, recs, range, resolution, num_chunks, split_size, axis, occ);
     LAUNCH_CHECK(&dbg, stream, "fields_accumulate");
+    return 0;
+}
+
+extern "C" int gsr_densify_stats(int32_t N, const float* grad_means2D, const int32_t* radii,
+                                 float* xyz_gradient_accum, float* denom, float* max_radii2D, gsr_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N < 0) return fail(-1, "N must be >= 0%s", "");
+    if (N == 0) return 0;
+    if (!grad_means2D || !radii || !xyz_gradient_accum || !denom || !max_radii2D)
+        return fail(-1, "grad_means2D, radii, xyz_gradient_accum, denom and max_radii2D are required%s", "");
+    GsrView dbg; memset(&dbg, 0, sizeof(dbg));
+    prof_begin(stream); hipLaunchKernelGGL(gsr_densify_stats_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, N, grad_means2D, radii,
+                       xyz_gradient_accum, denom, max_radii2D);
+    LAUNCH_CHECK(&dbg, stream, "densify_stats");
     return 0;
 }
 

@@ -156,6 +156,16 @@ int gsr_extract_fields(int32_t N, const float* xyz, const float* opacity, const 
                        int32_t num_chunks, const float* axis, const float* box_lo, const float* box_hi,
                        float* occ, float* norm_out, GsrAlloc tmp, gsr_stream_t stream);
 
+/* Per-step densification bookkeeping (main.py:279-281 + GaussianModel.add_densification_stats,
+ * gs_renderer.py:625-627), in place, for every Gaussian with radii[i] > 0:
+ *   max_radii2D[i] = max(max_radii2D[i], radii[i]);
+ *   xyz_gradient_accum[i] += |grad_means2D[i, 0:2]|;   denom[i] += 1.
+ * grad_means2D [N,3] is the gradient the backward left in the means2D holder; radii [N] int32 the
+ * forward's output; the three accumulators are [N] float32 (the reference's [N,1] / [N]).
+ * One launch, no host synchronisation. */
+int gsr_densify_stats(int32_t N, const float* grad_means2D, const int32_t* radii,
+                      float* xyz_gradient_accum, float* denom, float* max_radii2D, gsr_stream_t stream);
+
 /* Bytes of scratch the forward will request for geom / img (bin is data dependent). */
 size_t gsr_geom_bytes(int32_t N, int32_t image_height, int32_t image_width);
 size_t gsr_img_bytes(int32_t image_height, int32_t image_width);

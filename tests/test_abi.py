@@ -45,6 +45,8 @@ def test_c_argument_errors_without_gpu():
     assert lib.gsr_dist2(-1, None, None, _lib.GsrAlloc(), None) == -1
     assert lib.gsr_dist2(0, None, None, _lib.GsrAlloc(), None) == 0
     assert lib.gsr_profile_read(0, None, None, None) == 0
+    assert lib.gsr_densify_stats(0, None, None, None, None, None, None) == 0
+    assert lib.gsr_densify_stats(3, None, None, None, None, None, None) == -1
     a = _lib.GsrAlloc()
     assert lib.gsr_extract_fields(0, *([None] * 4), 128, 8, 16, *([None] * 5), a, None) == -1
     assert b"at least one Gaussian" in lib.gsr_last_error()
