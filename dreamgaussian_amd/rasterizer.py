@@ -50,7 +50,10 @@ def _f32c(t: Optional[torch.Tensor], device) -> Optional[torch.Tensor]:
         return None
     if t.device != device:
         raise RuntimeError(f"all rasterizer inputs must be on {device}, got {t.device}")
-    return t.detach().to(torch.float32).contiguous()
+    t = t.detach()
+    if t.dtype is torch.float32 and t.is_contiguous():
+        return t
+    return t.to(torch.float32).contiguous()
 
 
 def _view_struct(rs: GaussianRasterizationSettings, device, raw: bool = False):
@@ -116,6 +119,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         _last_stats.update(M=stats.num_instances, M_ref=stats.num_instances_ref,
                            V=stats.num_visible, max_tile=stats.max_tile_count, N=N, H=H, W=W, K=K)
         ctx.raster_settings = rs
+        ctx.view = (view, keep)            # the backward reuses the struct (and keeps its device constants alive)
         ctx.dims = (N, K)
         ctx.fwd_stats = stats
         ctx.present = (shc is not None, col is not None, sc is not None, cov is not None)
@@ -145,17 +149,25 @@ class _RasterizeGaussians(torch.autograd.Function):
                               else g.to(torch.float32).contiguous())
         gc, gd, ga = z(grad_color, (3, H, W)), z(grad_depth, (1, H, W)), z(grad_alpha, (1, H, W))
         # K6 writes every element of every gradient (exact zeros for culled Gaussians): no memset
-        f = lambda *s: (torch.empty if N > 0 else torch.zeros)(*s, dtype=torch.float32, device=dev)
-        d_m3, d_m2, d_op = f(N, 3), f(N, 3), f(N, 1)
-        d_sh = f(N, K, 3) if has_sh else None
-        d_col = f(N, 3) if has_col else None
-        d_sc = f(N, 3) if has_sr else None
-        d_rot = f(N, 4) if has_sr else None
-        d_cov = f(N, 6) if has_cov else None
+        # one allocation for all gradients, each carved out at a 256-byte boundary
+        widths = [3, 3, 1, 3 * K if has_sh else 0, 3 if has_col else 0, 3 if has_sr else 0, 4 if has_sr else 0,
+                  6 if has_cov else 0]
+        offs, total = [], 0
+        for w_ in widths:
+            offs.append(total)
+            total += (N * w_ + 63) & ~63
+        flat = (torch.empty if N > 0 else torch.zeros)(max(total, 1), dtype=torch.float32, device=dev)
+        part = lambda i, *shape: flat[offs[i]:offs[i] + N * widths[i]].view(*shape)
+        d_m3, d_m2, d_op = part(0, N, 3), part(1, N, 3), part(2, N, 1)
+        d_sh = part(3, N, K, 3) if has_sh else None
+        d_col = part(4, N, 3) if has_col else None
+        d_sc = part(5, N, 3) if has_sr else None
+        d_rot = part(6, N, 4) if has_sr else None
+        d_cov = part(7, N, 6) if has_cov else None
         if N > 0:
             tmp = _lib.Scratch(dev)
             with torch.cuda.device(dev):
-                view, keep = _view_struct(rs, dev, ctx.raw)
+                view, keep = ctx.view
                 stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
                 P = _lib.ptr
                 rc = lib.gsr_backward(

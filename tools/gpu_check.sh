@@ -1,6 +1,6 @@
 #!/bin/bash
 # One gpurun call; sections chosen by arguments (default: all). Outputs -> gpurun_out/.
-#   tests smoke bench benchall prof pmc
+#   tests smoke bench benchall prof pmc fields views ab
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 SECTIONS="${@:-tests smoke bench benchall prof}"
@@ -24,6 +24,24 @@ prof)
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_1M -o r01 -- python $R/bench.py --steps 5 --warmup 2 --cpu-budget 0 --no-roofline > $R/gpurun_out/prof_1M.log 2>&1)
   tail -2 gpurun_out/prof_1M.log; find gpurun_out/prof_1M -name "*stats*" | head
   f=$(find gpurun_out/prof_1M -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -12 "$f";;
+fields)
+  echo "== extract_fields bench + kernel trace"
+  timeout 200 python tools/fields_bench.py 2> gpurun_out/fields_bench.err | tee gpurun_out/fields_bench.jsonl
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_fields -o r01 -- python $R/tools/fields_bench.py --sizes 100000 --reps 5 > $R/gpurun_out/prof_fields.log 2>&1)
+  f=$(find gpurun_out/prof_fields -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -6 "$f"
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS --output-format csv -d $R/gpurun_out/pmc_fields -o r01 -- python $R/tools/fields_bench.py --sizes 100000 --reps 2 > $R/gpurun_out/pmc_fields.log 2>&1)
+  f=$(find gpurun_out/pmc_fields -name "*counter_collection.csv" | head -1); [ -n "$f" ] && python - "$f" <<'PY'
+import csv, sys, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
+for r in csv.DictReader(open(sys.argv[1])):
+    k = r["Kernel_Name"]
+    if "fields" not in k: continue
+    acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+for k, c in acc.items():
+    print(k, {a: round(b) for a, b in c.items()})
+    if c.get("SQ_BUSY_CYCLES"): print("   VALU busy share of SQ busy cycles:", round(c.get("SQ_ACTIVE_INST_VALU", 0) / c["SQ_BUSY_CYCLES"] , 3))
+PY
+  ;;
 ab)
   # A/B of the env-selectable variants: parity suite + 1M bench for each
   for v in ${AB_VARIANTS:-"GSR_DEFAULT=1" "GSR_BWD=b2f" "GSR_RECORDS=copy"}; do
