@@ -21,6 +21,8 @@ namespace {
 
 thread_local char g_err[512] = "";
 thread_local unsigned long long* g_pinned = nullptr;   // 8 x u64 host-pinned scratch
+thread_local hipEvent_t g_copied_own = nullptr;        // this thread's "counters copied" event (gsr_forward)
+thread_local hipEvent_t g_copied = nullptr;            // set while gsr_forward drives gsr_forward_begin
 
 int fail(int code, const char* fmt, const char* a = "", long long b = 0) {
     snprintf(g_err, sizeof(g_err), fmt, a, b);
@@ -341,12 +343,14 @@ extern "C" int gsr_forward_begin(const GsrView* view, int32_t N, int32_t K,
     prof_begin(stream); hipLaunchKernelGGL(gsr_tile_scan, dim3(1), dim3(1024), 0, stream, tile_count, tile_off, T, counters, tile_seg, seg_shift(),
                        (const unsigned long long*)(gbuf + GL.block_stats), N > 0 ? grid_pre : 0);
     LAUNCH_CHECK(view, stream, "tile_scan");
+    // the counters leave first: gsr_forward waits for THIS copy only (g_copied), so the launch-order
+    // kernel below runs while the host wakes up and allocates the bin scratch
+    HIP_TRY(hipMemcpyAsync(host_counters, counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    if (g_copied) HIP_TRY(hipEventRecord(g_copied, stream));
     if (!use_tile_order_off()) {                          // heaviest tiles first
         prof_begin(stream); hipLaunchKernelGGL(gsr_tile_order, dim3(1), dim3(1024), 0, stream, tile_count, T, counters, tile_order);
         LAUNCH_CHECK(view, stream, "tile_order");
     }
-
-    HIP_TRY(hipMemcpyAsync(host_counters, counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
     return 0;
 }
 
@@ -478,9 +482,14 @@ extern "C" int gsr_forward(const GsrView* view, int32_t N, int32_t K,
     Capture cg{geom, nullptr}, ci{img, nullptr};
     auto tramp = [](void* ctx, size_t bytes) -> void* { Capture* c = (Capture*)ctx; c->ptr = c->inner.resize(c->inner.ctx, bytes); return c->ptr; };
     GsrAlloc ag{&cg, tramp}, ai{&ci, tramp};
-    if (int rc = gsr_forward_begin(view, N, K, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                                   radii, ag, ai, (uint64_t*)g_pinned, stream_)) return rc;
-    HIP_TRY(hipStreamSynchronize((hipStream_t)stream_));
+    if (!g_copied_own) HIP_TRY(hipEventCreateWithFlags(&g_copied_own, hipEventDisableTiming));
+    hipEvent_t ev = g_copied_own;
+    g_copied = ev;                                        // gsr_forward_begin records it right after the counter copy
+    const int rc_begin = gsr_forward_begin(view, N, K, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                           radii, ag, ai, (uint64_t*)g_pinned, stream_);
+    g_copied = nullptr;
+    if (rc_begin) return rc_begin;
+    HIP_TRY(hipEventSynchronize(ev));
     return gsr_forward_finish(view, N, K, out_color, out_depth, out_alpha, cg.ptr, ci.ptr, bin, (const uint64_t*)g_pinned, stats, stream_);
 }
 
