@@ -21,6 +21,7 @@ namespace {
 
 thread_local char g_err[512] = "";
 thread_local unsigned long long* g_pinned = nullptr;   // 8 x u64 host-pinned scratch
+thread_local size_t g_bin_hint = 0;                    // bin scratch of this thread's previous gsr_forward + 25%
 thread_local hipEvent_t g_copied_own = nullptr;        // this thread's "counters copied" event (gsr_forward)
 thread_local hipEvent_t g_copied = nullptr;            // set while gsr_forward drives gsr_forward_begin
 
@@ -489,8 +490,24 @@ extern "C" int gsr_forward(const GsrView* view, int32_t N, int32_t K,
                                            radii, ag, ai, (uint64_t*)g_pinned, stream_);
     g_copied = nullptr;
     if (rc_begin) return rc_begin;
+    // While the per-Gaussian stage runs: ask for the bin scratch with last call's size + 25% (the host is
+    // about to wait anyway); the real request after the round trip is served from it when it fits.
+    struct BinPre { GsrAlloc inner; void* pre; size_t cap; };
+    BinPre bp{bin, nullptr, 0};
+    if (g_bin_hint) { bp.pre = bin.resize(bin.ctx, g_bin_hint); bp.cap = bp.pre ? g_bin_hint : 0; }
+    auto bin_tramp = [](void* ctx, size_t bytes) -> void* {
+        BinPre* b = (BinPre*)ctx;
+        return (b->pre && bytes <= b->cap) ? b->pre : b->inner.resize(b->inner.ctx, bytes);
+    };
     HIP_TRY(hipEventSynchronize(ev));
-    return gsr_forward_finish(view, N, K, out_color, out_depth, out_alpha, cg.ptr, ci.ptr, bin, (const uint64_t*)g_pinned, stats, stream_);
+    const int rc = gsr_forward_finish(view, N, K, out_color, out_depth, out_alpha, cg.ptr, ci.ptr, GsrAlloc{&bp, bin_tramp},
+                                      (const uint64_t*)g_pinned, stats, stream_);
+    if (rc == 0) {
+        const ViewConst vc = make_view(view);
+        const size_t need = bin_layout((size_t)g_pinned[2], use_record_copy(), geom_layout(N, vc.H, vc.W).nTiles).total;
+        g_bin_hint = need + need / 4;
+    }
+    return rc;
 }
 
 extern "C" int gsr_backward(const GsrView* view, int32_t N, int32_t K,
