@@ -114,3 +114,25 @@ def test_reference_argument_errors_come_from_this_repository(reference):
     z = torch.zeros(3, 3)
     with pytest.raises(Exception, match="excatly one of either SHs or precomputed colors"):
         rast(means3D=z, means2D=z, opacities=torch.ones(3, 1), scales=torch.ones(3, 3), rotations=torch.ones(3, 4))
+
+
+def test_python_side_covariance_and_colour_paths_agree(reference):
+    """`render(compute_cov3D_python=True, convert_SHs_python=True)` (gs_renderer.py:762-797) hands the
+    rasterizer `cov3D_precomp` / `colors_precomp` computed by the reference's own Python twins; the image
+    must equal the default path's (scales/rotations/SHs evaluated inside the rasterizer)."""
+    gs_renderer, cam_utils, calls = reference
+    np.random.seed(1)
+    r = gs_renderer.Renderer(sh_degree=0)
+    r.initialize(num_pts=300)
+    W = H = 48
+    fovy = math.radians(49.1)
+    cam = gs_renderer.MiniCam(cam_utils.orbit_camera(15, -60, 2.0), W, H, fovy, fovy, 0.01, 100)
+    with torch.no_grad():
+        a = r.render(cam)
+        b = r.render(cam, compute_cov3D_python=True, convert_SHs_python=True)
+    used = calls["args"]
+    assert used["sh"].numel() == 0 and tuple(used["colors_precomp"].shape) == (300, 3)
+    assert used["scales"].numel() == 0 and tuple(used["cov3Ds_precomp"].shape) == (300, 6)
+    assert torch.equal(a["radii"], b["radii"])
+    assert float((a["image"] - b["image"]).abs().max()) < 2e-6
+    assert float((a["depth"] - b["depth"]).abs().max()) < 1e-5 and float((a["alpha"] - b["alpha"]).abs().max()) < 2e-6
