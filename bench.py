@@ -136,6 +136,10 @@ def main():
                     help="cameras per step on each GPU (B > 1: dreamgaussian_amd.rasterize_views keeps them in flight "
                          "together; --views-serial renders them one after the other like the reference's loop)")
     ap.add_argument("--views-serial", action="store_true")
+    ap.add_argument("--activations", default="none", choices=["none", "torch", "fused"],
+                    help="what the timed step does about DreamGaussian's parameter activations (gs_renderer.py:134-142): "
+                         "none = the rasterizer alone on activated inputs (the headline metric); torch = sigmoid/exp/normalize "
+                         "as torch ops + their autograd, as Renderer.render does; fused = rasterize_gaussians_raw")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -188,7 +192,26 @@ def main():
             c, r, d, al = D.rasterize_views(t["means3D"], m2d_b, t["opacities"], vs, shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
             torch.autograd.backward([c, d, al], [g.unsqueeze(0).expand(a.views, *g.shape).contiguous() for g in gout])
 
+    if a.activations != "none":      # raw parameters whose activations reproduce the scene
+        raw = dict(opacity=torch.logit(sc["opacities"].clamp(1e-4, 1 - 1e-4)), scaling=torch.log(sc["scales"]),
+                   rotation=sc["rotations"] * 1.7)
+        traw = {k: v.to(dev).requires_grad_(True) for k, v in raw.items()}
+
+    def step_activations():
+        for v in list(t.values()) + list(traw.values()):
+            v.grad = None
+        m2d.grad = None
+        if a.activations == "torch":
+            out = rast(means3D=t["means3D"], means2D=m2d, shs=t["shs"], colors_precomp=None,
+                       opacities=torch.sigmoid(traw["opacity"]), scales=torch.exp(traw["scaling"]),
+                       rotations=torch.nn.functional.normalize(traw["rotation"]), cov3D_precomp=None)
+        else:
+            out = D.rasterize_gaussians_raw(t["means3D"], m2d, t["shs"], traw["opacity"], traw["scaling"], traw["rotation"], rs)
+        torch.autograd.backward([out[0], out[2], out[3]], gout)
+
     def step(gather=True):
+        if a.activations != "none":
+            return step_activations()
         if a.views > 1:
             return step_views()
         for v in t.values():
@@ -291,7 +314,7 @@ def main():
             "config": {"workload": f"BASELINE.json configs[{wl['cfg']}]: {wl['N']} Gaussians, SH degree "
                                    f"{wl['deg']}, {wl['W']}x{wl['H']}, fwd+bwd, scene '{a.kind}' seed 0, "
                                    f"orbit camera r=2 fovy=49.1",
-                       "views_per_step": world * a.views, "views_mode": ("single" if a.views == 1 else ("serial loop" if a.views_serial else "rasterize_views")), "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU",
+                       "views_per_step": world * a.views, "activations": a.activations, "views_mode": ("single" if a.views == 1 else ("serial loop" if a.views_serial else "rasterize_views")), "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU",
                        "N": wl["N"], "K": K, "V": st.get("V"), "M": st.get("M_ref"), "M_emitted": st.get("M"),
                        "max_tile_list": st.get("max_tile")},
             "roofline": roof, "path_roofline": path_roof, "cpu_baseline": cpu,
