@@ -136,3 +136,30 @@ def test_python_side_covariance_and_colour_paths_agree(reference):
     assert torch.equal(a["radii"], b["radii"])
     assert float((a["image"] - b["image"]).abs().max()) < 2e-6
     assert float((a["depth"] - b["depth"]).abs().max()) < 1e-5 and float((a["alpha"] - b["alpha"]).abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize("active", [1, 2, 3])
+def test_view_dependent_colour_convention_matches_the_reference_python(reference, active):
+    """SH degrees 1-3 depend on the view direction `xyz - camera_center` (gs_renderer.py:786-792, with the
+    reference's camera_center = -c2w[:3,3], :671). Colours the reference computes in Python
+    (`convert_SHs_python=True`) must give the image the rasterizer's own SH evaluation gives: this pins the
+    oracle's (and through it the HIP kernels') direction and `campos` convention to the reference's code."""
+    gs_renderer, cam_utils, calls = reference
+    np.random.seed(2)
+    r = gs_renderer.Renderer(sh_degree=3)
+    r.initialize(num_pts=250)
+    g = torch.Generator().manual_seed(active)
+    with torch.no_grad():
+        r.gaussians._features_rest.copy_(torch.randn(r.gaussians._features_rest.shape, generator=g) * 0.15)
+        r.gaussians._features_dc.copy_(torch.randn(r.gaussians._features_dc.shape, generator=g) * 0.3)
+    r.gaussians.active_sh_degree = active
+    W, H = 56, 40
+    fovy = math.radians(49.1)
+    fovx = 2 * math.atan(math.tan(fovy / 2) * W / H)
+    cam = gs_renderer.MiniCam(cam_utils.orbit_camera(-25, 110, 2.2), W, H, fovy, fovx, 0.01, 100)
+    with torch.no_grad():
+        a = r.render(cam)
+        assert tuple(calls["args"]["sh"].shape) == (250, 16, 3) and calls["args"]["settings"].sh_degree == active
+        b = r.render(cam, convert_SHs_python=True)
+        assert tuple(calls["args"]["colors_precomp"].shape) == (250, 3)
+    assert float((a["image"] - b["image"]).abs().max()) < 3e-6
