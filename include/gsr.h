@@ -19,6 +19,11 @@
  *                        by DreamGaussian, kept for surface completeness)
  *   gsr_dist2         <- simple_knn._C.distCUDA2(points), gs_renderer.py:341;
  *                        simple-knn/spatial.cu:15-26, simple_knn.cu:185-221
+ * and, either side of the path:
+ *   gsr_extract_fields <- GaussianModel.extract_fields, gs_renderer.py:218-294 (+ gaussian_3d_coeff :64-83)
+ *   gsr_densify_stats  <- main.py:279-281 + GaussianModel.add_densification_stats, gs_renderer.py:625-627
+ *   GsrView.raw_activations <- the activations Renderer.render applies before the call,
+ *                        gs_renderer.py:134-142, 762-766
  */
 #ifndef GSR_H
 #define GSR_H
@@ -95,7 +100,7 @@ int gsr_forward(const GsrView* view, int32_t N, int32_t K,
  *   gsr_forward_finish  after the caller has waited for `stream` (or an event recorded behind
  *                       begin): binning, sort, compositing; geom_ptr / img_ptr are the buffers the
  *                       callbacks returned in begin
- * gsr_forward == begin + stream synchronise + finish. Issuing every view's begin before the first
+ * gsr_forward == begin + wait for the counter copy + finish. Issuing every view's begin before the first
  * finish pays the host round trip once per batch of views instead of once per view. */
 int gsr_forward_begin(const GsrView* view, int32_t N, int32_t K,
                       const float* means3D, const float* shs, const float* colors_precomp,
