@@ -2,7 +2,7 @@
 GPU box; the oracle takes minutes there, so this is a report, not a test).
 Test infrastructure: uses oracle/ as the checker only.
 
-  python tools/parity_report.py --n 100000 --deg 3 --size 800 [--kind blob] [--f64]
+  python tests/parity_report.py --n 100000 --deg 3 --size 800 [--kind blob] [--f64]
 """
 import argparse, sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
