@@ -163,3 +163,66 @@ def test_view_dependent_colour_convention_matches_the_reference_python(reference
         b = r.render(cam, convert_SHs_python=True)
         assert tuple(calls["args"]["colors_precomp"].shape) == (250, 3)
     assert float((a["image"] - b["image"]).abs().max()) < 3e-6
+
+
+def test_unmodified_training_loop_runs_through_the_dropin_surface(reference, monkeypatch):
+    """SURVEY 7 step 8 in CPU-emulated form: the reference's own `main.GUI.prepare_train()` and
+    `GUI.train_step()` (main.py:117-300, unmodified) for several iterations -- known-view RGB/mask loss,
+    a random novel view per step, Adam step, `max_radii2D` / `add_densification_stats`, and
+    `densify_and_prune` (clone, split, prune with optimizer-state surgery) -- with this repository's packages
+    behind `gs_renderer.py`. Stubs only for what is unrelated and uninstalled (Appendix E): cv2, dearpygui,
+    rembg, mesh; the guidance network is a differentiable surrogate so that the novel-view render gets a
+    backward pass, as SDS gives it in the real run (the densification consumer reads its gradient holder)."""
+    import yaml
+    gs_renderer, cam_utils, calls = reference
+    for name in ("cv2", "dearpygui", "dearpygui.dearpygui", "rembg"):
+        monkeypatch.setitem(sys.modules, name, types.ModuleType(name))
+    sys.modules["dearpygui"].dearpygui = sys.modules["dearpygui.dearpygui"]
+    sys.modules["mesh"].safe_normalize = lambda x, eps=1e-20: x / torch.sqrt(torch.clamp((x * x).sum(-1, keepdim=True), min=eps))
+
+    class Zero123:                                              # guidance/zero123_utils.py surrogate (main.py:155-160, 180, 270)
+        def __init__(self, device, model_key=None): pass
+        def get_img_embeds(self, x): self.ref = x.mean()
+        def train_step(self, images, vers, hors, radii, step_ratio=None, default_elevation=0):
+            return ((images - 0.5) ** 2).mean() * 10.0
+    z = types.ModuleType("guidance.zero123_utils"); z.Zero123 = Zero123
+    monkeypatch.setitem(sys.modules, "guidance", types.ModuleType("guidance"))
+    monkeypatch.setitem(sys.modules, "guidance.zero123_utils", z)
+
+    class Event:                                                # torch.cuda.Event / synchronize (main.py:183-185, 290-292)
+        def __init__(self, enable_timing=False): pass
+        def record(self): pass
+        def elapsed_time(self, other): return 0.0
+    monkeypatch.setattr(torch.cuda, "Event", Event)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+
+    sys.modules.pop("main", None)
+    import main as ref_main                                     # the reference trainer, unmodified
+    cfg = yaml.safe_load(open(os.path.join(REF, "configs", "image.yaml")))
+    cfg.update(save_path="t", num_pts=260, ref_size=32, iters=20, density_start_iter=1, densification_interval=2,
+               densify_grad_threshold=1e-6, opacity_reset_interval=3, load=None, input=None)
+    opt = types.SimpleNamespace(**cfg)
+    np.random.seed(3); torch.manual_seed(3)
+    gui = ref_main.GUI(opt)
+    gui.device = torch.device("cpu")
+    yy, xx = np.mgrid[0:64, 0:64]
+    disc = (((xx - 32) ** 2 + (yy - 32) ** 2) < 18 ** 2).astype(np.float32)
+    gui.input_mask = disc[..., None]                            # what load_input leaves (main.py:391-397)
+    gui.input_img = np.stack([disc * 0.8, disc * 0.3, disc * 0.2], -1) + (1 - disc[..., None])
+    gui.prepare_train()
+    assert gui.enable_zero123 and gui.optimizer is gui.renderer.gaussians.optimizer
+    n0 = gui.renderer.gaussians.get_xyz.shape[0]
+    xyz0 = gui.renderer.gaussians.get_xyz.detach().clone()
+    sizes = []
+    for _ in range(4):
+        gui.train_step()                                        # main.py:182-300
+        g = gui.renderer.gaussians
+        sizes.append(int(g.get_xyz.shape[0]))
+        assert g.xyz_gradient_accum.shape[0] == g.get_xyz.shape[0] == g.max_radii2D.shape[0]
+    s = calls["args"]["settings"]
+    assert (s.image_height, s.image_width) == (128, 128)       # the last render was a novel view (main.py:211)
+    assert gui.step == 4 and any(n != n0 for n in sizes), sizes   # densify_and_prune changed the model
+    g = gui.renderer.gaussians
+    assert torch.isfinite(g.get_xyz).all() and torch.isfinite(g.get_opacity).all()
+    assert not torch.equal(g.get_xyz[:5], xyz0[:5]) or sizes[-1] != n0      # Adam moved the parameters
+    sys.modules.pop("main", None)
