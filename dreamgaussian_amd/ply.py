@@ -126,3 +126,52 @@ def load_ply(path: str, max_sh_degree: int, device="cpu") -> Dict[str, torch.Ten
     t = lambda a: torch.tensor(a, dtype=torch.float, device=device)
     return dict(xyz=t(xyz), features_dc=t(f_dc).transpose(1, 2).contiguous(),
                 features_rest=t(f_rest).transpose(1, 2).contiguous(), opacity=t(opac), scaling=t(scales), rotation=t(rots))
+
+
+# ---------------------------------------------------------------------------------------------------
+# The slice of the `plyfile` API that gs_renderer.py uses (`PlyElement.describe`, `PlyData([el]).write`,
+# `PlyData.read(path).elements[0]` with `[name]` and `.properties[i].name`, gs_renderer.py:414-415, 418-441),
+# so that the reference's own `save_ply` / `load_ply` run unmodified where `plyfile` is not installed:
+#     import sys, dreamgaussian_amd.ply as p; sys.modules.setdefault("plyfile", p)
+# ---------------------------------------------------------------------------------------------------
+class PlyProperty:
+    def __init__(self, name):
+        self.name = name
+
+
+class PlyElement:
+    def __init__(self, name, data):
+        self.name, self.data = name, data
+
+    @staticmethod
+    def describe(data, name):
+        return PlyElement(name, np.asarray(data))
+
+    @property
+    def properties(self):
+        return [PlyProperty(n) for n in self.data.dtype.names]
+
+    def __getitem__(self, key):
+        return self.data[key]
+
+    def __len__(self):
+        return len(self.data)
+
+
+class PlyData:
+    def __init__(self, elements=()):
+        self.elements = list(elements)
+
+    def write(self, path):
+        el = self.elements[0]
+        names = el.data.dtype.names
+        kinds = {np.dtype(t): n for n, t in (("float", "<f4"), ("double", "<f8"), ("uchar", "u1"), ("int", "<i4"))}
+        header = "ply\nformat binary_little_endian 1.0\nelement %s %d\n" % (el.name, len(el.data))
+        header += "".join(f"property {kinds[el.data.dtype[n].newbyteorder('<')]} {n}\n" for n in names) + "end_header\n"
+        with open(path, "wb") as fh:
+            fh.write(header.encode("ascii"))
+            fh.write(np.ascontiguousarray(el.data.astype(el.data.dtype.newbyteorder("<"))).tobytes())
+
+    @staticmethod
+    def read(path):
+        return PlyData([PlyElement("vertex", read_vertex_table(path))])

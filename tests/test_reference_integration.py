@@ -226,3 +226,34 @@ def test_unmodified_training_loop_runs_through_the_dropin_surface(reference, mon
     assert torch.isfinite(g.get_xyz).all() and torch.isfinite(g.get_opacity).all()
     assert not torch.equal(g.get_xyz[:5], xyz0[:5]) or sizes[-1] != n0      # Adam moved the parameters
     sys.modules.pop("main", None)
+
+
+def test_reference_save_and_load_ply_through_the_plyfile_shim(reference, monkeypatch, tmp_path):
+    """gs_renderer.py's own `save_ply` / `load_ply` (:391-462, unmodified) with dreamgaussian_amd.ply standing in for
+    the uninstalled `plyfile`: the file they write is byte-identical to dreamgaussian_amd.ply.save_ply's, and
+    loading it back gives the parameters bit for bit."""
+    from dreamgaussian_amd import ply
+    gs_renderer, _, _ = reference
+    monkeypatch.setattr(gs_renderer, "PlyData", ply.PlyData)
+    monkeypatch.setattr(gs_renderer, "PlyElement", ply.PlyElement)
+    g = torch.Generator().manual_seed(5)
+    gm = gs_renderer.GaussianModel(2)
+    N, K = 23, 9
+    gm._xyz = torch.randn(N, 3, generator=g)
+    gm._features_dc = torch.randn(N, 1, 3, generator=g)
+    gm._features_rest = torch.randn(N, K - 1, 3, generator=g)
+    gm._opacity = torch.randn(N, 1, generator=g)
+    gm._scaling = torch.randn(N, 3, generator=g)
+    gm._rotation = torch.randn(N, 4, generator=g)
+    a, b = str(tmp_path / "ref" / "m.ply"), str(tmp_path / "ours" / "m.ply")
+    gm.save_ply(a)                                                                   # the reference's writer logic
+    ply.save_ply(b, gm._xyz, gm._features_dc, gm._features_rest, gm._opacity, gm._scaling, gm._rotation)
+    assert open(a, "rb").read() == open(b, "rb").read()
+    gm2 = gs_renderer.GaussianModel(2)
+    gm2.load_ply(a)                                                                  # the reference's reader logic
+    ours = ply.load_ply(a, 2)
+    for name, key in (("_xyz", "xyz"), ("_features_dc", "features_dc"), ("_features_rest", "features_rest"),
+                      ("_opacity", "opacity"), ("_scaling", "scaling"), ("_rotation", "rotation")):
+        ref_t = getattr(gm2, name).detach()
+        assert torch.equal(ref_t, getattr(gm, name)), name
+        assert torch.equal(ref_t, ours[key]), name
