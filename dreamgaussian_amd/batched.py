@@ -73,10 +73,13 @@ class _RasterizeViews(torch.autograd.Function):
         views, keeps, geoms, imgs, bins, stats, events = [], [], [], [], [], [], []
         P = _lib.ptr
         with torch.cuda.device(dev):
+            # every view struct first: their .to()/.contiguous() copies run on the CURRENT stream and
+            # must be ordered before the side streams fork from it
+            structs = [_view_struct(settings[v], dev) for v in range(B)]
             for v in range(B):                       # phase 1: per-Gaussian stage of every view
                 s = streams[v]
                 s.wait_stream(cur)
-                view, keep = _view_struct(settings[v], dev)
+                view, keep = structs[v]
                 geom, img = _lib.Scratch(dev), _lib.Scratch(dev)
                 rc = lib.gsr_forward_begin(C.byref(view), N, K, P(m3), P(shc), P(col), P(op), P(sc), P(rot), P(cov),
                                            C.c_void_p(radii[v].data_ptr()), geom.alloc, img.alloc,
@@ -100,11 +103,13 @@ class _RasterizeViews(torch.autograd.Function):
             for s in streams:
                 cur.wait_stream(s)
         ctx.settings = settings
+        ctx.views = list(zip(views, keeps))    # the backward reuses the structs (and keeps their device constants alive)
         ctx.dims = (B, N, K, H, W)
         ctx.stats = stats
         ctx.present = (shc is not None, col is not None, sc is not None, cov is not None)
         empty = torch.empty(0, device=dev)
-        ctx.save_for_backward(m3, shc if shc is not None else empty, col if col is not None else empty, op,
+        ctx.save_for_backward(m3 if m3 is not None else empty, shc if shc is not None else empty,
+                              col if col is not None else empty, op if op is not None else empty,
                               sc if sc is not None else empty, rot if rot is not None else empty,
                               cov if cov is not None else empty, radii,
                               *[g.tensor for g in geoms], *[b.tensor for b in bins], *[i.tensor for i in imgs])
@@ -123,7 +128,7 @@ class _RasterizeViews(torch.autograd.Function):
         m3, shc, col, op, sc, rot, cov, radii = saved[:8]
         geoms, bins, imgs = saved[8:8 + B], saved[8 + B:8 + 2 * B], saved[8 + 2 * B:8 + 3 * B]
         has_sh, has_col, has_sr, has_cov = ctx.present
-        dev = m3.device
+        dev = radii.device
         z = lambda g, shape: (torch.zeros(shape, dtype=torch.float32, device=dev) if g is None
                               else g.to(torch.float32).contiguous())
         gc, gd, ga = z(g_color, (B, 3, H, W)), z(g_depth, (B, 1, H, W)), z(g_alpha, (B, 1, H, W))
@@ -143,7 +148,7 @@ class _RasterizeViews(torch.autograd.Function):
                 for v in range(B):
                     s = streams[v]
                     s.wait_stream(cur)
-                    view, keep = _view_struct(ctx.settings[v], dev)
+                    view, keep = ctx.views[v]
                     tmp = _lib.Scratch(dev)
                     rc = lib.gsr_backward(
                         C.byref(view), N, K, P(m3), P(shc) if has_sh else None, P(col) if has_col else None,

@@ -6,6 +6,7 @@
 #include "gsr_preprocess.hip"
 #include "gsr_binning.hip"
 #include "gsr_render.hip"
+#include "gsr_render_exp.hip"
 #include "gsr_knn.hip"
 #include "gsr_fields.hip"
 #include "gsr_densify.hip"
@@ -84,6 +85,21 @@ int launch_status(bool debug, hipStream_t stream, const char* name) {
 
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
+// Runs `fn` the first time the calling code reaches this call site on each device (function
+// attributes such as the > 64 KiB dynamic-LDS opt-in are per device; forward and backward run on
+// different host threads).
+template <typename F>
+int once_per_device(F fn) {
+    static std::mutex mu;
+    static bool done[64] = {};
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) { HIP_TRY(fn()); return 0; }
+    std::lock_guard<std::mutex> lk(mu);
+    if (!done[dev]) { HIP_TRY(fn()); done[dev] = true; }
+    return 0;
+}
+
 struct GeomLayout {
     size_t recs, emit, flags8, block_stats, tile_count, cursor, tile_last, tile_off, tile_seg, tile_order, plan_off, counters, total;
     int nTiles;
@@ -109,13 +125,14 @@ GeomLayout geom_layout(int N, int H, int W) {
     return L;
 }
 int seg_shift();
-struct BinLayout { size_t entries, recs, ckpt, plan_tile, plan_cap, total; };
-BinLayout bin_layout(size_t M, bool copy, int nTiles) {
+#define GSR_BWD_DEFAULT kBwdF2b
+struct BinLayout { size_t entries, ids, ckpt, plan_tile, plan_cap, total; };
+BinLayout bin_layout(size_t M, int nTiles) {
     BinLayout L;
     size_t o = 0;
-    // first: the sorted list (64-byte records, or 4-byte Gaussian indices) -- the backward finds
-    // it at offset 0 without knowing M
-    L.recs = o; o += align_up(M * (copy ? sizeof(SplatRec) : 4));
+    // first: the sorted lists (4-byte Gaussian indices) -- the backward finds them at offset 0
+    // without knowing M
+    L.ids = o; o += align_up(M * 4);
     L.entries = o; o += align_up(M * 8);
     // backward checkpoints: sum over tiles of floor((n_t-1) >> seg_shift) <= (M >> seg_shift) slots
     L.ckpt = o; o += align_up(((M >> seg_shift()) + 1) * (size_t)GSR_CKPT_FLOATS * 4);
@@ -161,82 +178,45 @@ int check_inputs(int N, int K, const GsrView* v, const float* means3D, const flo
     return 0;
 }
 
-constexpr int kHistLdsMaxTiles = 16384;
+constexpr int kHistLdsMaxTiles = 16384;   // 64 KiB of LDS histogram
 
-// GSR_RENDER_V0=1 selects the first-generation compositing kernels (scalar-load list walk) for
-// A/B measurements; the default is the LDS-staged generation.
-// GSR_SORT=bitonic selects the LDS bitonic network for every tile (default: bucket sort with
-// the network as the skew fallback). GSR_RECORDS=copy makes the sort write each tile's sorted
-// 64-byte record stream; the default (byid) keeps only sorted Gaussian indices and the
-// compositing kernels gather records from the per-Gaussian array.
-bool use_sort_bitonic() {
-    static const bool v = [] { const char* e = getenv("GSR_SORT"); return e && strcmp(e, "bitonic") == 0; }();
-    return v;
-}
-bool use_record_copy() {
-    static const bool v = [] {
-        const char* e = getenv("GSR_RECORDS");
-        const char* r = getenv("GSR_RENDER_V0");
-        return (e && strcmp(e, "copy") == 0) || (r && r[0] == '1') || use_sort_bitonic();
-    }();
-    return v;
-}
-// GSR_BWD=b2f selects the back-to-front (one workgroup per tile) backward compositing kernel.
-// GSR_SH=direct makes the forward per-Gaussian kernel read SH rows with per-lane 16-byte loads
-// (no LDS transpose, 4x the occupancy); measured SLOWER at 1M Gaussians (0.236 vs 0.152 ms:
-// 192-byte-strided rows defeat the coalescer), so the LDS transpose stays the default.
+// Environment switches kept for same-box A/B measurements (defaults = the shipped path):
+//   GSR_BWD=f2b|q2|quad   backward compositing kernel (gsr_render.hip / gsr_render_exp.hip)
+//   GSR_FWD=u4            experimental forward with four entries per trip (gsr_render_exp.hip)
+//   GSR_SH=direct         K1 reads SH rows with per-lane 16-byte loads (no LDS transpose; measured slower)
+//   GSR_TILE_ORDER=off    forward compositing tiles in row-major instead of heaviest-first order
+//   GSR_SEG_SHIFT=6..8    log2 of the backward segment length in list positions
 bool use_sh_stage() {
     static const bool v = [] { const char* e = getenv("GSR_SH"); return !(e && strcmp(e, "direct") == 0); }();
     return v;
 }
-// GSR_TILE_ORDER=off launches the forward compositing tiles in row-major instead of heaviest-first order.
 bool use_tile_order_off() {
     static const bool v = [] { const char* e = getenv("GSR_TILE_ORDER"); return e && strcmp(e, "off") == 0; }();
     return v;
 }
-// GSR_FWD_SCHED=1: forward compositing variant with a pinned LDS-read / VALU interleave.
-bool use_fwd_sched() {
-    static const bool v = [] { const char* e = getenv("GSR_FWD_SCHED"); return e && e[0] == '1'; }();
-    return v;
-}
-// GSR_CULL: "exact" (default) = ellipse-vs-block test in both compositing kernels' staging,
-// "aabb" = bounding-box test, "fwd" / "bwd" = exact in that kernel only.
-int cull_mode(bool fwd) {
-    static const int v = [] {
-        const char* e = getenv("GSR_CULL");
-        if (!e || strcmp(e, "exact") == 0) return 3;
-        if (strcmp(e, "fwd") == 0) return 1;
-        if (strcmp(e, "bwd") == 0) return 2;
-        return 0;
-    }();
-    return fwd ? (v & 1) : ((v >> 1) & 1);
-}
-// GSR_BWD_ACC=global: per-(block, Gaussian) global atomics instead of the per-workgroup LDS table.
-bool use_bwd_acc_lds() {
-    static const bool v = [] { const char* e = getenv("GSR_BWD_ACC"); return !(e && strcmp(e, "global") == 0); }();
-    return v && seg_shift() <= 8;   // table = 48 B << shift of LDS
-}
-// GSR_SEG_SHIFT: log2 of the backward segment length in list positions (default 10).
 int seg_shift() {
     static const int v = [] {
         const char* e = getenv("GSR_SEG_SHIFT");
         const int s = e ? atoi(e) : GSR_SEG_SHIFT_DEFAULT;
-        return (s < 6 || s > 14) ? GSR_SEG_SHIFT_DEFAULT : s;      // multiples of the 64-entry fetch round
+        return (s < 6 || s > 8) ? GSR_SEG_SHIFT_DEFAULT : s;       // multiples of the 64-entry fetch round; LDS table = 48 B << shift
     }();
     return v;
 }
-int k1_dbg() {   // GSR_K1_DBG: timing experiments on K1 (WRONG results)
-    static const int v = [] { const char* e = getenv("GSR_K1_DBG"); return e ? atoi(e) : 0; }();
+enum BwdKernel { kBwdF2b = 0, kBwdQ2 = 1, kBwdQuad = 2 };
+int bwd_kernel() {
+    static const int v = [] {
+        const char* e = getenv("GSR_BWD");
+        if (e && strcmp(e, "q2") == 0) return (int)kBwdQ2;
+        if (e && strcmp(e, "quad") == 0) return (int)kBwdQuad;
+        if (e && strcmp(e, "f2b") == 0) return (int)kBwdF2b;
+        return (int)GSR_BWD_DEFAULT;
+    }();
     return v;
 }
-bool use_bwd_b2f() {
-    static const bool v = [] { const char* e = getenv("GSR_BWD"); return e && strcmp(e, "b2f") == 0; }();
+bool use_fwd_u4() {
+    static const bool v = [] { const char* e = getenv("GSR_FWD"); return e && strcmp(e, "u4") == 0; }();
     return v;
 }
-bool use_render_v0() {
-    static const bool v = [] { const char* e = getenv("GSR_RENDER_V0"); return e && e[0] == '1'; }();
-    return v;
-}   // 64 KiB of LDS histogram
 
 }  // namespace
 
@@ -326,7 +306,11 @@ extern "C" int gsr_forward_begin(const GsrView* view, int32_t N, int32_t K,
     prof_end(stream, "memset_fwd");
 
     const int sh_direct = use_sh_stage() ? 0 : 1;
-    static const int k1_grid = [] { const char* e = getenv("GSR_K1_GRID"); return e ? atoi(e) : 512; }();
+    static const int k1_grid = [] {   // GSR_K1_GRID: workgroups of the per-Gaussian kernel (block_stats holds 2048)
+        const char* e = getenv("GSR_K1_GRID");
+        const int g = e ? atoi(e) : 512;
+        return g < 1 ? 1 : (g > 2048 ? 2048 : g);
+    }();
     const int grid_pre = N > 0 ? (int)fmin((double)((N + 255) / 256), sh_direct ? 2048.0 : (double)k1_grid) : 0;
     if (N > 0) {
         const size_t hist_bytes = hist_in_lds ? (((size_t)T * 4 + 15) & ~(size_t)15) : 0;
@@ -338,7 +322,7 @@ extern "C" int gsr_forward_begin(const GsrView* view, int32_t N, int32_t K,
             HIP_TRY(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         prof_begin(stream); hipLaunchKernelGGL(k1, dim3(grid_pre), dim3(256), lds, stream, vc, N, K, means3D, shs,
                            colors_precomp, opacities, scales, rotations, cov3D_precomp, recs, emit, radii,
-                           tile_count, (unsigned long long*)(gbuf + GL.block_stats), hist_in_lds, sh_direct, k1_dbg(), (uint8_t*)(gbuf + GL.flags8));
+                           tile_count, (unsigned long long*)(gbuf + GL.block_stats), hist_in_lds, sh_direct, (uint8_t*)(gbuf + GL.flags8));
         LAUNCH_CHECK(view, stream, "preprocess_fwd");
     }
     prof_begin(stream); hipLaunchKernelGGL(gsr_tile_scan, dim3(1), dim3(1024), 0, stream, tile_count, tile_off, T, counters, tile_seg, seg_shift(),
@@ -391,13 +375,11 @@ extern "C" int gsr_forward_finish(const GsrView* view, int32_t N, int32_t K,
     if (stats) { stats->num_instances = (int64_t)M; stats->num_instances_ref = (int64_t)M_ref; stats->num_visible = (int64_t)V; stats->max_tile_count = (int64_t)maxc; }
     if (M >= 0xfffffff0ull) return fail(-5, "too many tile instances (%s%lld)", "", (long long)M);
 
-    const bool copy = use_record_copy();
-    const BinLayout BL = bin_layout((size_t)M, copy, T);
+    const BinLayout BL = bin_layout((size_t)M, T);
     char* bbuf = (char*)bin.resize(bin.ctx, BL.total);
     if (!bbuf) return fail(-4, "bin scratch allocation failed%s", "");
     unsigned long long* entries = (unsigned long long*)(bbuf + BL.entries);
-    SplatRec* srecs = (SplatRec*)(bbuf + BL.recs);
-    uint32_t* sorted_ids = (uint32_t*)(bbuf + BL.recs);
+    uint32_t* sorted_ids = (uint32_t*)(bbuf + BL.ids);
     float* ckpt = (float*)(bbuf + BL.ckpt);
 
     if (M > 0) {
@@ -408,59 +390,36 @@ extern "C" int gsr_forward_finish(const GsrView* view, int32_t N, int32_t K,
                            vc.gx, T, hist_in_lds, (uint32_t)M);
         LAUNCH_CHECK(view, stream, "scatter");
         // per-tile sort, size classes by list length
-        SplatRec* out_recs = copy ? srecs : nullptr;
-        uint32_t* out_ids = copy ? nullptr : sorted_ids;
-        if (use_sort_bitonic()) {
-            prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_lds<2048, 256>), dim3(T), dim3(256), 2048 * 8, stream, tile_off, entries, recs, srecs, 0u, 2048u);
-            LAUNCH_CHECK(view, stream, "tile_sort_small");
-            if (maxc > 2048) {
-                static bool attr_set = false;
-                if (!attr_set) {
-                    HIP_TRY(hipFuncSetAttribute((const void*)gsr_tile_sort_lds<16384, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8));
-                    attr_set = true;
-                }
-                prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_lds<16384, 1024>), dim3(T), dim3(1024), 16384 * 8, stream, tile_off, entries, recs, srecs, 2048u, 16384u);
-                LAUNCH_CHECK(view, stream, "tile_sort_large");
-            }
-        } else {
-            constexpr size_t lds_s = 2048 * 8 + (512 + 1 + 512 + 40) * 4;
-            constexpr size_t lds_m = 8192 * 8 + (2048 + 1 + 2048 + 40) * 4;
-            constexpr size_t lds_l = 16384 * 8 + (2048 + 1 + 2048 + 40) * 4;
-            static bool attr_set = false;
-            if (!attr_set) {
-                HIP_TRY(hipFuncSetAttribute((const void*)gsr_tile_sort_bucket<8192, 1024, 2048>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
-                HIP_TRY(hipFuncSetAttribute((const void*)gsr_tile_sort_bucket<16384, 1024, 2048>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l));
-                attr_set = true;
-            }
-            prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<2048, 256, 512>), dim3(T), dim3(256), lds_s, stream, tile_off, entries, recs, out_recs, out_ids, 0u, 2048u);
-            LAUNCH_CHECK(view, stream, "tile_sort_small");
-            if (maxc > 2048) {
-                prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<8192, 1024, 2048>), dim3(T), dim3(1024), lds_m, stream, tile_off, entries, recs, out_recs, out_ids, 2048u, 8192u);
-                LAUNCH_CHECK(view, stream, "tile_sort_medium");
-            }
-            if (maxc > 8192) {
-                prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<16384, 1024, 2048>), dim3(T), dim3(1024), lds_l, stream, tile_off, entries, recs, out_recs, out_ids, 8192u, 16384u);
-                LAUNCH_CHECK(view, stream, "tile_sort_large");
-            }
+        constexpr size_t lds_s = 2048 * 8 + (512 + 1 + 512 + 40) * 4;
+        constexpr size_t lds_m = 8192 * 8 + (2048 + 1 + 2048 + 40) * 4;
+        constexpr size_t lds_l = 16384 * 8 + (2048 + 1 + 2048 + 40) * 4;
+        if (int rc = once_per_device([]() -> hipError_t {   // > 64 KiB of dynamic LDS is an opt-in per device
+                hipError_t e = hipFuncSetAttribute((const void*)gsr_tile_sort_bucket<8192, 1024, 2048>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m);
+                if (e != hipSuccess) return e;
+                return hipFuncSetAttribute((const void*)gsr_tile_sort_bucket<16384, 1024, 2048>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l);
+            })) return rc;
+        prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<2048, 256, 512>), dim3(T), dim3(256), lds_s, stream, tile_off, entries, sorted_ids, 0u, 2048u);
+        LAUNCH_CHECK(view, stream, "tile_sort_small");
+        if (maxc > 2048) {
+            prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<8192, 1024, 2048>), dim3(T), dim3(1024), lds_m, stream, tile_off, entries, sorted_ids, 2048u, 8192u);
+            LAUNCH_CHECK(view, stream, "tile_sort_medium");
+        }
+        if (maxc > 8192) {
+            prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<16384, 1024, 2048>), dim3(T), dim3(1024), lds_l, stream, tile_off, entries, sorted_ids, 8192u, 16384u);
+            LAUNCH_CHECK(view, stream, "tile_sort_large");
         }
         if (maxc > 16384) {
-            prof_begin(stream); hipLaunchKernelGGL(gsr_tile_sort_global_ids, dim3(T), dim3(1024), 0, stream, tile_off, entries, recs, out_recs, out_ids, 16384u);
+            prof_begin(stream); hipLaunchKernelGGL(gsr_tile_sort_global_ids, dim3(T), dim3(1024), 0, stream, tile_off, entries, sorted_ids, 16384u);
             LAUNCH_CHECK(view, stream, "tile_sort_global");
         }
     }
     prof_begin(stream);
-    if (use_render_v0())
-        hipLaunchKernelGGL(gsr_render_fwd_v0, dim3(T), dim3(256), 0, stream, tile_off, srecs, view->bg, W, H, vc.gx,
-                           out_color, out_depth, out_alpha, final_T, n_contrib);
-    else {
-#define GSR_LAUNCH_FWD(B, S, RECS, IDS)                                                              \
-        hipLaunchKernelGGL((gsr_render_fwd<B, S>), dim3(T), dim3(256), 0, stream, tile_off, RECS, IDS, view->bg, W, H, vc.gx, \
-                           out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, tile_order, cull_mode(true), seg_shift(), tile_last)
-        const bool sched = use_fwd_sched();
-        if (copy) { if (sched) GSR_LAUNCH_FWD(false, true, srecs, (const uint32_t*)nullptr); else GSR_LAUNCH_FWD(false, false, srecs, (const uint32_t*)nullptr); }
-        else { if (sched) GSR_LAUNCH_FWD(true, true, recs, sorted_ids); else GSR_LAUNCH_FWD(true, false, recs, sorted_ids); }
-#undef GSR_LAUNCH_FWD
-    }
+    if (use_fwd_u4())
+        hipLaunchKernelGGL(gsr_render_fwd_u4, dim3(T), dim3(256), 0, stream, tile_off, recs, sorted_ids, view->bg, W, H, vc.gx,
+                           out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, tile_order, seg_shift(), tile_last);
+    else
+        hipLaunchKernelGGL(gsr_render_fwd, dim3(T), dim3(256), 0, stream, tile_off, recs, sorted_ids, view->bg, W, H, vc.gx,
+                           out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, tile_order, seg_shift(), tile_last);
     LAUNCH_CHECK(view, stream, "render_fwd");
     return 0;
 }
@@ -504,7 +463,7 @@ extern "C" int gsr_forward(const GsrView* view, int32_t N, int32_t K,
                                       (const uint64_t*)g_pinned, stats, stream_);
     if (rc == 0) {
         const ViewConst vc = make_view(view);
-        const size_t need = bin_layout((size_t)g_pinned[2], use_record_copy(), geom_layout(N, vc.H, vc.W).nTiles).total;
+        const size_t need = bin_layout((size_t)g_pinned[2], geom_layout(N, vc.H, vc.W).nTiles).total;
         g_bin_hint = need + need / 4;
     }
     return rc;
@@ -553,7 +512,7 @@ extern "C" int gsr_backward(const GsrView* view, int32_t N, int32_t K,
         M = h[2]; maxc = h[3];
     }
     (void)maxc;
-    const SplatRec* srecs = (const SplatRec*)bin;          // BinLayout.recs == 0
+    const uint32_t* sorted_ids = (const uint32_t*)bin;    // BinLayout.ids == 0
 
     float* g2d = (float*)tmp.resize(tmp.ctx, align_up((size_t)N * GSR_G2D_STRIDE * 4));
     if (!g2d) return fail(-4, "tmp scratch allocation failed%s", "");
@@ -561,41 +520,32 @@ extern "C" int gsr_backward(const GsrView* view, int32_t N, int32_t K,
     HIP_TRY(hipMemsetAsync(g2d, 0, (size_t)N * GSR_G2D_STRIDE * 4, stream));
     prof_end(stream, "memset_bwd");
 
-    prof_begin(stream);
-    if (use_render_v0())
-        hipLaunchKernelGGL(gsr_render_bwd_v0, dim3(T), dim3(256), 0, stream, tile_off, srecs, view->bg, W, H, vc.gx,
-                           final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, g2d);
-    else if (use_bwd_b2f()) {
-        if (use_record_copy())
-            hipLaunchKernelGGL(gsr_render_bwd<false>, dim3(T), dim3(256), 0, stream, tile_off, srecs, (const uint32_t*)nullptr, view->bg, W, H, vc.gx,
-                               final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, g2d);
-        else
-            hipLaunchKernelGGL(gsr_render_bwd<true>, dim3(T), dim3(256), 0, stream, tile_off, recs, (const uint32_t*)bin, view->bg, W, H, vc.gx,
-                               final_T, n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, g2d);
-    } else if (M > 0) {
-        const bool copy = use_record_copy();
-        const BinLayout BL = bin_layout((size_t)M, copy, T);
+    if (M > 0) {
+        const BinLayout BL = bin_layout((size_t)M, T);
         const float* ckpt = (const float*)((const char*)bin + BL.ckpt);
         // scratch of the matching forward, written here: the backward work list
         uint32_t* plan_tile = (uint32_t*)((char*)const_cast<void*>(bin) + BL.plan_tile);
         uint32_t* plan_off = (uint32_t*)(const_cast<char*>(gbuf) + GL.plan_off);
         unsigned long long* plan_total = const_cast<unsigned long long*>(counters) + 4;
         const uint32_t* tile_last = (const uint32_t*)(gbuf + GL.tile_last);
+        prof_begin(stream);
         hipLaunchKernelGGL(gsr_bwd_plan, dim3(1), dim3(1024), 0, stream, tile_last, T, seg_shift(), (uint32_t)BL.plan_cap,
                            plan_off, plan_tile, plan_total);
         LAUNCH_CHECK(view, stream, "bwd_plan");
         prof_begin(stream);
         const unsigned grid = (unsigned)BL.plan_cap;
-        const int acc_lds = use_bwd_acc_lds() ? 1 : 0;
-        const size_t dyn = acc_lds ? ((size_t)GSR_G2D_STRIDE * 4) << seg_shift() : 0;
-#define GSR_LAUNCH_F2B(B, A, RECS, IDS)                                                                \
-        hipLaunchKernelGGL((gsr_render_bwd_f2b<B, A>), dim3(grid), dim3(256), dyn, stream, tile_off, RECS, IDS, view->bg, W, H, vc.gx, \
-                           final_T, n_contrib, totals, ckpt, tile_seg, dL_dcolor, dL_ddepth, dL_dalpha, g2d, cull_mode(false), seg_shift(), \
+        const size_t dyn = ((size_t)GSR_G2D_STRIDE * 4) << seg_shift();
+#define GSR_LAUNCH_BWD(KERNEL)                                                                          \
+        hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(256), dyn, stream, tile_off, recs, sorted_ids, view->bg, W, H, vc.gx, \
+                           final_T, n_contrib, totals, ckpt, tile_seg, dL_dcolor, dL_ddepth, dL_dalpha, g2d, seg_shift(), \
                            plan_tile, plan_off, plan_total)
-        if (copy) { if (acc_lds) GSR_LAUNCH_F2B(false, true, srecs, (const uint32_t*)nullptr); else GSR_LAUNCH_F2B(false, false, srecs, (const uint32_t*)nullptr); }
-        else { if (acc_lds) GSR_LAUNCH_F2B(true, true, recs, (const uint32_t*)bin); else GSR_LAUNCH_F2B(true, false, recs, (const uint32_t*)bin); }
-#undef GSR_LAUNCH_F2B
-    }
+        switch (bwd_kernel()) {
+            case kBwdQ2: GSR_LAUNCH_BWD(gsr_render_bwd_q2); break;
+            case kBwdQuad: GSR_LAUNCH_BWD(gsr_render_bwd_f2b_quad); break;
+            default: GSR_LAUNCH_BWD(gsr_render_bwd_f2b); break;
+        }
+#undef GSR_LAUNCH_BWD
+    } else prof_begin(stream);
     LAUNCH_CHECK(view, stream, "render_bwd");
 
     const int grid_n = (int)fmin((double)((N + 255) / 256), 2048.0);

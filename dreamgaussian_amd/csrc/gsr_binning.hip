@@ -7,9 +7,10 @@
 // MI355X design: no global M-element sort. Per-tile instance counts come out of K1's LDS
 // histograms; K2 scans them into segment offsets; K3 scatters 8-byte (depth,id) keys into the
 // tile segments through an LDS-privatised cursor reservation (one returning global atomic per
-// (workgroup,tile) instead of one per instance); K4 sorts each segment inside LDS (bitonic,
-// 64-bit keys, up to 16384 entries = 128 KiB of the CU's 160 KiB) and writes the tile's
-// 64-byte SplatRec stream in final order so the render kernels read it with scalar loads.
+// (workgroup,tile) instead of one per instance); K4 sorts each segment inside LDS (counting pass
+// into ~n/4 depth buckets + insertion sort per bucket on the 64-bit key; bitonic network as the
+// skew fallback; up to 16384 entries = 128 KiB of the CU's 160 KiB) and writes the tile's sorted
+// list of Gaussian INDICES; the compositing kernels gather the 64-byte records themselves.
 #include "gsr_device.h"
 
 // ---------------------------------------------------------------------------------------
@@ -129,7 +130,7 @@ gsr_scatter(int N, const EmitRec* __restrict__ emit, const uint32_t* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------
-// K4: per-tile sort + record gather.
+// Bitonic network (fallback of the bucket sort; in place in HBM for lists beyond the LDS classes)
 // Bitonic network in the "all ascending" form (first step of each merge mirrors, the rest
 // are half-cleaners) so that indices >= n act as +infinity keys and are simply skipped.
 // ---------------------------------------------------------------------------------------
@@ -233,57 +234,15 @@ gsr_bwd_plan(const uint32_t* __restrict__ tile_last, int T, int seg_shift, uint3
     if (threadIdx.x == 1023) total[0] = min(base + incl, capacity);
 }
 
-// write the tile's records in sorted order: 4 lanes move one 64-byte record
-__device__ __forceinline__ void gather_records(const unsigned long long* keys, uint32_t n,
-                                               const SplatRec* __restrict__ geom,
-                                               SplatRec* __restrict__ out, int nthreads) {
-    const uint32_t part = threadIdx.x & 3;
-    for (uint32_t i = threadIdx.x >> 2; i < n; i += (nthreads >> 2)) {
-        const uint32_t id = (uint32_t)keys[i];
-        const uint4 v = reinterpret_cast<const uint4*>(geom + id)[part];
-        reinterpret_cast<uint4*>(out + i)[part] = v;
-    }
-}
-
-template <int CAP, int NT>
-__global__ void __launch_bounds__(NT)
-gsr_tile_sort_lds(const uint32_t* __restrict__ tile_off, const unsigned long long* __restrict__ entries,
-                  const SplatRec* __restrict__ geom, SplatRec* __restrict__ out,
-                  uint32_t lo_excl, uint32_t hi_incl) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem_raw);
-    const uint32_t s = tile_off[blockIdx.x];
-    const uint32_t n = tile_off[blockIdx.x + 1] - s;
-    if (n <= lo_excl || n > hi_incl) return;
-    for (uint32_t i = threadIdx.x; i < n; i += NT) keys[i] = entries[s + i];
-    __syncthreads();
-    bitonic_sort(keys, n, NT);
-    gather_records(keys, n, geom, out + s, NT);
-}
-
-// fallback for lists longer than the LDS capacity: same network, in place in HBM
-extern "C" __global__ void __launch_bounds__(1024)
-gsr_tile_sort_global(const uint32_t* __restrict__ tile_off, unsigned long long* __restrict__ entries,
-                     const SplatRec* __restrict__ geom, SplatRec* __restrict__ out,
-                     uint32_t lo_excl) {
-    const uint32_t s = tile_off[blockIdx.x];
-    const uint32_t n = tile_off[blockIdx.x + 1] - s;
-    if (n <= lo_excl) return;
-    bitonic_sort(entries + s, n, 1024);
-    gather_records(entries + s, n, geom, out + s, 1024);
-}
-
-
 // ---------------------------------------------------------------------------------------
-// K4b: per-tile BUCKET sort (default). The bitonic network above costs log^2 passes over LDS
+// K4: per-tile BUCKET sort. The bitonic network above costs log^2 passes over LDS
 // (105 barrier-separated passes for 8k keys). Depth keys of one tile are spread smoothly
 // between the tile's nearest and farthest Gaussian, so one counting pass into ~n/4 buckets
 // by linearly quantised depth (monotone => bucket order = depth order) followed by an
 // insertion sort of each few-element bucket on the full 64-bit key (depth bits, then index:
 // the same total order as the network) is O(n). A tile whose keys pile up in one bucket
 // (max bucket > kBucketLimit, e.g. thousands of equal depths) falls back to the network.
-// Output: the tile's Gaussian indices in final order (out_ids) and/or its 64-byte record
-// stream (out_recs).
+// Output: the tile's Gaussian indices in final order (out_ids).
 // dynamic LDS: u64 keys[CAP] | u32 off[NBMAX+1] | u32 cur[NBMAX] | u32 red[40]
 // ---------------------------------------------------------------------------------------
 constexpr uint32_t kBucketLimit = 64;
@@ -310,7 +269,6 @@ __device__ __forceinline__ void block_excl_scan_u32(uint32_t* a, int n, uint32_t
 template <int CAP, int NT, int NBMAX>
 __global__ void __launch_bounds__(NT)
 gsr_tile_sort_bucket(const uint32_t* __restrict__ tile_off, const unsigned long long* __restrict__ entries,
-                     const SplatRec* __restrict__ geom, SplatRec* __restrict__ out_recs,
                      uint32_t* __restrict__ out_ids, uint32_t lo_excl, uint32_t hi_incl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem_raw);
@@ -377,28 +335,20 @@ gsr_tile_sort_bucket(const uint32_t* __restrict__ tile_off, const unsigned long 
         bitonic_sort(keys, n, NT);
     }
     (void)wave;
-    if (out_ids) for (uint32_t i = threadIdx.x; i < n; i += NT) out_ids[s + i] = (uint32_t)keys[i];
-    if (out_recs) gather_records(keys, n, geom, out_recs + s, NT);
+    for (uint32_t i = threadIdx.x; i < n; i += NT) out_ids[s + i] = (uint32_t)keys[i];
 }
 
 // lists longer than the largest LDS class: network in place in HBM, then the same outputs
 extern "C" __global__ void __launch_bounds__(1024)
 gsr_tile_sort_global_ids(const uint32_t* __restrict__ tile_off, unsigned long long* __restrict__ entries,
-                         const SplatRec* __restrict__ geom, SplatRec* __restrict__ out_recs,
                          uint32_t* __restrict__ out_ids, uint32_t lo_excl) {
     const uint32_t s = tile_off[blockIdx.x];
     const uint32_t n = tile_off[blockIdx.x + 1] - s;
     if (n <= lo_excl) return;
     bitonic_sort(entries + s, n, 1024);
-    if (out_ids) for (uint32_t i = threadIdx.x; i < n; i += 1024) out_ids[s + i] = (uint32_t)entries[s + i];
-    if (out_recs) gather_records(entries + s, n, geom, out_recs + s, 1024);
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) out_ids[s + i] = (uint32_t)entries[s + i];
 }
 
-template __global__ void gsr_tile_sort_bucket<2048, 256, 512>(const uint32_t*, const unsigned long long*, const SplatRec*, SplatRec*, uint32_t*, uint32_t, uint32_t);
-template __global__ void gsr_tile_sort_bucket<8192, 1024, 2048>(const uint32_t*, const unsigned long long*, const SplatRec*, SplatRec*, uint32_t*, uint32_t, uint32_t);
-template __global__ void gsr_tile_sort_bucket<16384, 1024, 2048>(const uint32_t*, const unsigned long long*, const SplatRec*, SplatRec*, uint32_t*, uint32_t, uint32_t);
-
-template __global__ void gsr_tile_sort_lds<2048, 256>(const uint32_t*, const unsigned long long*,
-                                                      const SplatRec*, SplatRec*, uint32_t, uint32_t);
-template __global__ void gsr_tile_sort_lds<16384, 1024>(const uint32_t*, const unsigned long long*,
-                                                        const SplatRec*, SplatRec*, uint32_t, uint32_t);
+template __global__ void gsr_tile_sort_bucket<2048, 256, 512>(const uint32_t*, const unsigned long long*, uint32_t*, uint32_t, uint32_t);
+template __global__ void gsr_tile_sort_bucket<8192, 1024, 2048>(const uint32_t*, const unsigned long long*, uint32_t*, uint32_t, uint32_t);
+template __global__ void gsr_tile_sort_bucket<16384, 1024, 2048>(const uint32_t*, const unsigned long long*, uint32_t*, uint32_t, uint32_t);

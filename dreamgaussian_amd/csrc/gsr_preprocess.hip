@@ -221,7 +221,7 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
                    SplatRec* __restrict__ recs, EmitRec* __restrict__ emit,
                    int32_t* __restrict__ radii, uint32_t* __restrict__ tile_count,
                    unsigned long long* __restrict__ block_stats /*[grid][2]: M_ref, V per workgroup*/,
-                   int hist_in_lds, int sh_direct, int dbg /* timing experiments: 1 no tile loop, 2 no stores, 4 no colour */,
+                   int hist_in_lds, int sh_direct,
                    uint8_t* __restrict__ flags8 /* colour-clamp bits for K6: 1 B instead of a 64-B record line */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_pp[];
     const int nTiles = vc.gx * vc.gy;
@@ -231,7 +231,7 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
     // sh_direct: every lane reads its own SH row with 16-byte loads (no LDS transpose): LDS then
     // only holds the tile histogram and ~4x more waves fit on a CU -- the kernel is latency-bound
     // (PMC: 79% of wave cycles waiting at 2 waves/SIMD with the 50 KiB staging buffer).
-    const bool stage = (shs != nullptr) && (K > 1) && !sh_direct && !(dbg & 8);   // dbg 8: no SH traffic at all
+    const bool stage = (shs != nullptr) && (K > 1) && !sh_direct;
 
     if (hist_in_lds) {
         for (int t = threadIdx.x; t < nTiles; t += blockDim.x) hist[t] = 0;
@@ -328,7 +328,7 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
                         dx *= inv; dy *= inv; dz *= inv;
                         float B[16];
                         sh_basis(vc.sh_degree, dx, dy, dz, B);
-                        const int nb = (dbg & 12) ? 0 : (vc.sh_degree + 1) * (vc.sh_degree + 1);
+                        const int nb = (vc.sh_degree + 1) * (vc.sh_degree + 1);
                         const float* row = stage ? (shbuf + threadIdx.x * (rowlen + 1)) : (shs + (size_t)idx * rowlen);
                         float coef[48];
                         if (!stage && (rowlen & 3) == 0) {          // 16-byte aligned rows: wide loads
@@ -378,7 +378,7 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
                             ey1 = min(ry1, min(iby1, vc.H - 1) / GSR_TILE + 1);
                         }
                     }
-                    if (ex1 > ex0 && ey1 > ey0 && !(dbg & 1)) {
+                    if (ex1 > ex0 && ey1 > ey0) {
                         // tile-exact emission for small rects: keep a tile only if alpha can reach
                         // 1/255 on one of its pixels (bit mask travels to the scatter kernel)
                         const bool masked = (ex1 - ex0) * (ey1 - ey0) <= GSR_EMIT_MASK_TILES;
@@ -410,7 +410,6 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
         }
         radii[idx] = radius_out;
         flags8[idx] = (uint8_t)rec.flags;
-        if (dbg & 2) { if (rec.x == 12345.678f) radii[idx] = 7; continue; }
         reinterpret_cast<uint4*>(recs + idx)[0] = reinterpret_cast<uint4*>(&rec)[0];
         reinterpret_cast<uint4*>(recs + idx)[1] = reinterpret_cast<uint4*>(&rec)[1];
         reinterpret_cast<uint4*>(recs + idx)[2] = reinterpret_cast<uint4*>(&rec)[2];
@@ -595,7 +594,7 @@ gsr_preprocess_bwd(ViewConst vc, int N, int K,
             const Proj2D pj = project_cov(vc, V, pv, S);
             const float a = pj.a, b = pj.b, c = pj.c;
             const float det = a * c - b * b;
-            const float d2i = 1.f / (det * det);
+            const float d2i = 1.f / (det * det + 0.0000001f);   // the external package's guard (denom2inv); det >= 0.09 for PSD covariances
             const float gA = g[2], gB = g[3], gC = g[4];
             const float dLa = d2i * (-c * c * gA + b * c * gB - b * b * gC);
             const float dLb = d2i * (2.f * b * c * gA - (a * c + b * b) * gB + 2.f * a * b * gC);

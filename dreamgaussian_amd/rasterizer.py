@@ -38,6 +38,10 @@ class GaussianRasterizationSettings(NamedTuple):
 
 
 _last_stats = {}
+# The backward normally hands the forward's GsrStats back to gsr_backward (no host round trip). Setting this
+# to False exercises the ABI's other documented mode (fwd_stats == NULL: the library reads the counters back
+# from the device, blocking) -- used by tests/test_parity_gpu.py.
+_pass_fwd_stats = True
 
 
 def last_stats() -> dict:
@@ -124,8 +128,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.fwd_stats = stats
         ctx.present = (shc is not None, col is not None, sc is not None, cov is not None)
         empty = torch.empty(0, device=dev)
-        ctx.save_for_backward(m3, shc if shc is not None else empty, col if col is not None else empty,
-                              op if op is not None else empty, sc if sc is not None else empty,
+        ctx.save_for_backward(m3 if m3 is not None else empty, shc if shc is not None else empty,
+                              col if col is not None else empty, op if op is not None else empty, sc if sc is not None else empty,
                               rot if rot is not None else empty, cov if cov is not None else empty,
                               radii, geom.tensor, binb.tensor, img.tensor)
         ctx.shapes = (means3D.shape, means2D.shape, None if sh is None else sh.shape,
@@ -143,7 +147,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         has_sh, has_col, has_sr, has_cov = ctx.present
         N, K = ctx.dims
         rs = ctx.raster_settings
-        dev = m3.device
+        dev = radii.device                 # (m3 is an empty placeholder when N == 0)
         H, W = int(rs.image_height), int(rs.image_width)
         z = lambda g, shape: (torch.zeros(shape, dtype=torch.float32, device=dev) if g is None
                               else g.to(torch.float32).contiguous())
@@ -174,7 +178,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                     C.byref(view), N, K, P(m3), P(shc) if has_sh else None, P(col) if has_col else None,
                     P(op), P(sc) if has_sr else None, P(rot) if has_sr else None,
                     P(cov) if has_cov else None, P(radii), P(gc), P(gd), P(ga),
-                    P(geom), P(binb), P(img), C.byref(ctx.fwd_stats), P(d_m3), P(d_m2), P(d_sh), P(d_col), P(d_op),
+                    P(geom), P(binb), P(img), C.byref(ctx.fwd_stats) if _pass_fwd_stats else None, P(d_m3), P(d_m2), P(d_sh), P(d_col), P(d_op),
                     P(d_sc), P(d_rot), P(d_cov), tmp.alloc, stream)
             tmp.release()
             _lib.check(rc, "gsr_backward")

@@ -106,3 +106,48 @@ def assert_grads_close(hg, og, aux=None, rtol=GRAD_RTOL, floors=None):
                 f"d{k}: max abs err {strict.max().item():.3e} vs {rtol:.0e} * scale {scale:.3e}"
         if err.numel():
             assert err.max().item() <= FRAGILE_GRAD_REL * scale + 1e-9, f"d{k}: fragile row err {err.max().item():.3e}"
+
+
+# ---- bounded fragile set -----------------------------------------------------
+ONE_FLIP_ALPHA = (1.0 / 255.0) / (1.0 - 1.0 / 255.0) * 1.02     # |d alpha| of ONE flipped alpha >= 1/255 decision (T <= 1)
+
+
+def fragile_report(ho, oo, hg, og, aux, sc=None, floors=None):
+    """How much of the oracle-flagged (ambiguous-decision) set actually differs, and by how much.
+    Returns a dict; the callers assert caps on it. A flagged pixel that misses the strict bound must look
+    like ONE flipped decision: |d alpha| <= ONE_FLIP_ALPHA and |d colour| <= ONE_FLIP_ALPHA * max colour."""
+    floors = floors or {}
+    fp = torch.as_tensor(aux["fragile_pixels"]).bool()
+    fg = torch.as_tensor(aux["fragile_gaussians"]).bool()
+    err_c = (ho[0].double() - oo[0].double()).abs().amax(0)
+    err_a = (ho[3].double() - oo[3].double()).abs()[0]
+    bad = ((err_c > FWD_ATOL) | (err_a > FWD_ATOL)) & fp
+    cmax = max(1.0, float(aux["pre"]["color"].max())) if "pre" in aux else 1.0
+    worst_a = float(err_a[bad].max()) if bad.any() else 0.0
+    worst_c = float(err_c[bad].max()) if bad.any() else 0.0
+    beyond_one = int((bad & ((err_a > ONE_FLIP_ALPHA + FWD_ATOL) | (err_c > ONE_FLIP_ALPHA * cmax + FWD_ATOL))).sum())
+    rows_bad = 0
+    worst_rel = 0.0
+    for k, ref in og.items():
+        ref = ref.double()
+        got = hg[k].double().reshape(ref.shape)
+        scale = max(ref.abs().max().item(), floors.get(k, 0.0)) + 1e-300
+        err = (got - ref).abs().reshape(ref.shape[0], -1).max(1).values / scale
+        rows_bad = max(rows_bad, int(((err > GRAD_RTOL) & fg).sum()))
+        if (fg & (err > GRAD_RTOL)).any():
+            worst_rel = max(worst_rel, float(err[fg].max()))
+    return dict(flagged_pixels=int(fp.sum()), flagged_gaussians=int(fg.sum()),
+                flagged_pixels_different=int(bad.sum()), beyond_one_flip=beyond_one, worst_dalpha=worst_a, worst_dcolor=worst_c, cmax=cmax,
+                flagged_gaussians_different=rows_bad, worst_grad_rel=worst_rel)
+
+
+def assert_fragile_bounded(rep, n_pixels, n_gauss):
+    """caps: at most 2e-4 of the pixels / Gaussians (>= 8) may be flagged AND different; a different pixel is
+    within ONE flipped decision, except for at most max(2, 1e-5 P) pixels that may hold two."""
+    cap_p = max(8, int(2e-4 * n_pixels))
+    cap_g = max(8, int(2e-4 * n_gauss))
+    assert rep["flagged_pixels_different"] <= cap_p, rep
+    assert rep["flagged_gaussians_different"] <= cap_g, rep
+    assert rep["beyond_one_flip"] <= max(2, int(1e-5 * n_pixels)), rep
+    assert rep["worst_dalpha"] <= 2 * ONE_FLIP_ALPHA + FWD_ATOL, rep
+    assert rep["worst_dcolor"] <= 2 * ONE_FLIP_ALPHA * rep["cmax"] + FWD_ATOL, rep
