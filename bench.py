@@ -1,8 +1,10 @@
 #!/usr/bin/env python
 """bench.py -- Mrays/s (fwd+bwd) of the MI355X splat rasterizer on BASELINE.json's workloads.
 
-  python bench.py [--gpus N --steps K --warmup W] [--workload 1M-800-sh3] [--kind blob]
+  python bench.py [--gpus N --steps K --warmup W] [--workload 1M-800-sh3] [--kind blob] [--step render|sds]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  (`--gpus N` without a launcher's RANK/WORLD_SIZE in the environment spawns the N ranks itself through
+  torch.distributed.run on 127.0.0.1, and fails loudly when the box has fewer than N GPUs.)
 
 A step = one forward + one backward of the rasterizer (through the drop-in
 `GaussianRasterizer` autograd surface, i.e. the path gs_renderer.py:800-809 / main.py:273
@@ -10,6 +12,10 @@ take) for ONE camera over the synthetic scene, inputs and dL/d{color,depth,alpha
 resident in HBM. With N>1 every rank renders its own orbit camera of the same (replicated)
 scene -- the view-parallel mode of SURVEY 8(e) -- and rank 0 gathers the N images with RCCL
 inside the timed region; per-GPU work is fixed ("weak" scaling), value = total rays / time.
+`--step sds` times the whole exchange of DreamGaussian's multi-view SDS step (main.py:219-275) on
+BASELINE configs[3] (250k Gaussians, 512x512, one view per GPU): render, RCCL gather of the images to
+rank 0, scatter of dL/dimage back, local backward, bucketed all-reduce of the per-Gaussian gradients.
+With N>1 the default run appends that measurement to the same JSON line ("sds_step").
 
 One JSON line on stdout (rank 0). Besides the driver's contract it carries
   roofline      the dominant kernel's algorithmic bytes / its hipEvent-measured duration
@@ -74,52 +80,144 @@ def build_inputs(wl, kind, dev, azimuth):
     return sc, rs_cpu, rs, grads
 
 
-def cpu_baseline(sc, rs_cpu, grads, budget_s=15.0, max_threads=16):
-    """CPU oracle on a bounded sample of the SAME scene/camera/loss: the per-Gaussian stage and
-    the binning run in full (they define the tile lists), compositing fwd+bwd runs on a strided
-    subset of the non-empty 16x16 tiles sized to ~budget_s; the whole-frame time is estimated by
-    scaling the measured composite time with the (instance x pixel) pair count.
-    kind 'port': the reference has no CPU path and its CUDA extension is absent."""
+def _cpu_worker(job, threads=1):
+    """One process of the CPU baseline: compositing fwd+bwd of a strided subset of the non-empty tiles,
+    one torch thread (the oracle's per-tile Python loop does not scale across threads)."""
+    wl, kind, azimuth, tiles, seed_w = job
+    import torch as _t
+    _t.set_num_threads(threads)
     from oracle import gs_oracle as O
-    nthreads = max(1, min(os.cpu_count() or 1, max_threads))   # torch CPU ops stop scaling well before 256 threads
-    torch.set_num_threads(nthreads)
+    from dreamgaussian_amd import synthetic as syn
+    sc = syn.make_scene(wl["N"], wl["deg"], 0, kind)
+    rs_cpu = syn.make_settings(syn.orbit_pose(0.0, azimuth, 2.0), wl["W"], wl["H"], sh_degree=wl["deg"])
+    g = _t.Generator().manual_seed(seed_w)
+    H, W = wl["H"], wl["W"]
+    grads = [_t.rand(3, H, W, generator=g), _t.rand(1, H, W, generator=g), _t.rand(1, H, W, generator=g)]
     S = O.Settings(*rs_cpu)
-    H, W = int(S.image_height), int(S.image_width)
-
-    def run(tiles):
-        t = {k: v.detach().clone().requires_grad_(True) for k, v in sc.items()}
-        O.TIMERS["composite_fwd"] = O.TIMERS["composite_bwd"] = 0.0
-        t0 = time.perf_counter()
-        c, r, d, a, aux = O.rasterize(t["means3D"], None, t["opacities"], S, shs=t["shs"],
-                                      scales=t["scales"], rotations=t["rotations"],
-                                      return_aux=True, tiles=tiles)
-        torch.autograd.backward([c, d, a], grads)
-        total = time.perf_counter() - t0
-        comp = O.TIMERS["composite_fwd"] + O.TIMERS["composite_bwd"]
-        return total - comp, comp, aux
-
-    # probe: two tiles -> seconds per (instance x pixel) pair; also times the per-Gaussian stage
-    t_pg, _, aux = run([])
+    t = {k: v.detach().clone().requires_grad_(True) for k, v in sc.items()}
+    O.TIMERS["composite_fwd"] = O.TIMERS["composite_bwd"] = 0.0
+    t0 = time.perf_counter()
+    c, r, d, a, aux = O.rasterize(t["means3D"], None, t["opacities"], S, shs=t["shs"], scales=t["scales"],
+                                  rotations=t["rotations"], return_aux=True, tiles=tiles)
+    _t.autograd.backward([c, d, a], grads)
+    total = time.perf_counter() - t0
+    comp = O.TIMERS["composite_fwd"] + O.TIMERS["composite_bwd"]
     ranges = aux["ranges"]
-    cnt = ranges[1:] - ranges[:-1]
-    nonempty = [int(t) for t in range(len(cnt)) if cnt[t] > 0]
-    total_pairs = float(cnt.sum()) * 256.0
+    return total - comp, comp, (ranges[1:] - ranges[:-1]).tolist()
+
+
+def cpu_baseline(wl, kind, azimuth, budget_s=20.0, procs=None):
+    """CPU oracle (kind 'port': the reference has no CPU path and its CUDA extension is absent, SURVEY
+    0.1/0.4) on the SAME scene/camera/loss. The per-Gaussian stage + binning (fwd+bwd) is timed in this
+    process on <= 16 torch threads (torch CPU ops stop scaling there); compositing fwd+bwd runs in `procs`
+    single-threaded worker processes (the oracle's per-tile loop), each on a strided share of a tile sample
+    sized to ~budget_s per worker. Frame time = t(per-Gaussian stage) + slowest worker's composite time
+    scaled to all instance-pixel pairs; cores = the larger of the two process/thread counts."""
+    import multiprocessing as mp
+    ncpu = os.cpu_count() or 1
+    procs = procs or max(1, min(32, ncpu // 2))
+    nthreads = max(1, min(16, ncpu))
+    torch.set_num_threads(nthreads)
+    t_pg, _, cnt = _cpu_worker((wl, kind, azimuth, [], 1), threads=nthreads)
+    nonempty = [t for t, c in enumerate(cnt) if c > 0]
+    H, W = wl["H"], wl["W"]
     if not nonempty:
         return dict(value=H * W / t_pg / 1e6, unit="Mrays/s", cores=nthreads, kind="port", sample="empty scene")
-    probe = [nonempty[len(nonempty) // 3], nonempty[(2 * len(nonempty)) // 3]]
-    _, c_probe, _ = run(probe)
-    per_pair = max(c_probe, 1e-4) / (float(sum(cnt[t] for t in probe)) * 256.0)
-    stride = max(1, int(round(total_pairs * per_pair / budget_s)))
-    tiles = nonempty[::stride]
-    t_pg2, t_comp, _ = run(tiles)
-    t_pg = min(t_pg, t_pg2)
-    pairs_s = float(sum(cnt[t] for t in tiles)) * 256.0
+    total_pairs = float(sum(cnt)) * 256.0
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(procs) as pool:
+        probe = [nonempty[len(nonempty) // 3], nonempty[(2 * len(nonempty)) // 3]]
+        _, c_probe, _ = pool.apply(_cpu_worker, ((wl, kind, azimuth, probe, 1),))
+        per_pair = max(c_probe, 1e-4) / (float(sum(cnt[t] for t in probe)) * 256.0)
+        stride = max(1, int(round(total_pairs * per_pair / (budget_s * procs))))
+        sample = nonempty[::stride]
+        jobs = [(wl, kind, azimuth, sample[w::procs], 1) for w in range(procs) if sample[w::procs]]
+        res = pool.map(_cpu_worker, jobs)
+    t_comp = max(r[1] for r in res)
+    pairs_s = float(sum(cnt[t] for t in sample)) * 256.0
     t_full = t_pg + t_comp * total_pairs / pairs_s
-    return dict(value=H * W / t_full / 1e6, unit="Mrays/s", cores=nthreads, kind="port",
-                sample=(f"oracle fwd+bwd, same scene/camera/loss, {nthreads} torch threads of {os.cpu_count()} "
-                        f"host cores: per-Gaussian stage + binning in full ({t_pg:.1f} s), compositing on "
-                        f"{len(tiles)} of {len(nonempty)} non-empty tiles ({100.0 * pairs_s / total_pairs:.1f}% of "
-                        f"instance-pixel pairs, {t_comp:.1f} s), frame time scaled by pair count to {t_full:.0f} s"))
+    return dict(value=H * W / t_full / 1e6, unit="Mrays/s", cores=max(procs, nthreads), kind="port",
+                sample=(f"oracle fwd+bwd, same scene/camera/loss, on {ncpu} host cores: per-Gaussian stage + binning "
+                        f"in full on {nthreads} torch threads ({t_pg:.1f} s); compositing in {len(jobs)} single-threaded "
+                        f"processes on {len(sample)} of {len(nonempty)} non-empty tiles ({100.0 * pairs_s / total_pairs:.1f}% "
+                        f"of instance-pixel pairs, slowest worker {t_comp:.1f} s); frame time scaled by pair count "
+                        f"to {t_full:.1f} s"))
+
+
+def spawn_ranks(n):
+    """`--gpus n` without a launcher: run torch.distributed.run ourselves (one process per GPU, 127.0.0.1)."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n:
+        raise SystemExit(f"bench.py --gpus {n}: this box has {have} GPU(s); refusing to measure fewer ranks than asked")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))
+
+
+def run_sds(a, dev, rank, world):
+    """The multi-view SDS exchange (main.py:219-275) on BASELINE configs[3]: 250k Gaussians, SH degree 0,
+    512x512, ONE orbit view per GPU. Timed region of a step, on every rank: forward of the own view, RCCL
+    gather of the [5,H,W] images to rank 0, the image-space loss gradient on rank 0 (an elementwise surrogate of
+    the guidance: the real one is a diffusion UNet and is out of scope), scatter of dL/dimage, local backward,
+    bucketed all-reduce of the per-Gaussian gradients (every rank then holds the summed gradient and can take
+    the identical Adam step: no parameter broadcast). Returns the result dict (rank 0) or None."""
+    import torch.distributed as dist
+    import dreamgaussian_amd as D
+    from dreamgaussian_amd import views
+    wl = WORKLOADS["250k-512-sh0"]
+    azimuth = 360.0 * rank / max(world, 1)
+    sc, _, rs, _ = build_inputs(wl, a.kind, dev, azimuth)
+    t = {k: v.to(dev).requires_grad_(True) for k, v in sc.items()}
+    m2d = torch.zeros(wl["N"], 3, device=dev, requires_grad=True)
+    rast = D.GaussianRasterizer(raster_settings=rs)
+    H, W = wl["H"], wl["W"]
+    wimg = torch.rand(world, 5, H, W, generator=torch.Generator().manual_seed(7)).to(dev) if rank == 0 else None
+    params = list(t.values())
+
+    def step():
+        for v in params:
+            v.grad = None
+        m2d.grad = None
+        color, radii, depth, alpha = rast(means3D=t["means3D"], means2D=m2d, shs=t["shs"], colors_precomp=None,
+                                          opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"],
+                                          cov3D_precomp=None)
+        local = torch.cat([color, depth, alpha], 0).unsqueeze(0)              # [1,5,H,W], differentiable
+        batch = views.gather_images(local.detach(), dst=0, num_views=world)
+        gw = (batch - 0.5) * wimg if rank == 0 else None                     # d(surrogate loss)/d(images) on rank 0
+        g_local = views.scatter_view_grads(gw, local, src=0, num_views=world)
+        torch.autograd.backward([local], [g_local])
+        views.allreduce_grads(params)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        td = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(td, op=dist.ReduceOp.MAX)
+        dt = float(td.item())
+    if rank != 0:
+        return None
+    st = D.last_stats()
+    grad_bytes = sum(p.numel() * 4 for p in params)
+    return {"workload": f"BASELINE.json configs[3]: {wl['N']} Gaussians, SH degree {wl['deg']}, {W}x{H}, one orbit view per "
+                        f"GPU ({world} views), scene '{a.kind}'",
+            "timed": "fwd + RCCL gather(images) + loss grad on rank 0 + scatter(dL/dimage) + bwd + bucketed all-reduce(grads)",
+            "value": round(H * W * world * a.steps / dt / 1e6, 3), "unit": "Mrays/s", "ms_per_step": round(dt / a.steps * 1e3, 4),
+            "views_per_step": world, "image_bytes_per_view": 5 * H * W * 4, "allreduce_bytes": grad_bytes,
+            "M": st.get("M_ref"), "M_emitted": st.get("M")}
 
 
 def main():
@@ -129,7 +227,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="1M-800-sh3", choices=sorted(WORKLOADS))
     ap.add_argument("--kind", default="blob", choices=["blob", "trained"])
-    ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-oracle compositing; 0 disables")
+    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-oracle compositing per worker; 0 disables")
+    ap.add_argument("--step", default="render", choices=["render", "sds"],
+                    help="render = rasterizer fwd+bwd (+ RCCL gather of the images when N>1): the headline metric; "
+                         "sds = the multi-view SDS exchange on BASELINE configs[3] (see the module docstring)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--trace-steps", action="store_true", help="print every timed step's wall time to stderr")
     ap.add_argument("--views", type=int, default=1,
@@ -145,10 +246,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    if a.gpus > 1 and "RANK" not in os.environ:
+        spawn_ranks(a.gpus)                      # does not return
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -159,6 +264,20 @@ def main():
     import dreamgaussian_amd as D
     from dreamgaussian_amd import _lib, views
 
+    if a.step == "sds":
+        res = run_sds(a, dev, rank, world)
+        if rank == 0:
+            out = {"metric": "Mrays/s (multi-view SDS step, fwd+bwd+exchange)", "value": res["value"], "unit": "Mrays/s",
+                   "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": res["ms_per_step"],
+                   "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                   "config": {"workload": res["workload"], "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU",
+                              "timed": res["timed"], "allreduce_bytes": res["allreduce_bytes"],
+                              "image_bytes_per_view": res["image_bytes_per_view"], "M": res["M"], "M_emitted": res["M_emitted"]},
+                   "roofline": None, "cpu_baseline": None}
+            print(json.dumps(out), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     wl = WORKLOADS[a.workload]
     K = (wl["deg"] + 1) ** 2
     azimuth = 360.0 * rank / max(world, 1)          # rank r renders orbit view r
@@ -276,22 +395,31 @@ def main():
         ab = alg_bytes(wl["N"], K, st["V"], st["M_ref"], P)
         per_step = {k: v[0] / a.steps for k, v in kern.items()}
         dom = max(per_step, key=per_step.get)
-        traffic = None
+        # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate passes,
+        # MI355X_MICROARCH.md HBM section; tools/pmc_summary.py -> profiles/pmc_traffic.json). The file carries
+        # the digest of the kernel sources it was collected with: a stale file reads as null, never as a number.
+        traffic, traffic_note = None, "not collected"
         tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tf):
             try:
-                # HBM bytes per launch from committed rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE;
-                # read side doubled as MI355X_MICROARCH.md's HBM section prescribes for gfx950):
-                # tools/pmc_summary.py -> profiles/pmc_traffic.json; null if not collected
-                traffic = json.load(open(tf)).get(f"{a.workload}/{a.kind}", {}).get(dom, {}).get("hbm_bytes")
+                from dreamgaussian_amd import build as _build
+                tj = json.load(open(tf))
+                if tj.get("source_digest") == _build._digest():
+                    traffic = tj.get(f"{a.workload}/{a.kind}", {}).get(dom, {}).get("hbm_bytes")
+                    traffic_note = tj.get("note", "rocprofv3 PMC, same kernel sources")
+                else:
+                    traffic_note = "profiles/pmc_traffic.json was collected with other kernel sources"
             except Exception:
                 traffic = None
         if dom in ab:
             ach = ab[dom] / (per_step[dom] * 1e-3) / 1e9
+            ab_emit = alg_bytes(wl["N"], K, st["V"], st["M"], P)       # priced with the lists the kernels really walk
             roof = dict(bound="hbm", kernel=dom, achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(ach / HBM_PEAK_GBS, 5), traffic=traffic,
-                        alg_bytes_per_launch=ab[dom], avg_launch_ms=round(per_step[dom], 4),
-                        launches_per_step=1)
+                        frac=round(ach / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_note,
+                        alg_bytes_per_launch=ab[dom], instances_priced="M_ref (reference emission rule, SURVEY 8(d))",
+                        alg_bytes_per_launch_emitted=ab_emit[dom],
+                        frac_emitted=round(ab_emit[dom] / (per_step[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                        avg_launch_ms=round(per_step[dom], 4), launches_per_step=1)
         ach_p = ab["total"] / (dt / a.steps) / 1e9
         path_roof = dict(bound="hbm", achieved=round(ach_p, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                          frac=round(ach_p / HBM_PEAK_GBS, 5), alg_bytes_per_step=ab["total"],
@@ -299,9 +427,15 @@ def main():
     if world > 1:
         dist.barrier()
 
+    sds = None
+    if world > 1 and a.views == 1 and a.activations == "none":
+        for v in list(t.values()) + [m2d]:         # release the headline scene before the second measurement
+            v.grad = None
+        sds = run_sds(a, dev, rank, world)
+
     cpu = None
     if rank == 0 and world == 1 and a.cpu_budget > 0:
-        cpu = cpu_baseline(sc, rs_cpu, grads_cpu, a.cpu_budget)
+        cpu = cpu_baseline(wl, a.kind, azimuth, a.cpu_budget)
         cpu["value"] = float(f"{cpu['value']:.4g}")
 
     if rank == 0:
@@ -321,6 +455,8 @@ def main():
             "kernels_ms_per_step": {k: round(v[0] / a.steps, 4) for k, v in sorted(kern.items())},
             "ms_per_step_with_events": None if dt_prof is None else round(dt_prof / a.steps * 1e3, 4),
         }
+        if sds is not None:
+            out["sds_step"] = sds
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

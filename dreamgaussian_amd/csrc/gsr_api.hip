@@ -202,11 +202,12 @@ int seg_shift() {
     }();
     return v;
 }
-enum BwdKernel { kBwdF2b = 0, kBwdQ2 = 1, kBwdQuad = 2 };
+enum BwdKernel { kBwdF2b = 0, kBwdQ2 = 1, kBwdQuad = 2, kBwdQ2P = 3 };
 int bwd_kernel() {
     static const int v = [] {
         const char* e = getenv("GSR_BWD");
         if (e && strcmp(e, "q2") == 0) return (int)kBwdQ2;
+        if (e && strcmp(e, "q2p") == 0) return (int)kBwdQ2P;
         if (e && strcmp(e, "quad") == 0) return (int)kBwdQuad;
         if (e && strcmp(e, "f2b") == 0) return (int)kBwdF2b;
         return (int)GSR_BWD_DEFAULT;
@@ -540,7 +541,8 @@ extern "C" int gsr_backward(const GsrView* view, int32_t N, int32_t K,
                            final_T, n_contrib, totals, ckpt, tile_seg, dL_dcolor, dL_ddepth, dL_dalpha, g2d, seg_shift(), \
                            plan_tile, plan_off, plan_total)
         switch (bwd_kernel()) {
-            case kBwdQ2: GSR_LAUNCH_BWD(gsr_render_bwd_q2); break;
+            case kBwdQ2: GSR_LAUNCH_BWD(gsr_render_bwd_q2<false>); break;
+            case kBwdQ2P: GSR_LAUNCH_BWD(gsr_render_bwd_q2<true>); break;
             case kBwdQuad: GSR_LAUNCH_BWD(gsr_render_bwd_f2b_quad); break;
             default: GSR_LAUNCH_BWD(gsr_render_bwd_f2b); break;
         }

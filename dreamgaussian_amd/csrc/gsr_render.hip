@@ -380,6 +380,7 @@ __device__ __forceinline__ float add_other_half(float v) {
     return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_ROW_ROR(8), 0xf, 0xf, false));
 }
 
+template <bool PREFETCH>   // PREFETCH: the next round's records are fetched while this round is processed
 __global__ void __launch_bounds__(256)
 gsr_render_bwd_q2(GSR_BWD_PARAMS) {
     __shared__ float4 stage[4][3][GSR_RB];                                   // 12 KiB staged records, slot = fetching lane
@@ -441,7 +442,7 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
         T = c[0];
         Cgf = c[256] * gC0 + c[512] * gC1 + c[768] * gC2 + c[1024] * gD + c[1280] * gA;
     }
-    const float bx0 = (float)bx, bx1 = (float)(bx + 4), by0 = (float)by, by1 = (float)(by + 4);
+    const float bx0 = (float)bx, by0 = (float)by;
     // pass 1 writes (m, w) of pixel l15 of entry k to mw1[k * KSTRIDE]; pass 2 lane (h2, k2) reads mw2[0..15]
     float* __restrict__ mw1 = &mw[wave][row][(l15 >> 3) * GSR_Q2_HSTRIDE + (l15 & 7) * 2];
     const int k2 = l15 & 7, h2 = l15 >> 3;
@@ -471,19 +472,35 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
         if (valid) *reinterpret_cast<float2*>(mw1 + (kslot) * GSR_Q2_KSTRIDE) = make_float2(m, w); \
     }
 
+    float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa, pc = pa;       // PREFETCH: records of the next round
+    if (PREFETCH && seg_lo + lane < seg_hi) {
+        const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + ids[start + seg_lo + lane]);
+        pa = p[0]; pb = p[1]; pc = p[2];
+    }
     for (uint32_t pos0 = seg_lo; pos0 < seg_hi; pos0 += GSR_RB) {   // 0-based positions pos0 .. pos0+63
         const uint32_t i = pos0 + lane;
         bool h0 = false, h1 = false, h2q = false, h3 = false;
         float4 ra, rb, rc;
+        if (PREFETCH) {
+            ra = pa; rb = pb; rc = pc;
+            if (i + GSR_RB < seg_hi) {
+                const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + ids[start + i + GSR_RB]);
+                pa = p[0]; pb = p[1]; pc = p[2];
+            }
+        }
         if (i < seg_hi) {
-            const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + ids[start + i]);
-            ra = p[0]; rb = p[1]; rc = p[2];
+            if (!PREFETCH) {
+                const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + ids[start + i]);
+                ra = p[0]; rb = p[1]; rc = p[2];
+            }
             const float thr = min_visible_power(rb.y);
             // exact ellipse-vs-quad support tests; an entry behind a quad's deepest contributor is never blended there
-            h0 = (i < ql0) && rect_max_power(ra.x, ra.y, ra.z, ra.w, rb.x, bx0, bx0 + 3.f, by0, by0 + 3.f) >= thr;
-            h1 = (i < ql1) && rect_max_power(ra.x, ra.y, ra.z, ra.w, rb.x, bx1, bx1 + 3.f, by0, by0 + 3.f) >= thr;
-            h2q = (i < ql2) && rect_max_power(ra.x, ra.y, ra.z, ra.w, rb.x, bx0, bx0 + 3.f, by1, by1 + 3.f) >= thr;
-            h3 = (i < ql3) && rect_max_power(ra.x, ra.y, ra.z, ra.w, rb.x, bx1, bx1 + 3.f, by1, by1 + 3.f) >= thr;
+            float qp[4];
+            quad_max_powers(ra.x, ra.y, ra.z, ra.w, rb.x, bx0, by0, qp);
+            h0 = (i < ql0) && qp[0] >= thr;
+            h1 = (i < ql1) && qp[1] >= thr;
+            h2q = (i < ql2) && qp[2] >= thr;
+            h3 = (i < ql3) && qp[3] >= thr;
         }
         const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2q), m3 = __ballot(h3);
         if ((m0 | m1 | m2 | m3) == 0ull) continue;
@@ -560,3 +577,5 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
 #undef GSR_Q2_ENTRY
     bwd_flush(acc, min(1u << seg_shift, n - seg_lo), start + seg_lo, recs, ids, g2d);
 }
+template __global__ void gsr_render_bwd_q2<false>(GSR_BWD_PARAMS);
+template __global__ void gsr_render_bwd_q2<true>(GSR_BWD_PARAMS);

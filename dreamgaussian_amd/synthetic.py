@@ -65,7 +65,7 @@ def make_settings(c2w, W, H, fovy_deg=49.1, znear=0.01, zfar=100.0, sh_degree=0,
 def nn3_mean_sqdist(xyz: np.ndarray) -> np.ndarray:
     """Host stand-in for distCUDA2 when building scenes (exact 3-NN mean squared distance)."""
     from scipy.spatial import cKDTree
-    d, _ = cKDTree(xyz).query(xyz, k=4)
+    d, _ = cKDTree(xyz).query(xyz, k=4, workers=-1)      # all host cores: 8 s -> ~1 s at 1M points
     return (d[:, 1:] ** 2).mean(1)
 
 

@@ -58,13 +58,29 @@ def gather_views_async(color: torch.Tensor, depth: torch.Tensor, alpha: torch.Te
         return dist.all_gather_into_tensor(full.view(-1), local.view(-1), group=group, async_op=True)
 
 
-def gather_images(local: torch.Tensor, dst: Optional[int] = 0, group=None) -> Optional[torch.Tensor]:
-    """local [b,C,H,W] (this rank's views, equal b on every rank) -> [b*world,C,H,W] in VIEW
-    order (view i = rank i % world, slot i // world) on `dst` (None = every rank)."""
+def views_on_rank(num_views: int, rank: int, world: int) -> int:
+    """How many of `num_views` round-robin views rank `rank` owns."""
+    return len(range(rank, num_views, world))
+
+
+def gather_images(local: torch.Tensor, dst: Optional[int] = 0, group=None,
+                  num_views: Optional[int] = None) -> Optional[torch.Tensor]:
+    """local [b,C,H,W] (this rank's views) -> [num_views,C,H,W] in VIEW order (view i = rank i % world,
+    slot i // world) on `dst` (None = every rank). `num_views` = total number of views; when it is not a
+    multiple of the world size the ranks hold unequal counts (rank r: views r, r+world, ...) and the
+    shorter ranks are padded for the collective. Default: b * world (equal counts)."""
     rank, world = _world(group)
     if world == 1:
         return local
+    b = int(local.shape[0])
+    if num_views is None:
+        num_views = b * world
+    bmax = (num_views + world - 1) // world
+    if b != views_on_rank(num_views, rank, world):
+        raise RuntimeError(f"rank {rank} holds {b} views, expected {views_on_rank(num_views, rank, world)} of {num_views}")
     local = local.contiguous()
+    if b < bmax:
+        local = torch.cat([local, local.new_zeros((bmax - b,) + tuple(local.shape[1:]))], 0)
     if dst is None:
         out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
         dist.all_gather([out[i] for i in range(world)], local, group=group)
@@ -74,25 +90,31 @@ def gather_images(local: torch.Tensor, dst: Optional[int] = 0, group=None) -> Op
         dist.gather(local, [out[i] for i in range(world)] if rank == dst else None, dst=dst, group=group)
         if rank != dst:
             return None
-    # [world, b, ...] -> view order: index = slot * world + rank
-    return out.transpose(0, 1).reshape((-1,) + tuple(local.shape[1:]))
+    # [world, bmax, ...] -> view order: index = slot * world + rank; padded slots are exactly the indices >= num_views
+    return out.transpose(0, 1).reshape((-1,) + tuple(local.shape[1:]))[:num_views]
 
 
 def scatter_view_grads(grad_all: Optional[torch.Tensor], like: torch.Tensor, src: int = 0,
-                       group=None) -> torch.Tensor:
-    """Inverse of gather_images for the backward: `grad_all` [b*world,C,H,W] in view order on
-    `src` -> this rank's [b,C,H,W] slice."""
+                       group=None, num_views: Optional[int] = None) -> torch.Tensor:
+    """Inverse of gather_images for the backward: `grad_all` [num_views,C,H,W] in view order on
+    `src` -> this rank's [b,C,H,W] slice (`like` gives its shape)."""
     rank, world = _world(group)
     if world == 1:
         return grad_all
-    out = torch.empty_like(like)
+    b = int(like.shape[0])
+    if num_views is None:
+        num_views = b * world
+    bmax = (num_views + world - 1) // world
+    out = like.new_empty((bmax,) + tuple(like.shape[1:]))
     if rank == src:
-        b = like.shape[0]
-        g = grad_all.reshape((b, world) + tuple(like.shape[1:])).transpose(0, 1).contiguous()
+        g = grad_all
+        if num_views < bmax * world:
+            g = torch.cat([g, g.new_zeros((bmax * world - num_views,) + tuple(g.shape[1:]))], 0)
+        g = g.reshape((bmax, world) + tuple(like.shape[1:])).transpose(0, 1).contiguous()
         dist.scatter(out, [g[i] for i in range(world)], src=src, group=group)
     else:
         dist.scatter(out, None, src=src, group=group)
-    return out
+    return out[:b]
 
 
 def allreduce_grads(params: Iterable[torch.Tensor], group=None, bucket_bytes: int = 64 << 20):

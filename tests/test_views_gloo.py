@@ -1,4 +1,4 @@
-"""View-parallel host logic (dreamgaussian_amd/views.py) on CPU: two gloo processes.
+"""View-parallel host logic (dreamgaussian_amd/views.py) on CPU: two and four gloo processes.
 Each rank renders its own camera (with the oracle standing in for the GPU rasterizer, as the
 checker) and the gathered batch / reduced gradients must equal the serial result."""
 import os
@@ -92,6 +92,63 @@ def test_two_rank_view_parallel_equals_serial():
     for k, v in sc.items():
         for r in (r0, r1):
             assert torch.allclose(r["grads"][k], v.grad, rtol=1e-4, atol=1e-6 * v.grad.abs().max().item()), k
+
+
+def _worker_ragged(rank, world, port, q, azs):
+    """The multi-view SDS step of main.py:219-275 over `world` ranks with UNEQUAL view counts: render own views,
+    gather to rank 0, loss gradient on rank 0, scatter, local backward, bucketed all-reduce."""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import gs_oracle as O
+        from dreamgaussian_amd import views
+        W, H = 24, 16
+        sc = {k: v.clone().requires_grad_(True) for k, v in O.make_scene(80, 0, 0, "trained").items()}
+        mine = views.shard_views(azs)
+        assert len(mine) == views.views_on_rank(len(azs), rank, world)
+        local = torch.stack([_render(az, sc, W, H) for az in mine]) if mine else torch.zeros(0, 5, H, W)
+        batch = views.gather_images(local.detach(), dst=0, num_views=len(azs))
+        gw = torch.rand(len(azs), 5, H, W, generator=torch.Generator().manual_seed(1))
+        g_local = views.scatter_view_grads(gw if rank == 0 else None, local, src=0, num_views=len(azs))
+        assert tuple(g_local.shape) == tuple(local.shape)
+        if mine:
+            torch.autograd.backward([local], [g_local])
+        for v in sc.values():                      # a rank without views still takes part in the all-reduce
+            if v.grad is None:
+                v.grad = torch.zeros_like(v)
+        views.allreduce_grads(list(sc.values()), bucket_bytes=1 << 9)
+        q.put(dict(rank=rank, batch=batch, grads={k: v.grad.clone() for k, v in sc.items()}))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("nviews", [6, 3], ids=["6_views_on_4_ranks", "3_views_on_4_ranks"])
+def test_four_rank_unequal_view_counts_equal_serial(nviews):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import gs_oracle as O
+    world, port = 4, _free_port()
+    azs = [360.0 * i / nviews for i in range(nviews)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_ragged, args=(r, world, port, q, azs)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda r: r["rank"])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    W, H = 24, 16
+    sc = {k: v.clone().requires_grad_(True) for k, v in O.make_scene(80, 0, 0, "trained").items()}
+    serial = torch.stack([_render(az, sc, W, H) for az in azs])
+    gw = torch.rand(nviews, 5, H, W, generator=torch.Generator().manual_seed(1))
+    torch.autograd.backward([serial], [gw])
+    assert torch.allclose(res[0]["batch"], serial.detach(), atol=1e-6) and all(r["batch"] is None for r in res[1:])
+    for k, v in sc.items():
+        for r in res:
+            assert torch.allclose(r["grads"][k], v.grad, rtol=1e-4, atol=1e-6 * v.grad.abs().max().item()), (k, r["rank"])
 
 
 def test_single_process_fallthrough():

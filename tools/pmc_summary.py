@@ -62,9 +62,17 @@ def main():
                 rd_raw, wr = row["FETCH_SIZE"] * 1024.0, row["WRITE_SIZE"] * 1024.0
                 traffic[fam] = {"read_bytes_raw": rd_raw, "read_bytes_x2": 2 * rd_raw, "write_bytes": wr,
                                 "hbm_bytes": 2 * rd_raw + wr}
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from dreamgaussian_amd import build as _build
+        dig = _build._digest()
         doc = {}
         if os.path.exists(path):
             doc = json.load(open(path))
+            if doc.get("source_digest") != dig:       # counters of other kernel sources: start over
+                doc = {}
+        doc["source_digest"] = dig                    # bench.py reports `traffic` only when this matches its own build
+        doc["note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), per launch; read side doubled "
+                       "(gfx950 counts 64 B per 128-B request on wide streaming reads: upper bound for gather kernels)")
         doc[key] = traffic
         json.dump(doc, open(path, "w"), indent=1, sort_keys=True)
         print("wrote", path)

@@ -1,0 +1,190 @@
+#!/usr/bin/env python
+"""BASELINE.json configs[4]: DreamGaussian stage 1 (`main.py --config configs/image.yaml
+input=data/catstatue_rgba.png`, 500 iterations incl. densify/prune) with the reference's UNMODIFIED
+`main.py` / `gs_renderer.py` driving this repository's HIP rasterizer (libgsr.so) on one MI355X.
+
+  tools/stage_reference.sh            # dev container: copy the reference files into ./_ref_stage (git-ignored)
+  python tools/run_stage1.py [--ref _ref_stage] [--iters 500] [--out profiles/r02_stage1.json]
+
+What runs: `GUI(opt)` (-> `Renderer.initialize` -> `distCUDA2`), `GUI.prepare_train()`, iters x
+`GUI.train_step()` (main.py:182-300: known-view MSE on image + alpha, one random novel view per step at
+128/256/512, guidance loss, `loss.backward()`, Adam, `add_densification_stats`, `densify_and_prune` every 100
+steps), the final `prune` and `save_model('model')` -- i.e. `GUI.train()` (main.py:889-898) without its last
+line `save_model('geo+tex')`, which needs mcubes / xatlas / nvdiffrast / sklearn (not installed, no network).
+
+Deviations forced by the environment, all in THIS launcher, none in the reference files:
+  * `cv2`, `dearpygui`, `rembg`, `trimesh`, `pymeshlab`, `kiui`, `mesh`, `mesh_utils`, `omegaconf`: stub modules;
+    `cv2.imread/resize` are Pillow-backed (bilinear instead of OpenCV's INTER_AREA up-sampling);
+  * `plyfile`: dreamgaussian_amd.ply's slice of its API (byte-identical files, tests/test_reference_integration.py);
+  * guidance: zero123 needs `diffusers` + downloaded weights; a deterministic differentiable SURROGATE
+    (`Zero123` below) stands in so that the novel-view render receives a backward pass exactly where SDS
+    gives it one (the densification consumer reads that render's gradient holder, main.py:279-281).
+    The numbers therefore measure the rasterizer + torch side of stage 1, not the diffusion UNet.
+
+Reports wall-clock (un-instrumented run), the per-iteration split rasterizer forward / rasterizer backward /
+everything else (second run with hipEvents around every libgsr kernel), the Gaussian count over time and
+PSNR of `render(fixed_cam)` against the input image at ref_size (our definition; the reference computes none).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def install_stubs():
+    from dreamgaussian_amd import ply
+    mods = {}
+    for name in ("cv2", "dearpygui", "dearpygui.dearpygui", "rembg", "trimesh", "pymeshlab", "kiui", "mesh", "mesh_utils",
+                 "plyfile", "guidance", "guidance.zero123_utils"):
+        mods[name] = types.ModuleType(name)
+    mods["dearpygui"].dearpygui = mods["dearpygui.dearpygui"]
+    mods["kiui"].lo = lambda *a, **k: None
+    mods["mesh"].Mesh = object
+    mods["mesh"].safe_normalize = lambda x, eps=1e-20: x / torch.sqrt(torch.clamp((x * x).sum(-1, keepdim=True), min=eps))
+    mods["mesh_utils"].decimate_mesh = mods["mesh_utils"].clean_mesh = None
+    mods["plyfile"].PlyData, mods["plyfile"].PlyElement = ply.PlyData, ply.PlyElement
+
+    from PIL import Image
+    cv2 = mods["cv2"]
+    cv2.IMREAD_UNCHANGED, cv2.INTER_AREA = -1, 3
+
+    def imread(path, flags=None):                    # -> BGRA / BGR uint8, like OpenCV
+        im = np.array(Image.open(path))
+        if im.ndim == 3 and im.shape[-1] == 4:
+            return im[..., [2, 1, 0, 3]].copy()
+        return im[..., ::-1].copy()
+
+    def resize(img, size, interpolation=None):       # size = (W, H)
+        chans = [np.array(Image.fromarray(img[..., c]).resize(size, Image.BILINEAR)) for c in range(img.shape[-1])]
+        return np.stack(chans, -1)
+    cv2.imread, cv2.resize = imread, resize
+
+    class Zero123:
+        """SURROGATE for guidance/zero123_utils.py:Zero123 (main.py:155-160, 180, 270). Deterministic and
+        differentiable in `images`: pulls the novel view's colour statistics towards the reference image's.
+        NOT a diffusion prior."""
+        def __init__(self, device, model_key=None):
+            self.device = device
+            self.ref_mean = None
+
+        @torch.no_grad()
+        def get_img_embeds(self, x):
+            self.ref_mean = x.mean(dim=(0, 2, 3), keepdim=True)
+
+        def train_step(self, images, vers, hors, radii, step_ratio=None, default_elevation=0):
+            return ((images - self.ref_mean) ** 2).mean() * 100.0
+    mods["guidance.zero123_utils"].Zero123 = Zero123
+    sys.modules.update(mods)
+
+
+def make_opt(ref, iters, input_path):
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(ref, "configs", "image.yaml")))
+    cfg.update(input=input_path, save_path="catstatue", iters=iters, outdir=os.path.join(ROOT, "gpurun_out", "stage1_logs"))
+    return types.SimpleNamespace(**cfg)
+
+
+def psnr_fixed_view(gui):
+    with torch.no_grad():
+        out = gui.renderer.render(gui.fixed_cam)
+        mse = torch.mean((out["image"].unsqueeze(0) - gui.input_img_torch) ** 2).item()
+    return -10.0 * math.log10(max(mse, 1e-12))
+
+
+def run(ref, iters, input_path, profiled):
+    from dreamgaussian_amd import _lib
+    for m in ("main", "gs_renderer", "sh_utils", "cam_utils", "grid_put"):
+        sys.modules.pop(m, None)
+    import main as ref_main                          # the reference trainer, unmodified
+    import gs_renderer
+    import diff_gaussian_rasterization as dgr
+    assert gs_renderer.GaussianRasterizer is dgr.GaussianRasterizer, "gs_renderer.py is not bound to this repository's package"
+    np.random.seed(0); torch.manual_seed(0); torch.cuda.manual_seed(0)
+    opt = make_opt(ref, iters, input_path)
+    t_init0 = time.perf_counter()
+    gui = ref_main.GUI(opt)                          # load_input, Renderer.initialize -> distCUDA2
+    gui.prepare_train()
+    torch.cuda.synchronize()
+    t_init = time.perf_counter() - t_init0
+    psnr0 = psnr_fixed_view(gui)
+    if profiled:
+        _lib.profile_reset(); _lib.profile_enable(True)
+    counts, step_ms = [], []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(iters):
+        ts = time.perf_counter()
+        gui.train_step()                             # main.py:182-300 (synchronises at its end, main.py:290)
+        step_ms.append((time.perf_counter() - ts) * 1e3)
+        counts.append(int(gui.renderer.gaussians.get_xyz.shape[0]))
+    gui.renderer.gaussians.prune(min_opacity=0.01, extent=1, max_screen_size=1)      # main.py:895
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    kern = {}
+    if profiled:
+        _lib.profile_enable(False)
+        kern = _lib.profile_read()
+    gui.save_model(mode="model")                     # main.py:897 (PLY through the plyfile shim)
+    n_final = int(gui.renderer.gaussians.get_xyz.shape[0])
+    res = dict(iters=iters, wall_s=round(wall, 3), init_s=round(t_init, 3), ms_per_iter=round(wall / iters * 1e3, 3),
+               psnr_before=round(psnr0, 2), psnr_after=round(psnr_fixed_view(gui), 2), n_initial=counts[0] if counts else None,
+               n_final=n_final, n_max=max(counts) if counts else None, n_every_100=counts[99::100],
+               ms_per_iter_by_resolution={r: round(float(np.mean(step_ms[a:b])), 3) for r, a, b in
+                                          (("128", 0, int(0.3 * iters) - 1), ("256", int(0.3 * iters), int(0.6 * iters) - 1),
+                                           ("512", int(0.6 * iters), iters)) if b > a})
+    if profiled:
+        fwd = sum(ms for k, (ms, n) in kern.items() if k in ("memset_fwd", "preprocess_fwd", "tile_scan", "tile_order", "scatter", "render_fwd") or k.startswith("tile_sort"))
+        bwd = sum(ms for k, (ms, n) in kern.items() if k in ("memset_bwd", "bwd_plan", "render_bwd", "preprocess_bwd"))
+        other = sum(ms for k, (ms, n) in kern.items()) - fwd - bwd
+        res["rasterizer_kernel_ms_per_iter"] = dict(forward=round(fwd / iters, 4), backward=round(bwd / iters, 4),
+                                                    other_libgsr=round(other / iters, 4),
+                                                    renders_per_iter=2, note="2 renders per iteration: known view 256^2 + one novel view")
+        res["everything_else_ms_per_iter"] = round(wall / iters * 1e3 - (fwd + bwd + other) / iters, 3)
+        res["kernels_total_ms"] = {k: round(v[0], 2) for k, v in sorted(kern.items())}
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default=None, help="directory holding the reference's main.py etc. (default: ./_ref_stage, then /root/reference)")
+    ap.add_argument("--iters", type=int, default=500)
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "stage1.json"))
+    ap.add_argument("--no-profiled-run", action="store_true")
+    a = ap.parse_args()
+    ref = a.ref or next((d for d in (os.path.join(ROOT, "_ref_stage"), "/root/reference") if os.path.isdir(d)), None)
+    if ref is None:
+        raise SystemExit("no reference checkout: run tools/stage_reference.sh in the dev container first")
+    if not torch.cuda.is_available():
+        raise SystemExit("run_stage1.py needs an MI355X: the reference allocates on 'cuda' and libgsr.so has no CPU path")
+    install_stubs()
+    sys.path.insert(0, ref)
+    input_path = os.path.join(ref, "data", "catstatue_rgba.png")
+    plain = run(ref, a.iters, input_path, profiled=False)
+    prof = None if a.no_profiled_run else run(ref, a.iters, input_path, profiled=True)
+    from dreamgaussian_amd import _lib
+    out = {"config": "BASELINE.json configs[4]: main.py --config configs/image.yaml input=data/catstatue_rgba.png, "
+                     f"{a.iters} iterations incl. densify/prune, 1 x MI355X, HIP rasterizer ({_lib.load().gsr_version().decode()})",
+           "guidance": "SURROGATE (colour-statistics loss), zero123 weights/diffusers unavailable: the UNet's time is NOT in these numbers",
+           "deviations": "stub modules for cv2 (Pillow), dearpygui, rembg, trimesh, pymeshlab, kiui, mesh, mesh_utils, omegaconf; "
+                         "plyfile -> dreamgaussian_amd.ply; save_model('geo+tex') skipped (mcubes/xatlas/nvdiffrast absent)",
+           "device": torch.cuda.get_device_name(0), "torch": torch.__version__,
+           "run": plain, "profiled_run": prof}
+    os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+    json.dump(out, open(a.out, "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
