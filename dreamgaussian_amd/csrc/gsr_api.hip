@@ -112,7 +112,7 @@ GeomLayout geom_layout(int N, int H, int W) {
     L.recs = o; o += align_up((size_t)N * sizeof(SplatRec));
     L.emit = o; o += align_up((size_t)N * sizeof(EmitRec));
     L.flags8 = o; o += align_up((size_t)N);
-    L.block_stats = o; o += align_up(2048 * 2 * 8);       // K1 grid <= 2048 workgroups
+    L.block_stats = o; o += align_up(2048 * 3 * 8);       // K1 grid <= 2048 workgroups
     L.tile_count = o; o += align_up((size_t)L.nTiles * 4);
     L.cursor = o; o += align_up((size_t)L.nTiles * 4);
     L.tile_last = o; o += align_up((size_t)L.nTiles * 4);
@@ -125,7 +125,7 @@ GeomLayout geom_layout(int N, int H, int W) {
     return L;
 }
 int seg_shift();
-#define GSR_BWD_DEFAULT kBwdF2b
+#define GSR_BWD_DEFAULT kBwdQ2
 struct BinLayout { size_t entries, ids, ckpt, plan_tile, plan_cap, total; };
 BinLayout bin_layout(size_t M, int nTiles) {
     BinLayout L;
@@ -202,12 +202,11 @@ int seg_shift() {
     }();
     return v;
 }
-enum BwdKernel { kBwdF2b = 0, kBwdQ2 = 1, kBwdQuad = 2, kBwdQ2P = 3 };
+enum BwdKernel { kBwdF2b = 0, kBwdQ2 = 1, kBwdQuad = 2 };
 int bwd_kernel() {
     static const int v = [] {
         const char* e = getenv("GSR_BWD");
         if (e && strcmp(e, "q2") == 0) return (int)kBwdQ2;
-        if (e && strcmp(e, "q2p") == 0) return (int)kBwdQ2P;
         if (e && strcmp(e, "quad") == 0) return (int)kBwdQuad;
         if (e && strcmp(e, "f2b") == 0) return (int)kBwdF2b;
         return (int)GSR_BWD_DEFAULT;
@@ -535,14 +534,14 @@ extern "C" int gsr_backward(const GsrView* view, int32_t N, int32_t K,
         LAUNCH_CHECK(view, stream, "bwd_plan");
         prof_begin(stream);
         const unsigned grid = (unsigned)BL.plan_cap;
-        const size_t dyn = ((size_t)GSR_G2D_STRIDE * 4) << seg_shift();
+        // workgroup table: [2^shift][12] floats, or [2^shift][10] 64-bit fixed-point sums for the q2 kernel
+        const size_t dyn = (bwd_kernel() == kBwdQ2 ? (size_t)GSR_Q2_ROW * 8 : (size_t)GSR_G2D_STRIDE * 4) << seg_shift();
 #define GSR_LAUNCH_BWD(KERNEL)                                                                          \
         hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(256), dyn, stream, tile_off, recs, sorted_ids, view->bg, W, H, vc.gx, \
                            final_T, n_contrib, totals, ckpt, tile_seg, dL_dcolor, dL_ddepth, dL_dalpha, g2d, seg_shift(), \
                            plan_tile, plan_off, plan_total)
         switch (bwd_kernel()) {
-            case kBwdQ2: GSR_LAUNCH_BWD(gsr_render_bwd_q2<false>); break;
-            case kBwdQ2P: GSR_LAUNCH_BWD(gsr_render_bwd_q2<true>); break;
+            case kBwdQ2: GSR_LAUNCH_BWD(gsr_render_bwd_q2); break;
             case kBwdQuad: GSR_LAUNCH_BWD(gsr_render_bwd_f2b_quad); break;
             default: GSR_LAUNCH_BWD(gsr_render_bwd_f2b); break;
         }

@@ -15,7 +15,7 @@
 
 // ---------------------------------------------------------------------------------------
 // K2: exclusive scan of the per-tile counts (single workgroup; T is a few thousand).
-// counters[2] = M_emit, counters[3] = max per-tile count.
+// counters[0] = M_ref, [1] = V, [2] = M_emit, [3] = max per-tile count, [5] = bits of max(colour, depth).
 // ---------------------------------------------------------------------------------------
 extern "C" __global__ void __launch_bounds__(1024)
 gsr_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_off, int T,
@@ -58,17 +58,17 @@ gsr_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ ti
         tile_seg[i] = srun; srun += c ? (c - 1) >> seg_shift : 0u;
     }
     {   // K1's per-workgroup statistics (M_ref, V): parallel sum over the workgroups
-        __shared__ unsigned long long sref[16], svis[16];
-        unsigned long long a = 0, b = 0;
-        for (int i = threadIdx.x; i < nblocks; i += 1024) { a += block_stats[2 * i]; b += block_stats[2 * i + 1]; }
+        __shared__ unsigned long long sref[16], svis[16], smax[16];
+        unsigned long long a = 0, b = 0, c = 0;
+        for (int i = threadIdx.x; i < nblocks; i += 1024) { a += block_stats[3 * i]; b += block_stats[3 * i + 1]; c = max(c, block_stats[3 * i + 2]); }
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
-        if (lane == 0) { sref[wave] = a; svis[wave] = b; }
+        for (int off = 32; off >= 1; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); c = max(c, (unsigned long long)__shfl_xor(c, off, 64)); }
+        if (lane == 0) { sref[wave] = a; svis[wave] = b; smax[wave] = c; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            unsigned long long ta = 0, tb = 0;
-            for (int w = 0; w < 16; ++w) { ta += sref[w]; tb += svis[w]; }
-            counters[0] = ta; counters[1] = tb;
+            unsigned long long ta = 0, tb = 0, tc = 0;
+            for (int w = 0; w < 16; ++w) { ta += sref[w]; tb += svis[w]; tc = max(tc, smax[w]); }
+            counters[0] = ta; counters[1] = tb; counters[5] = tc;
         }
     }
     if (threadIdx.x == 1023) {

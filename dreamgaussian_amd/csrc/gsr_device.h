@@ -33,7 +33,7 @@ static_assert(sizeof(SplatRec) == 64, "SplatRec must be 64 bytes");
 // Backward segments: a tile's depth-sorted list is cut every 2^seg_shift positions; the forward
 // leaves a per-pixel checkpoint (T and the five running sums) at every cut so that each segment
 // of the backward can start front-to-back on its own workgroup.
-#define GSR_SEG_SHIFT_DEFAULT 7    // 128 list positions per segment (env GSR_SEG_SHIFT: 6..14); 1M Gaussians: 0.58 ms at 10, 0.44 ms at 7
+#define GSR_SEG_SHIFT_DEFAULT 6    // 64 list positions per segment = one fetch round per wave (env GSR_SEG_SHIFT: 6..8)
 #define GSR_CKPT_FLOATS (6 * 256)   // one checkpoint: [T, C0, C1, C2, D, A][256 pixels of the tile]
 
 // per-Gaussian streaming side array for the scatter kernel (coalesced 16 B / lane)

@@ -220,7 +220,7 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
                    const float* __restrict__ cov3D_precomp,
                    SplatRec* __restrict__ recs, EmitRec* __restrict__ emit,
                    int32_t* __restrict__ radii, uint32_t* __restrict__ tile_count,
-                   unsigned long long* __restrict__ block_stats /*[grid][2]: M_ref, V per workgroup*/,
+                   unsigned long long* __restrict__ block_stats /*[grid][3]: M_ref, V, max(colour, depth) bits per workgroup*/,
                    int hist_in_lds, int sh_direct,
                    uint8_t* __restrict__ flags8 /* colour-clamp bits for K6: 1 B instead of a 64-B record line */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_pp[];
@@ -241,6 +241,7 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
     const float* __restrict__ V = vc.view;
     const float* __restrict__ P = vc.proj;
     unsigned long long my_ref = 0, my_vis = 0;
+    float my_cmax = 0.f;              // largest colour component / depth of a listed Gaussian (bound used by the backward)
 
     const bool pipelined = stage && (rowlen & 3) == 0 && rowlen <= 4 * STAGE_PF && blockDim.x == 256;
     float4 pf[STAGE_PF];
@@ -357,6 +358,7 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
                     rec.x = px; rec.y = py;
                     rec.qa = -0.5f * cA * GSR_LOG2E; rec.qb = -cB * GSR_LOG2E; rec.qc = -0.5f * cC * GSR_LOG2E;
                     rec.opac = op; rec.r = cr; rec.g = cg; rec.b = cb; rec.depth = pv.z;
+                    my_cmax = fmaxf(my_cmax, fmaxf(fmaxf(fabsf(cr), fabsf(cg)), fmaxf(fabsf(cb), pv.z)));
                     // Exact no-op culling: a pixel can only pass the alpha >= 1/255 test inside the
                     // axis-aligned box |dx| <= sqrt(2 tau a), |dy| <= sqrt(2 tau c), tau = ln(255 o)
                     // (a 0.2% safety margin dominates fp32 rounding of the in-kernel alpha).
@@ -420,18 +422,20 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
     // statistics: wave -> workgroup in LDS -> one plain store per workgroup (summed by tile_scan).
     // Same-address global atomics execute one after the other at the memory side: 2 per wave to two
     // shared counters was ~40 us of serialised tail at 2048 waves.
-    __shared__ unsigned long long wstat[2][16];
+    __shared__ unsigned long long wstat[3][16];
+    const uint32_t wave_cmax = wave_max_u32(__float_as_uint(my_cmax));   // non-negative floats order like their bits
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         my_ref += __shfl_xor(my_ref, off, 64);
         my_vis += __shfl_xor(my_vis, off, 64);
     }
-    if ((threadIdx.x & 63) == 0) { wstat[0][threadIdx.x >> 6] = my_ref; wstat[1][threadIdx.x >> 6] = my_vis; }
+    if ((threadIdx.x & 63) == 0) { wstat[0][threadIdx.x >> 6] = my_ref; wstat[1][threadIdx.x >> 6] = my_vis; wstat[2][threadIdx.x >> 6] = wave_cmax; }
     __syncthreads();
-    if (threadIdx.x < 2) {
+    if (threadIdx.x < 3) {
         unsigned long long sum = 0;
-        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sum += wstat[threadIdx.x][w];
-        block_stats[2 * blockIdx.x + threadIdx.x] = sum;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w)
+            sum = threadIdx.x < 2 ? sum + wstat[threadIdx.x][w] : max(sum, wstat[2][w]);
+        block_stats[3 * blockIdx.x + threadIdx.x] = sum;
     }
     if (hist_in_lds) {
         // every workgroup starts its flush at a different tile: no burst of atomics on one address

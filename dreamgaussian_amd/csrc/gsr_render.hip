@@ -344,14 +344,14 @@ gsr_render_bwd_f2b(GSR_BWD_PARAMS) {
 }
 
 // -----------------------------------------------------------------------------------------
-// K5b (default): quad lists + two passes.
+// K5b (default): quad lists + two passes + fixed-point accumulation.
 //
 // Every 16-lane DPP row of a wave owns a 4x4 pixel quad (row r: quad (r & 1, r >> 1) of the 8x8
 // block, lane l15: pixel (l15 & 3, l15 >> 2) of the quad). A fetched record is tested exactly
-// against each of the four quads; the survivors are staged once (slot = fetching lane) and every
-// quad gets its own byte list of staged slots, so a row iterates only over Gaussians that can
-// blend in ITS sixteen pixels and the wave loops to the longest of the four lists (at 1M
-// Gaussians 1.5x fewer trips than one 8x8 list, tests/lane_stats.py).
+// against each of the four quads (quad_max_powers); the survivors are staged once (slot =
+// fetching lane) and every quad gets its own byte list of staged slots, so a row iterates only
+// over Gaussians that can blend in ITS sixteen pixels and the wave loops to the longest of the
+// four lists (at 1M Gaussians 1.5x fewer trips than one 8x8 list, tests/lane_stats.py).
 //
 // pass 1 (lane = pixel), eight list entries per batch: the serial front-to-back recurrence of
 //   T and the c.g prefix; (m, w) go to LDS:  mw[wave][quad][entry k][half h][8 pixels] float2,
@@ -359,14 +359,27 @@ gsr_render_bwd_f2b(GSR_BWD_PARAMS) {
 //   per LDS cycle hit 16 distinct 4-bank slots in pass 2).
 // pass 2 (lane = (quad, half h = l15 >> 3, entry k = l15 & 7)): each lane sums ITS entry over
 //   the eight pixels of ITS half -- S_0, S_x, S_y, S_xx, S_xy, S_yy and the four w * g sums are
-//   plain FMAs, the per-pixel gradients come from a per-wave LDS table written once -- the two
-//   halves meet through one DPP row rotation per value, and each lane adds five of the ten
-//   totals to the workgroup's LDS table. No transposing reduction, no per-entry cross-lane chain.
+//   plain FMAs against per-pixel gradients held in registers -- the two halves meet through one
+//   DPP row rotation per value, and each lane adds five of the ten totals to the workgroup's
+//   table. No transposing reduction, no per-entry cross-lane chain.
+//
+// The table is 64-bit FIXED POINT. Measured on gfx950 (profiles/r02_ubench_lds_valu.txt):
+// ds_add_f32 costs 2.8 LDS cycles PER ACTIVE LANE (177 cycles for a full wave), ds_add_u64 5.9
+// cycles per instruction; with float atomics the LDS pipe was 76% busy and this kernel slower
+// than the round-1 one. Every contributor of a table row derives the same exponent from data
+// all of them see: |m| <= 101 cmax gsum_p (T <= 1, opacity G <= 1, 1/(1 - alpha) <= 100, colour
+// components and depth <= cmax -- a per-launch maximum K1 leaves in counters[5] -- and
+// gsum_p = |gC0| + |gC1| + |gC2| + |gD| + |gA| of the pixel), at most 256 pixels add into a row,
+// and |dx|, |dy| <= R = max(|x - tile centre x|, |y - tile centre y|) + 7.5. With
+// 2^e0 * 256 * 101 * cmax * max_tile(gsum) < 2^60 the zeroth moments and the w sums use e0, the
+// first moments e0 - eR, the second e0 - 2 eR (2^eR > R): no overflow, resolution below 1e-12 of
+// the largest possible row total, and the workgroup's sums no longer depend on the order of the adds.
 // -----------------------------------------------------------------------------------------
 #define GSR_Q2_BATCH 8
 #define GSR_Q2_KSTRIDE 40     // floats between consecutive entries of a quad's batch
 #define GSR_Q2_HSTRIDE 20     // floats between the two pixel halves of an entry
 #define GSR_QL_PITCH 80       // bytes per quad list (64 + zero padding, multiple of 8)
+#define GSR_Q2_ROW 10         // u64 per table row: S_x S_y S_xx S_xy S_yy | S_0 W0 W1 W2 W3
 
 __device__ __forceinline__ float row_max_f(float v) {       // every lane of a 16-lane row receives the row's maximum
     v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140 /* row_mirror */, 0xf, 0xf, false)));
@@ -379,15 +392,28 @@ __device__ __forceinline__ float row_max_f(float v) {       // every lane of a 1
 __device__ __forceinline__ float add_other_half(float v) {
     return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_ROW_ROR(8), 0xf, 0xf, false));
 }
+// v * 2^e as a two's-complement 64-bit integer (|v * 2^e| < 2^62; exact: the split is done on exactly representable floats)
+__device__ __forceinline__ unsigned long long to_fixed(float v, int e) {
+    const float x = ldexpf(v, e);
+    const float hi = floorf(x * 2.3283064365386963e-10f);            // floor(x / 2^32)
+    const float lo = fmaf(-hi, 4294967296.f, x);                      // in [0, 2^32)
+    return ((unsigned long long)(uint32_t)(int32_t)hi << 32) | (unsigned long long)(uint32_t)lo;
+}
+__device__ __forceinline__ float from_fixed(unsigned long long v, int e) {
+    return ldexpf((float)(long long)v, -e);
+}
+// exponent with 2^result > R for the per-row scale of the moments; the SAME expression in pass 2 and in the flush
+__device__ __forceinline__ int row_radius_exp(float gx, float gy, float tcx, float tcy) {
+    return __builtin_amdgcn_frexp_expf(fmaxf(fabsf(gx - tcx), fabsf(gy - tcy)) + 7.5f);
+}
 
-template <bool PREFETCH>   // PREFETCH: the next round's records are fetched while this round is processed
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 4)   // <= 128 VGPRs: four workgroups per CU (LDS: 34 KiB + 5 KiB table at 64-entry segments)
 gsr_render_bwd_q2(GSR_BWD_PARAMS) {
     __shared__ float4 stage[4][3][GSR_RB];                                   // 12 KiB staged records, slot = fetching lane
     __shared__ __attribute__((aligned(8))) uint8_t qlist[4][4][GSR_QL_PITCH]; // 1.25 KiB [wave][quad][k] = staged slot of the quad's k-th entry
     __shared__ __attribute__((aligned(16))) float mw[4][4][GSR_Q2_BATCH * GSR_Q2_KSTRIDE];   // 20 KiB
-    __shared__ float4 gtab[4][64];                                           // 4 KiB per-pixel (gC0, gC1, gC2, gD), [wave][lane]
-    extern __shared__ __attribute__((aligned(16))) float acc[];              // [(1 << seg_shift) * GSR_G2D_STRIDE]
+    __shared__ uint32_t gmax_bits;                                           // max over the tile of gsum (bits of a non-negative float)
+    extern __shared__ __attribute__((aligned(16))) unsigned long long acc64[];   // [(1 << seg_shift) * GSR_Q2_ROW]
     if (blockIdx.x >= (uint32_t)plan_total[0]) return;
     const int tile = (int)plan_tile[blockIdx.x];
     const uint32_t seg = blockIdx.x - plan_off[tile];
@@ -398,10 +424,20 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int row = lane >> 4, l15 = lane & 15;
-    const int bx = (tile % gx) * GSR_TILE + (wave & 1) * 8;
-    const int by = (tile / gx) * GSR_TILE + (wave >> 1) * 8;
-    for (int q = threadIdx.x; q < (GSR_G2D_STRIDE << seg_shift); q += 256) acc[q] = 0.f;
+    // records of the first round: requested before anything else so that the two dependent loads
+    // (index, record) overlap the per-pixel set-up below; entries past this wave's own end are masked later
+    const uint32_t seg_end = min(seg_lo + (1u << seg_shift), n);
+    float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa, pc = pa;
+    if (seg_lo + lane < seg_end) {
+        const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + ids[start + seg_lo + lane]);
+        pa = p[0]; pb = p[1]; pc = p[2];
+    }
+    const int tx0 = (tile % gx) * GSR_TILE, ty0 = (tile / gx) * GSR_TILE;
+    const int bx = tx0 + (wave & 1) * 8, by = ty0 + (wave >> 1) * 8;
+    for (int q = threadIdx.x; q < (GSR_Q2_ROW << seg_shift); q += 256) acc64[q] = 0ull;
     for (int q = threadIdx.x; q < 4 * 4 * GSR_QL_PITCH / 4; q += 256) reinterpret_cast<uint32_t*>(&qlist[0][0][0])[q] = 0u;   // stale reads stay inside the stage
+    if (threadIdx.x == 0) gmax_bits = 0u;
+    __syncthreads();
     bool active = (bx < W) && (by < H);                   // wave-uniform; no early return: barriers below
     const int qx = bx + (row & 1) * 4, qy = by + (row >> 1) * 4;         // this row's quad
     const int lx = (row & 1) * 4 + (l15 & 3), ly = (row >> 1) * 4 + (l15 >> 2);
@@ -425,8 +461,20 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
         Cg_total = totals[pix] * gC0 + totals[HW + pix] * gC1 + totals[2 * HW + pix] * gC2
                  + totals[3 * HW + pix] * gD + totals[4 * HW + pix] * gA;
     }
-    gtab[wave][lane] = make_float4(gC0, gC1, gC2, gD);    // pass 2 reads other lanes' pixels
+    float4* __restrict__ gtab = reinterpret_cast<float4*>(&mw[wave][0][0]);   // per-wave, read once below, then the space is pass 1's
+    gtab[lane] = make_float4(gC0, gC1, gC2, gD);          // pass 2 reads other lanes' pixels
+    {
+        const float gsum = fabsf(gC0) + fabsf(gC1) + fabsf(gC2) + fabsf(gD) + fabsf(gA);
+        const uint32_t wm = wave_max_u32(__float_as_uint(gsum));          // non-negative floats order like their bits
+        if (lane == 0) atomicMax(&gmax_bits, wm);
+    }
     __syncthreads();
+    const bool poisoned = gmax_bits >= 0x7f800000u;       // an infinite or NaN incoming gradient somewhere in the tile
+    const float gmax = poisoned ? 1.f : __uint_as_float(gmax_bits);
+    if (!(gmax > 0.f)) return;                            // block-uniform: a zero incoming gradient adds nothing anywhere
+    const float cmax = fmaxf(fmaxf(__uint_as_float((uint32_t)plan_total[1]), 1.f), fmaxf(fabsf(bg[0]), fmaxf(fabsf(bg[1]), fabsf(bg[2]))));
+    const int e0 = 60 - __builtin_amdgcn_frexp_expf(25856.f * cmax * gmax);     // 2^e0 * (256 * 101 * cmax * gmax) < 2^60
+    const float tcx = (float)tx0 + 7.5f, tcy = (float)ty0 + 7.5f;
     // deepest contributor of each quad (list positions are < 2^24: exact as floats) and of the wave
     const uint32_t row_last = (uint32_t)row_max_f((float)last_contrib);
     const uint32_t ql0 = __builtin_amdgcn_readlane(row_last, 0), ql1 = __builtin_amdgcn_readlane(row_last, 16),
@@ -447,8 +495,12 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
     float* __restrict__ mw1 = &mw[wave][row][(l15 >> 3) * GSR_Q2_HSTRIDE + (l15 & 7) * 2];
     const int k2 = l15 & 7, h2 = l15 >> 3;
     const float* __restrict__ mw2 = &mw[wave][row][k2 * GSR_Q2_KSTRIDE + h2 * GSR_Q2_HSTRIDE];
-    const float4* __restrict__ gt2 = &gtab[wave][row * 16 + h2 * 8];
     const float qxf = (float)qx, qyf = (float)(qy + 2 * h2);                 // first pixel of pass 2's half
+    float4 g2[8];                                                            // gradients of the 8 pixels of pass 2's half
+    wave_lds_handoff();
+#pragma unroll
+    for (int i2 = 0; i2 < 8; ++i2) g2[i2] = gtab[row * 16 + h2 * 8 + i2];
+    wave_lds_handoff();                                   // ... before pass 1 writes over the table
 
     // ea = x y qa qb | eb = qc opac r g | ec = b depth - - ; kpos = 1-based list position (row-uniform)
 #define GSR_Q2_ENTRY(ea, eb, ec, kpos, valid, kslot)                                             \
@@ -472,27 +524,15 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
         if (valid) *reinterpret_cast<float2*>(mw1 + (kslot) * GSR_Q2_KSTRIDE) = make_float2(m, w); \
     }
 
-    float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa, pc = pa;       // PREFETCH: records of the next round
-    if (PREFETCH && seg_lo + lane < seg_hi) {
-        const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + ids[start + seg_lo + lane]);
-        pa = p[0]; pb = p[1]; pc = p[2];
-    }
     for (uint32_t pos0 = seg_lo; pos0 < seg_hi; pos0 += GSR_RB) {   // 0-based positions pos0 .. pos0+63
         const uint32_t i = pos0 + lane;
         bool h0 = false, h1 = false, h2q = false, h3 = false;
-        float4 ra, rb, rc;
-        if (PREFETCH) {
-            ra = pa; rb = pb; rc = pc;
-            if (i + GSR_RB < seg_hi) {
-                const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + ids[start + i + GSR_RB]);
-                pa = p[0]; pb = p[1]; pc = p[2];
-            }
+        const float4 ra = pa, rb = pb, rc = pc;
+        if (i + GSR_RB < seg_hi) {                        // next round's records: in flight during this round
+            const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + ids[start + i + GSR_RB]);
+            pa = p[0]; pb = p[1]; pc = p[2];
         }
         if (i < seg_hi) {
-            if (!PREFETCH) {
-                const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + ids[start + i]);
-                ra = p[0]; rb = p[1]; rc = p[2];
-            }
             const float thr = min_visible_power(rb.y);
             // exact ellipse-vs-quad support tests; an entry behind a quad's deepest contributor is never blended there
             float qp[4];
@@ -515,7 +555,7 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
         const uint32_t accrow0 = pos0 - seg_lo;           // table row of staged slot 0
         wave_lds_handoff();
         for (int jb = 0; jb < nmax; jb += GSR_Q2_BATCH) {
-            // ---- pass 1: entries jb .. jb+7 of every quad list (stale slots beyond a list: in range, finite, masked)
+            // ---- pass 1: entries jb .. jb+7 of every quad list (stale slots beyond a list: in range, masked)
             const uint2 sl = *reinterpret_cast<const uint2*>(ql + jb);
             uint32_t slot[GSR_Q2_BATCH];
 #pragma unroll
@@ -534,8 +574,8 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
             // ---- pass 2: lane (row, h2, k2) sums entry jb + k2 of its quad over the 8 pixels of half h2
             {
                 const bool v2 = jb + k2 < nmine;
-                const uint32_t myslot = ql[jb + k2];      // staged slot of this lane's entry (in range even when !v2)
-                const float2 gxy = *reinterpret_cast<const float2*>(&sa[myslot]);
+                const uint32_t s2 = ql[jb + k2];          // staged slot of this lane's entry (in range even when !v2)
+                const float2 gxy = *reinterpret_cast<const float2*>(&sa[s2]);
                 const float dxb = gxy.x - qxf, dyb = gxy.y - qyf;
                 float S0 = 0.f, Sx = 0.f, Sy = 0.f, Sxx = 0.f, Sxy = 0.f, Syy = 0.f, W0 = 0.f, W1 = 0.f, W2 = 0.f, W3 = 0.f;
 #pragma unroll
@@ -545,7 +585,7 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
 #pragma unroll
                     for (int c2 = 0; c2 < 4; c2 += 2) {
                         const float4 v = *reinterpret_cast<const float4*>(mw2 + (r2 * 4 + c2) * 2);   // m, w, m', w' of two pixels
-                        const float4 g0 = gt2[r2 * 4 + c2], g1 = gt2[r2 * 4 + c2 + 1];
+                        const float4 g0 = g2[r2 * 4 + c2], g1 = g2[r2 * 4 + c2 + 1];
                         const float dx0 = dxb - (float)c2, dx1 = dxb - (float)(c2 + 1);
                         const float t0 = v.x * dx0, t1 = v.z * dx1;
                         R0 += v.x; R0 += v.z;
@@ -562,20 +602,69 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
                 S0 = add_other_half(S0); Sx = add_other_half(Sx); Sy = add_other_half(Sy);
                 Sxx = add_other_half(Sxx); Sxy = add_other_half(Sxy); Syy = add_other_half(Syy);
                 W0 = add_other_half(W0); W1 = add_other_half(W1); W2 = add_other_half(W2); W3 = add_other_half(W3);
-                if (v2) {   // lane h2 = 0 adds table slots 0..4, lane h2 = 1 slots 5..9
-                    float* a = acc + (accrow0 + myslot) * GSR_G2D_STRIDE + h2 * 5;
-                    atomicAdd(a + 0, h2 ? S0 : Sx);
-                    atomicAdd(a + 1, h2 ? W0 : Sy);
-                    atomicAdd(a + 2, h2 ? W1 : Sxx);
-                    atomicAdd(a + 3, h2 ? W2 : Sxy);
-                    atomicAdd(a + 4, h2 ? W3 : Syy);
+                if (v2) {   // lane h2 = 0 adds table slots 0..4 (moments), lane h2 = 1 slots 5..9 (S_0 and the w sums)
+                    const int eR = row_radius_exp(gxy.x, gxy.y, tcx, tcy);
+                    const int e1 = h2 ? e0 : e0 - eR, e2 = h2 ? e0 : e0 - 2 * eR;
+                    unsigned long long* a = acc64 + (accrow0 + s2) * GSR_Q2_ROW + h2 * 5;
+                    atomicAdd(a + 0, to_fixed(h2 ? S0 : Sx, e1));
+                    atomicAdd(a + 1, to_fixed(h2 ? W0 : Sy, e1));
+                    atomicAdd(a + 2, to_fixed(h2 ? W1 : Sxx, e2));
+                    atomicAdd(a + 3, to_fixed(h2 ? W2 : Sxy, e2));
+                    atomicAdd(a + 4, to_fixed(h2 ? W3 : Syy, e2));
                 }
             }
             wave_lds_handoff();                           // pass 2's reads precede the next batch's / round's writes
         }
     }
 #undef GSR_Q2_ENTRY
-    bwd_flush(acc, min(1u << seg_shift, n - seg_lo), start + seg_lo, recs, ids, g2d);
+    // ---- flush: fixed point -> float, raw moments -> the accumulator layout K6 reads, coalesced global atomics
+    __syncthreads();
+    const uint32_t len = min(1u << seg_shift, n - seg_lo);
+    float out[GSR_G2D_STRIDE];
+    uint32_t gid = 0;
+    bool any = false;
+    if (threadIdx.x < len) {                              // seg_shift <= 8: one table row per thread
+        const unsigned long long* a = acc64 + threadIdx.x * GSR_Q2_ROW;
+        unsigned long long v[GSR_Q2_ROW];
+#pragma unroll
+        for (int q = 0; q < GSR_Q2_ROW; ++q) { v[q] = a[q]; any = any || (v[q] != 0ull); }
+        any = any || poisoned;                            // non-finite input: the fixed-point sums mean nothing -> NaN out, like float arithmetic
+        if (any) {
+            gid = ids[start + seg_lo + threadIdx.x];
+            const SplatRec* __restrict__ g = recs + gid;
+            const float qa = g->qa, qb = g->qb, qc = g->qc, op = g->opac;
+            const int eR = row_radius_exp(g->x, g->y, tcx, tcy);
+            const float Sx = from_fixed(v[0], e0 - eR), Sy = from_fixed(v[1], e0 - eR);
+            const float Sxx = from_fixed(v[2], e0 - 2 * eR), Sxy = from_fixed(v[3], e0 - 2 * eR), Syy = from_fixed(v[4], e0 - 2 * eR);
+            const float S0 = from_fixed(v[5], e0);
+            out[0] = 2.f * qa * Sx + qb * Sy;             // mean2D.x (ln2 * 0.5 W applied in K6)
+            out[1] = 2.f * qc * Sy + qb * Sx;
+            out[2] = -0.5f * Sxx; out[3] = -Sxy; out[4] = -0.5f * Syy;   // true conic A, B, C
+            out[5] = op != 0.f ? S0 / op : 0.f;           // opacity
+            out[6] = from_fixed(v[6], e0); out[7] = from_fixed(v[7], e0); out[8] = from_fixed(v[8], e0);
+            out[9] = from_fixed(v[9], e0);
+            out[10] = out[11] = 0.f;
+            if (poisoned) {
+#pragma unroll
+                for (int q = 0; q < 10; ++q) out[q] = __uint_as_float(0x7fc00000u);
+            }
+        }
+    }
+    __syncthreads();                                      // every row is in registers: the table may be overwritten
+    float* accf = reinterpret_cast<float*>(acc64);        // [len][12] floats (48 B per row <= 80 B per row before)
+    uint32_t* gids = reinterpret_cast<uint32_t*>(&mw[0][0][0]);   // pass 2 is over: reuse as [len] Gaussian indices
+    if (threadIdx.x < len) {
+        gids[threadIdx.x] = any ? gid : 0xffffffffu;
+#pragma unroll
+        for (int q = 0; q < GSR_G2D_STRIDE; ++q) accf[threadIdx.x * GSR_G2D_STRIDE + q] = any ? out[q] : 0.f;
+    }
+    __syncthreads();
+    // consecutive threads = consecutive slots of consecutive list positions
+    for (uint32_t e = threadIdx.x; e < len * GSR_G2D_STRIDE; e += 256) {
+        const float v = accf[e];
+        if (v != 0.f) {
+            const uint32_t r = e / GSR_G2D_STRIDE, slot = e - r * GSR_G2D_STRIDE;
+            atomicAdd(g2d + (size_t)gids[r] * GSR_G2D_STRIDE + slot, v);
+        }
+    }
 }
-template __global__ void gsr_render_bwd_q2<false>(GSR_BWD_PARAMS);
-template __global__ void gsr_render_bwd_q2<true>(GSR_BWD_PARAMS);
