@@ -16,7 +16,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgsr.so")
 STAMP = os.path.join(HERE, ".libgsr.stamp")
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-shared",
+# -fno-slp-vectorize: hipcc packs adjacent scalar fp32 ops into v_pk_* (+ v_mov shuffles); on gfx950 a v_pk_fma_f32
+# issues in 4.4 cycles against 2.2 for v_fma_f32 (profiles/r02_ubench_lds_valu.txt): no gain, only the shuffles
+FLAGS = ["-O3", "-std=c++17", "-munsafe-fp-atomics", "-fno-slp-vectorize", "-fPIC", "-shared",
          "-Wall", "-Wno-unused-function"]
 
 

@@ -325,17 +325,13 @@ extern "C" int gsr_forward_begin(const GsrView* view, int32_t N, int32_t K,
                            tile_count, (unsigned long long*)(gbuf + GL.block_stats), hist_in_lds, sh_direct, (uint8_t*)(gbuf + GL.flags8));
         LAUNCH_CHECK(view, stream, "preprocess_fwd");
     }
+    // one single-workgroup kernel: scan of the counts, K1's statistics, heaviest-first launch order
     prof_begin(stream); hipLaunchKernelGGL(gsr_tile_scan, dim3(1), dim3(1024), 0, stream, tile_count, tile_off, T, counters, tile_seg, seg_shift(),
-                       (const unsigned long long*)(gbuf + GL.block_stats), N > 0 ? grid_pre : 0);
+                       (const unsigned long long*)(gbuf + GL.block_stats), N > 0 ? grid_pre : 0, tile_order);
     LAUNCH_CHECK(view, stream, "tile_scan");
-    // the counters leave first: gsr_forward waits for THIS copy only (g_copied), so the launch-order
-    // kernel below runs while the host wakes up and allocates the bin scratch
+    // gsr_forward waits for THIS copy only (g_copied)
     HIP_TRY(hipMemcpyAsync(host_counters, counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
     if (g_copied) HIP_TRY(hipEventRecord(g_copied, stream));
-    if (!use_tile_order_off()) {                          // heaviest tiles first
-        prof_begin(stream); hipLaunchKernelGGL(gsr_tile_order, dim3(1), dim3(1024), 0, stream, tile_count, T, counters, tile_order);
-        LAUNCH_CHECK(view, stream, "tile_order");
-    }
     return 0;
 }
 

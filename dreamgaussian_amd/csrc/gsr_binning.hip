@@ -8,8 +8,8 @@
 // histograms; K2 scans them into segment offsets; K3 scatters 8-byte (depth,id) keys into the
 // tile segments through an LDS-privatised cursor reservation (one returning global atomic per
 // (workgroup,tile) instead of one per instance); K4 sorts each segment inside LDS (counting pass
-// into ~n/4 depth buckets + insertion sort per bucket on the 64-bit key; bitonic network as the
-// skew fallback; up to 16384 entries = 128 KiB of the CU's 160 KiB) and writes the tile's sorted
+// into ~n/4 depth buckets + rank inside each bucket on the 64-bit key; rank sort for lists of <= 256;
+// bitonic network as the skew fallback; up to 16384 entries = 128 KiB of the CU's 160 KiB) and writes the tile's sorted
 // list of Gaussian INDICES; the compositing kernels gather the 64-byte records themselves.
 #include "gsr_device.h"
 
@@ -20,7 +20,8 @@
 extern "C" __global__ void __launch_bounds__(1024)
 gsr_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_off, int T,
               unsigned long long* __restrict__ counters, uint32_t* __restrict__ tile_seg, int seg_shift,
-              const unsigned long long* __restrict__ block_stats, int nblocks) {
+              const unsigned long long* __restrict__ block_stats, int nblocks,
+              uint32_t* __restrict__ order /* heaviest-first launch order of the compositing forward, or NULL */) {
     // tile_seg[t] = index of tile t's first checkpoint slot = exclusive scan of floor((n_t-1) >> seg_shift)
     __shared__ unsigned long long wsum[16];
     __shared__ uint32_t wsegs[16];
@@ -71,12 +72,42 @@ gsr_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ ti
             counters[0] = ta; counters[1] = tb; counters[5] = tc;
         }
     }
+    uint32_t maxc = 0;
+    for (int w = 0; w < 16; ++w) maxc = max(maxc, wmax[w]);
     if (threadIdx.x == 1023) {
         tile_off[T] = (uint32_t)(wave_base + incl);
         counters[2] = wave_base + incl;
-        uint32_t m = 0;
-        for (int w = 0; w < 16; ++w) m = max(m, wmax[w]);
-        counters[3] = m;
+        counters[3] = maxc;
+    }
+    if (!order) return;
+    // Heaviest-first launch order (longest-processing-time-first: the dispatcher hands workgroups to CUs in
+    // index order, so tile weights are dealt round-robin). An approximate order is enough: counting sort of
+    // the tiles into 256 weight classes (an exact LDS bitonic sort of 2500 keys on one workgroup took 31 us).
+    __shared__ uint32_t cls_cnt[256];
+    __shared__ uint32_t cls_off[256];
+    const float scale = maxc > 0 ? 255.0f / (float)maxc : 0.f;
+    if (threadIdx.x < 256) cls_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += 1024) {
+        const uint32_t c = 255u - min(255u, (uint32_t)((float)tile_count[t] * scale));   // class 0 = heaviest
+        atomicAdd(&cls_cnt[c], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {                               // exclusive scan of 256 counters by one wave
+        uint32_t v[4], sum = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v[q] = cls_cnt[threadIdx.x * 4 + q]; sum += v[q]; }
+        uint32_t inc = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(inc, o, 64); if ((int)threadIdx.x >= o) inc += u; }
+        uint32_t run2 = inc - sum;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { cls_off[threadIdx.x * 4 + q] = run2; run2 += v[q]; }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += 1024) {
+        const uint32_t c = 255u - min(255u, (uint32_t)((float)tile_count[t] * scale));
+        order[atomicAdd(&cls_off[c], 1u)] = (uint32_t)t;
     }
 }
 
@@ -164,42 +195,6 @@ __device__ __forceinline__ void bitonic_sort(KeyPtr keys, uint32_t n, int nthrea
     }
 }
 
-// Heaviest-first launch order for the compositing forward (longest-processing-time-first: the
-// dispatcher hands workgroups to CUs in index order, so tile weights are dealt round-robin).
-// An approximate order is enough: counting sort of the tiles into 256 weight classes (O(T), a
-// few microseconds; an exact LDS bitonic sort of 2500 keys on one workgroup took 31 us).
-extern "C" __global__ void __launch_bounds__(1024)
-gsr_tile_order(const uint32_t* __restrict__ tile_count, int T, const unsigned long long* __restrict__ counters,
-               uint32_t* __restrict__ order) {
-    __shared__ uint32_t cls_cnt[256];
-    __shared__ uint32_t cls_off[256];
-    const uint32_t maxc = (uint32_t)counters[3];
-    const float scale = maxc > 0 ? 255.0f / (float)maxc : 0.f;
-    if (threadIdx.x < 256) cls_cnt[threadIdx.x] = 0;
-    __syncthreads();
-    for (int t = threadIdx.x; t < T; t += 1024) {
-        const uint32_t c = 255u - min(255u, (uint32_t)((float)tile_count[t] * scale));   // class 0 = heaviest
-        atomicAdd(&cls_cnt[c], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x < 64) {                               // exclusive scan of 256 counters by one wave
-        uint32_t v[4], sum = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { v[q] = cls_cnt[threadIdx.x * 4 + q]; sum += v[q]; }
-        uint32_t incl = sum;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(incl, o, 64); if ((int)threadIdx.x >= o) incl += u; }
-        uint32_t run = incl - sum;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { cls_off[threadIdx.x * 4 + q] = run; run += v[q]; }
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < T; t += 1024) {
-        const uint32_t c = 255u - min(255u, (uint32_t)((float)tile_count[t] * scale));
-        order[atomicAdd(&cls_off[c], 1u)] = (uint32_t)t;
-    }
-}
-
 // Work list of the segmented backward: one entry per (tile, segment) whose segment starts before
 // the tile's deepest blended list position (tile_last, written by the forward). A 2-D grid
 // (tiles x longest list) would launch ~6x more workgroups than have work, and at 128-entry
@@ -279,11 +274,36 @@ gsr_tile_sort_bucket(const uint32_t* __restrict__ tile_off, const unsigned long 
     const uint32_t n = tile_off[blockIdx.x + 1] - s;
     if (n <= lo_excl || n > hi_incl) return;
     const unsigned long long* __restrict__ src = entries + s;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    bool use_network = n <= 512;
-    if (!use_network) {
+    const int lane = threadIdx.x & 63;
+    constexpr int PER = CAP / NT;                      // entries per thread: ONE pass over HBM, the keys stay in registers
+    unsigned long long mine[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const uint32_t i = threadIdx.x + u * NT;
+        mine[u] = i < n ? src[i] : ~0ull;
+    }
+    if (n <= 256) {
+        // rank sort: every key counts the keys below it (keys are distinct: the index is part of them); the
+        // reads are wave-uniform (broadcast). One barrier instead of the network's 36 for 256 keys -- the list
+        // lengths of DreamGaussian-sized scenes (a few thousand Gaussians on 256 tiles) live here.
+#pragma unroll
+        for (int u = 0; u < PER; ++u) { const uint32_t i = threadIdx.x + u * NT; if (i < n) keys[i] = mine[u]; }
+        __syncthreads();
+        if (threadIdx.x < n) {                          // n <= 256 <= NT: one key per thread
+            const unsigned long long k = mine[0];
+            uint32_t rank = 0;
+            for (uint32_t q = 0; q < n; ++q) rank += keys[q] < k ? 1u : 0u;
+            out_ids[s + rank] = (uint32_t)k;
+        }
+        return;
+    }
+    bool use_network = false;
+    {
         uint32_t mn = 0xffffffffu, mx = 0u;
-        for (uint32_t i = threadIdx.x; i < n; i += NT) { const uint32_t d = (uint32_t)(src[i] >> 32); mn = min(mn, d); mx = max(mx, d); }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            if (threadIdx.x + u * NT < n) { const uint32_t d = (uint32_t)(mine[u] >> 32); mn = min(mn, d); mx = max(mx, d); }
+        }
         mx = wave_max_u32(mx);
         mn = ~wave_max_u32(~mn);
         if (threadIdx.x == 0) { red[32] = 0xffffffffu; red[33] = 0u; red[34] = 0u; }
@@ -296,10 +316,11 @@ gsr_tile_sort_bucket(const uint32_t* __restrict__ tile_off, const unsigned long 
         const float scale = range > 0.f ? (float)NB / range : 0.f;
         for (int b = threadIdx.x; b <= NB; b += NT) { off[b] = 0; if (b < NB) cur[b] = 0; }
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < n; i += NT) {
-            const float f = __uint_as_float((uint32_t)(src[i] >> 32));
-            const int b = min((int)((f - fmin) * scale), NB - 1);
-            atomicAdd(&off[b], 1u);
+        int bucket[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            bucket[u] = min((int)((__uint_as_float((uint32_t)(mine[u] >> 32)) - fmin) * scale), NB - 1);
+            if (threadIdx.x + u * NT < n) atomicAdd(&off[bucket[u]], 1u);
         }
         __syncthreads();
         uint32_t m = 0;
@@ -310,31 +331,31 @@ gsr_tile_sort_bucket(const uint32_t* __restrict__ tile_off, const unsigned long 
         use_network = red[34] > kBucketLimit;             // block-uniform
         if (!use_network) {
             block_excl_scan_u32<NT>(off, NB + 1, red);      // off[NB] = n
-            for (uint32_t i = threadIdx.x; i < n; i += NT) {
-                const unsigned long long k = src[i];
-                const float f = __uint_as_float((uint32_t)(k >> 32));
-                const int b = min((int)((f - fmin) * scale), NB - 1);
-                keys[off[b] + atomicAdd(&cur[b], 1u)] = k;
-            }
+#pragma unroll
+            for (int u = 0; u < PER; ++u)
+                if (threadIdx.x + u * NT < n) keys[off[bucket[u]] + atomicAdd(&cur[bucket[u]], 1u)] = mine[u];
             __syncthreads();
-            for (int b = threadIdx.x; b < NB; b += NT) {
-                const uint32_t lo = off[b], hi = off[b + 1];
-                for (uint32_t i = lo + 1; i < hi; ++i) {
-                    const unsigned long long k = keys[i];
-                    uint32_t j = i;
-                    while (j > lo && keys[j - 1] > k) { keys[j] = keys[j - 1]; --j; }
-                    keys[j] = k;
+            // final position = bucket start + rank inside the bucket (a few keys): no serial insertion, no
+            // second buffer -- the index goes straight to HBM
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                if (threadIdx.x + u * NT < n) {
+                    const uint32_t lo = off[bucket[u]], hi = off[bucket[u] + 1];
+                    const unsigned long long k = mine[u];
+                    uint32_t rank = 0;
+                    for (uint32_t q = lo; q < hi; ++q) rank += keys[q] < k ? 1u : 0u;
+                    out_ids[s + lo + rank] = (uint32_t)k;
                 }
             }
-            __syncthreads();
+            return;
         }
     }
-    if (use_network) {
-        for (uint32_t i = threadIdx.x; i < n; i += NT) keys[i] = src[i];
-        __syncthreads();
-        bitonic_sort(keys, n, NT);
-    }
-    (void)wave;
+    // skewed depths (e.g. thousands of equal keys in one bucket): the network
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < PER; ++u) { const uint32_t i = threadIdx.x + u * NT; if (i < n) keys[i] = mine[u]; }
+    __syncthreads();
+    bitonic_sort(keys, n, NT);
     for (uint32_t i = threadIdx.x; i < n; i += NT) out_ids[s + i] = (uint32_t)keys[i];
 }
 

@@ -81,27 +81,32 @@ gsr_render_fwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict
     // padding slots are read (never used): keep them finite so that 0 * garbage stays 0
     for (int q = lane; q < 3 * (GSR_RB + 2); q += 64) (&stage[wave][0][0])[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     wave_lds_handoff();
-    // Two-deep fetch pipeline: while round r is composited, the records of round r+1 (whose
-    // list entries were fetched during round r-1) and the list entries of round r+2 are in flight.
-    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra;
-    uint32_t id_next = 0;
+    // Three-deep fetch pipeline: while round r is composited, the records of rounds r+1 and r+2 and the
+    // list entries of round r+3 are in flight (the gathers miss the XCD's L2 half of the time: one round of
+    // compositing, ~1 us, does not cover them; registers are free here -- the kernel never fills the wave slots).
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra, na = ra, nb = ra, nc = ra;
+    uint32_t id_next = 0;                                  // list entry of round r+2 (r+3 after the loads below)
     if (start + lane < end) {
         const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + ids[start + lane]);
         ra = p[0]; rb = p[1]; rc = p[2];
     }
-    if (start + GSR_RB + lane < end) id_next = ids[start + GSR_RB + lane];
+    if (start + GSR_RB + lane < end) {
+        const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + ids[start + GSR_RB + lane]);
+        na = p[0]; nb = p[1]; nc = p[2];
+    }
+    if (start + 2 * GSR_RB + lane < end) id_next = ids[start + 2 * GSR_RB + lane];
     for (uint32_t base = start; base < end; base += GSR_RB) {
         if (__ballot(!done) == 0ull) break;
-        float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na, nc = na;
+        float4 ma = make_float4(0.f, 0.f, 0.f, 0.f), mb = ma, mc = ma;
         uint32_t id_next2 = 0;
         {
-            const uint32_t i1 = base + GSR_RB + lane;
-            if (i1 < end) {
-                const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + id_next);
-                na = p[0]; nb = p[1]; nc = p[2];
-            }
             const uint32_t i2 = base + 2 * GSR_RB + lane;
-            if (i2 < end) id_next2 = ids[i2];
+            if (i2 < end) {
+                const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + id_next);
+                ma = p[0]; mb = p[1]; mc = p[2];
+            }
+            const uint32_t i3 = base + 3 * GSR_RB + lane;
+            if (i3 < end) id_next2 = ids[i3];
         }
         const uint32_t rel = base - start;
         if (rel != 0u && (rel & ((1u << seg_shift) - 1u)) == 0u) {    // segment cut: checkpoint for the backward
@@ -133,7 +138,7 @@ gsr_render_fwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict
             }
             wave_lds_handoff();                           // reads above precede the next round's writes
         }
-        ra = na; rb = nb; rc = nc; id_next = id_next2;
+        ra = na; rb = nb; rc = nc; na = ma; nb = mb; nc = mc; id_next = id_next2;
     }
 #undef GSR_FWD_ENTRY
     {   // how deep the backward has to walk this tile's list

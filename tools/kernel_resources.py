@@ -5,7 +5,7 @@
 import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "dreamgaussian_amd", "csrc", "gsr_api.hip")
-out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics",
+out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fno-slp-vectorize",
                       "-fPIC", "-shared", "-Rpass-analysis=kernel-resource-usage", src, "-o", "/tmp/_kr.so"],
                      capture_output=True, text=True).stderr
 rows, cur = [], None
