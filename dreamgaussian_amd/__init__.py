@@ -4,14 +4,15 @@ Public surface (mirrors what gs_renderer.py imports, gs_renderer.py:10-14):
     GaussianRasterizationSettings, GaussianRasterizer   (package `diff_gaussian_rasterization`)
     distCUDA2                                           (package `simple_knn._C`)
 Beside the drop-in names: rasterize_views (several cameras in flight), rasterize_gaussians_raw
-(fused activations), extract_fields (GaussianModel.extract_fields, gs_renderer.py:218-294).
+(fused activations), rasterize_gaussians_split (fused activations + features_dc / features_rest read in place),
+extract_fields (GaussianModel.extract_fields, gs_renderer.py:218-294).
 """
 from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer,
-                         rasterize_gaussians, rasterize_gaussians_raw, last_stats)
+                         rasterize_gaussians, rasterize_gaussians_raw, rasterize_gaussians_split, last_stats)
 from .knn import distCUDA2
 from .batched import rasterize_views
 from .fields import extract_fields
 from .densify import add_densification_stats
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_gaussians_raw",
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_gaussians_raw", "rasterize_gaussians_split",
            "last_stats", "distCUDA2", "rasterize_views", "extract_fields", "add_densification_stats"]

@@ -24,7 +24,8 @@ class GsrView(C.Structure):
                 ("prefiltered", C.c_int32), ("debug", C.c_int32),
                 ("bg", C.c_void_p), ("viewmatrix", C.c_void_p),
                 ("projmatrix", C.c_void_p), ("campos", C.c_void_p),
-                ("raw_activations", C.c_int32), ("reserved", C.c_int32)]
+                ("raw_activations", C.c_int32), ("reserved", C.c_int32),
+                ("shs_rest", C.c_void_p), ("dL_dshs_rest", C.c_void_p)]
 
 
 RESIZE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)

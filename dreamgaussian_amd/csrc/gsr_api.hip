@@ -175,6 +175,7 @@ int check_inputs(int N, int K, const GsrView* v, const float* means3D, const flo
     if (sr == (cov3D != nullptr) || ((scales != nullptr) != (rots != nullptr)))
         return fail(-1, "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!%s", "");
     if (shs && K < (v->sh_degree + 1) * (v->sh_degree + 1)) return fail(-1, "shs has fewer coefficients than sh_degree needs%s", "");
+    if (v->shs_rest && (!shs || K < 2)) return fail(-1, "split SH input (GsrView.shs_rest) needs shs = features_dc and K >= 2%s", "");
     return 0;
 }
 
@@ -183,13 +184,8 @@ constexpr int kHistLdsMaxTiles = 16384;   // 64 KiB of LDS histogram
 // Environment switches kept for same-box A/B measurements (defaults = the shipped path):
 //   GSR_BWD=f2b|q2|quad   backward compositing kernel (gsr_render.hip / gsr_render_exp.hip)
 //   GSR_FWD=u4            experimental forward with four entries per trip (gsr_render_exp.hip)
-//   GSR_SH=direct         K1 reads SH rows with per-lane 16-byte loads (no LDS transpose; measured slower)
 //   GSR_TILE_ORDER=off    forward compositing tiles in row-major instead of heaviest-first order
 //   GSR_SEG_SHIFT=6..8    log2 of the backward segment length in list positions
-bool use_sh_stage() {
-    static const bool v = [] { const char* e = getenv("GSR_SH"); return !(e && strcmp(e, "direct") == 0); }();
-    return v;
-}
 bool use_tile_order_off() {
     static const bool v = [] { const char* e = getenv("GSR_TILE_ORDER"); return e && strcmp(e, "off") == 0; }();
     return v;
@@ -305,24 +301,23 @@ extern "C" int gsr_forward_begin(const GsrView* view, int32_t N, int32_t K,
     HIP_TRY(hipMemsetAsync(gbuf + GL.tile_count, 0, GL.tile_off - GL.tile_count, stream));
     prof_end(stream, "memset_fwd");
 
-    const int sh_direct = use_sh_stage() ? 0 : 1;
     static const int k1_grid = [] {   // GSR_K1_GRID: workgroups of the per-Gaussian kernel (block_stats holds 2048)
         const char* e = getenv("GSR_K1_GRID");
-        const int g = e ? atoi(e) : 512;
+        const int g = e ? atoi(e) : 1024;
         return g < 1 ? 1 : (g > 2048 ? 2048 : g);
     }();
-    const int grid_pre = N > 0 ? (int)fmin((double)((N + 255) / 256), sh_direct ? 2048.0 : (double)k1_grid) : 0;
+    const int grid_pre = N > 0 ? (int)fmin((double)((N + 255) / 256), (double)k1_grid) : 0;
     if (N > 0) {
         const size_t hist_bytes = hist_in_lds ? (((size_t)T * 4 + 15) & ~(size_t)15) : 0;
-        const size_t sh_bytes = (shs && K > 1 && !sh_direct) ? (size_t)256 * (3 * K + 1) * 4 : 0;
-        const size_t lds = hist_bytes + sh_bytes;
+        const bool coop = shs && view->sh_degree > 0;                       // basis table + colour table (gsr_preprocess.hip)
+        const size_t lds = hist_bytes + (coop ? (size_t)256 * GSR_K1_BPITCH * 4 + 256 * 16 : 0);
         if (lds > 160 * 1024) return fail(-1, "preprocess needs more than 160 KiB of LDS%s", "");
         auto k1 = vc.raw_act ? gsr_preprocess_fwd<true> : gsr_preprocess_fwd<false>;
         if (lds > 48 * 1024)
             HIP_TRY(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        prof_begin(stream); hipLaunchKernelGGL(k1, dim3(grid_pre), dim3(256), lds, stream, vc, N, K, means3D, shs,
+        prof_begin(stream); hipLaunchKernelGGL(k1, dim3(grid_pre), dim3(256), lds, stream, vc, N, K, means3D, shs, view->shs_rest,
                            colors_precomp, opacities, scales, rotations, cov3D_precomp, recs, emit, radii,
-                           tile_count, (unsigned long long*)(gbuf + GL.block_stats), hist_in_lds, sh_direct, (uint8_t*)(gbuf + GL.flags8));
+                           tile_count, (unsigned long long*)(gbuf + GL.block_stats), hist_in_lds, (uint8_t*)(gbuf + GL.flags8));
         LAUNCH_CHECK(view, stream, "preprocess_fwd");
     }
     // one single-workgroup kernel: scan of the counts, K1's statistics, heaviest-first launch order
@@ -382,7 +377,9 @@ extern "C" int gsr_forward_finish(const GsrView* view, int32_t N, int32_t K,
         const size_t lds = hist_in_lds ? (size_t)T * 4 : 0;
         if (lds > 48 * 1024)
             HIP_TRY(hipFuncSetAttribute((const void*)gsr_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        prof_begin(stream); hipLaunchKernelGGL(gsr_scatter, dim3(grid_n), dim3(256), lds, stream, N, emit, tile_off, cursor, entries,
+        static const int scatter_grid = [] { const char* e = getenv("GSR_SCATTER_GRID"); const int g = e ? atoi(e) : 512; return g < 1 ? 1 : (g > 4096 ? 4096 : g); }();
+        const int grid_sc = (int)fmin((double)((N + 255) / 256), (double)scatter_grid);
+        prof_begin(stream); hipLaunchKernelGGL(gsr_scatter, dim3(grid_sc), dim3(256), lds, stream, N, emit, tile_off, cursor, entries,
                            vc.gx, T, hist_in_lds, (uint32_t)M);
         LAUNCH_CHECK(view, stream, "scatter");
         // per-tile sort, size classes by list length
@@ -483,6 +480,7 @@ extern "C" int gsr_backward(const GsrView* view, int32_t N, int32_t K,
     if (!dL_dcolor || !dL_ddepth || !dL_dalpha) return fail(-1, "incoming gradients are required%s", "");
     if (!dL_dmeans3D || !dL_dmeans2D || !dL_dopacities) return fail(-1, "dL_dmeans3D/dL_dmeans2D/dL_dopacities are required%s", "");
     if (shs && !dL_dshs) return fail(-1, "dL_dshs is required with shs%s", "");
+    if (view->shs_rest && (!shs || !view->dL_dshs_rest || K < 2)) return fail(-1, "split SH input needs shs (features_dc), K >= 2 and GsrView.dL_dshs_rest%s", "");
     if (!tmp.resize) return fail(-1, "tmp allocator is required%s", "");
     const ViewConst vc = make_view(view);
     const int H = vc.H, W = vc.W;
@@ -554,12 +552,12 @@ extern "C" int gsr_backward(const GsrView* view, int32_t N, int32_t K,
     }
     prof_begin(stream);
     if (vc.raw_act)
-        hipLaunchKernelGGL(gsr_preprocess_bwd<true>, dim3(grid_n), dim3(256), lds, stream, vc, N, K, means3D, shs,
+        hipLaunchKernelGGL(gsr_preprocess_bwd<true>, dim3(grid_n), dim3(256), lds, stream, vc, N, K, means3D, shs, view->shs_rest, view->dL_dshs_rest,
                            colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, (const uint8_t*)(gbuf + GL.flags8), g2d,
                            dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacities, dL_dscales,
                            dL_drotations, dL_dcov3D);
     else
-        hipLaunchKernelGGL(gsr_preprocess_bwd<false>, dim3(grid_n), dim3(256), lds, stream, vc, N, K, means3D, shs,
+        hipLaunchKernelGGL(gsr_preprocess_bwd<false>, dim3(grid_n), dim3(256), lds, stream, vc, N, K, means3D, shs, view->shs_rest, view->dL_dshs_rest,
                            colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, (const uint8_t*)(gbuf + GL.flags8), g2d,
                            dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacities, dL_dscales,
                            dL_drotations, dL_dcov3D);

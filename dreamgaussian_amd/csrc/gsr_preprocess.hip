@@ -158,31 +158,22 @@ __device__ __forceinline__ void stage_rows_in(const float* __restrict__ src, flo
     }
 }
 
-// Software-pipelined variant of stage_rows_in for 256-thread blocks and rows of <= 48 floats
-// (K <= 16): the loads of batch i+1 are issued into registers before batch i is computed and
-// are committed to LDS one iteration later, so the HBM round trip hides behind the math.
-constexpr int STAGE_PF = 12;   // 16-byte loads per thread per batch (256 threads x 12 x 16 B = 48 KiB)
-__device__ __forceinline__ void stage_issue(const float* __restrict__ src, int cnt, int rowlen, float4 (&v)[STAGE_PF]) {
-    const float4* s4 = reinterpret_cast<const float4*>(src);
-    const int nvec = (cnt * rowlen) >> 2;
-#pragma unroll
-    for (int u = 0; u < STAGE_PF; ++u) {
-        const int i = threadIdx.x + u * 256;
-        if (i < nvec) v[u] = s4[i];
+// split rows: element e of a row lives in `dc` (e < 3) or in `rest` (e >= 3): DreamGaussian's two feature tensors
+__device__ __forceinline__ void stage_rows_in_split(const float* __restrict__ dc, const float* __restrict__ rest, float* lds,
+                                                    int cnt, int rowlen) {
+    const int pitch = rowlen + 1, restlen = rowlen - 3;
+    for (int e = threadIdx.x; e < cnt * rowlen; e += blockDim.x) {
+        const int row = e / rowlen, col = e - row * rowlen;
+        lds[row * pitch + col] = col < 3 ? dc[row * 3 + col] : rest[(size_t)row * restlen + (col - 3)];
     }
 }
-template <int RL>   // RL > 0: compile-time row length (48 = SH degree 3), 0: runtime
-__device__ __forceinline__ void stage_commit(float* lds, int cnt, int rowlen_rt, const float4 (&v)[STAGE_PF]) {
-    const int rowlen = RL > 0 ? RL : rowlen_rt;
-    const int nvec = (cnt * rowlen) >> 2, pitch = rowlen + 1;
-#pragma unroll
-    for (int u = 0; u < STAGE_PF; ++u) {
-        const int i = threadIdx.x + u * 256;
-        if (i < nvec) {
-            const int e = 4 * i, row = e / rowlen, col = e - row * rowlen;
-            float* d = lds + row * pitch + col;
-            d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
-        }
+__device__ __forceinline__ void stage_rows_out_split(float* __restrict__ dc, float* __restrict__ rest, const float* lds,
+                                                     int cnt, int rowlen) {
+    const int pitch = rowlen + 1, restlen = rowlen - 3;
+    for (int e = threadIdx.x; e < cnt * rowlen; e += blockDim.x) {
+        const int row = e / rowlen, col = e - row * rowlen;
+        const float v = lds[row * pitch + col];
+        if (col < 3) dc[row * 3 + col] = v; else rest[(size_t)row * restlen + (col - 3)] = v;
     }
 }
 
@@ -208,30 +199,44 @@ __device__ __forceinline__ void stage_rows_out(float* __restrict__ dst, const fl
 }  // namespace
 
 // ---------------------------------------------------------------------------------------
-// K1: preprocess forward.  grid-stride over batches of blockDim.x Gaussians.
-// dynamic LDS: [hist: nTilesLds ints][sh stage: blockDim.x * (3K+1) floats if shs]
+// K1: preprocess forward.  grid-stride over batches of 256 Gaussians, three phases per batch:
+// (per WAVE: the 64 Gaussians of a wave only touch that wave's slice of the LDS tables, no workgroup barrier)
+//   A (lane = Gaussian)      frustum test, view direction, SH basis values -> LDS table
+//   B (lane = coefficient)   16 lanes share one Gaussian: lane k loads coefficient k's three channels with one
+//                            12-byte load (a row is 16 x 12 B contiguous: four rows per wave instruction, fully
+//                            coalesced), multiplies by the basis value and the 16-lane DPP row sums the colour.
+//                            The SH rows never sit in LDS (the round-1 kernel staged 48 floats per Gaussian:
+//                            60 KiB per workgroup, 2 waves per SIMD, 34% of the HBM roofline), and the two
+//                            tensors of DreamGaussian's `get_features` (features_dc / features_rest,
+//                            gs_renderer.py:209-212) can be read where they are: lane 0 reads the first, lanes
+//                            1.. the second -- no torch.cat copy.
+//   C (lane = Gaussian)      projection, 2D covariance, conic, radius, tile rectangle, exact tile emission, record.
+// dynamic LDS: [hist: nTiles u32 when hist_in_lds][basis: 256 x 17 floats][colour: 256 x float4 (w = in-frustum flag)]
 // ---------------------------------------------------------------------------------------
+typedef float gsr_f3 __attribute__((ext_vector_type(3)));
+typedef gsr_f3 gsr_f3u __attribute__((aligned(4)));
+#define GSR_K1_BPITCH 17
+
 template <bool RAW>      // RAW: the inputs are DreamGaussian's raw parameters, activations fused (ViewConst.raw_act)
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 4)
 gsr_preprocess_fwd(ViewConst vc, int N, int K,
                    const float* __restrict__ means3D, const float* __restrict__ shs,
+                   const float* __restrict__ shs_rest /* NULL: shs is [N,K,3]; else shs is [N,1,3] and this [N,K-1,3] */,
                    const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
                    const float* __restrict__ scales, const float* __restrict__ rotations,
                    const float* __restrict__ cov3D_precomp,
                    SplatRec* __restrict__ recs, EmitRec* __restrict__ emit,
                    int32_t* __restrict__ radii, uint32_t* __restrict__ tile_count,
                    unsigned long long* __restrict__ block_stats /*[grid][3]: M_ref, V, max(colour, depth) bits per workgroup*/,
-                   int hist_in_lds, int sh_direct,
+                   int hist_in_lds,
                    uint8_t* __restrict__ flags8 /* colour-clamp bits for K6: 1 B instead of a 64-B record line */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_pp[];
     const int nTiles = vc.gx * vc.gy;
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem_pp);
-    float* shbuf = reinterpret_cast<float*>(smem_pp + (hist_in_lds ? ((nTiles * 4 + 15) & ~15) : 0));
-    const int rowlen = 3 * K;
-    // sh_direct: every lane reads its own SH row with 16-byte loads (no LDS transpose): LDS then
-    // only holds the tile histogram and ~4x more waves fit on a CU -- the kernel is latency-bound
-    // (PMC: 79% of wave cycles waiting at 2 waves/SIMD with the 50 KiB staging buffer).
-    const bool stage = (shs != nullptr) && (K > 1) && !sh_direct;
+    float* basis = reinterpret_cast<float*>(smem_pp + (hist_in_lds ? ((nTiles * 4 + 15) & ~15) : 0));
+    float4* colour = reinterpret_cast<float4*>(basis + 256 * GSR_K1_BPITCH);
+    const int nb = (vc.sh_degree + 1) * (vc.sh_degree + 1);          // active coefficients (<= 16)
+    const bool coop = (shs != nullptr) && nb > 1;                     // phases A/B only for view-dependent colour
 
     if (hist_in_lds) {
         for (int t = threadIdx.x; t < nTiles; t += blockDim.x) hist[t] = 0;
@@ -242,28 +247,75 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
     const float* __restrict__ P = vc.proj;
     unsigned long long my_ref = 0, my_vis = 0;
     float my_cmax = 0.f;              // largest colour component / depth of a listed Gaussian (bound used by the backward)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, grp = lane >> 4;
 
-    const bool pipelined = stage && (rowlen & 3) == 0 && rowlen <= 4 * STAGE_PF && blockDim.x == 256;
-    float4 pf[STAGE_PF];
-    if (pipelined && (int)(blockIdx.x * blockDim.x) < N)
-        stage_issue(shs + (size_t)(blockIdx.x * blockDim.x) * rowlen, min((int)blockDim.x, N - (int)(blockIdx.x * blockDim.x)), rowlen, pf);
-
-    for (int base = blockIdx.x * blockDim.x; base < N; base += gridDim.x * blockDim.x) {
-        const int cnt = min((int)blockDim.x, N - base);
-        if (stage) {
-            __syncthreads();   // previous batch's readers are done
-            if (pipelined) {
-                if (rowlen == 48) stage_commit<48>(shbuf, cnt, rowlen, pf); else stage_commit<0>(shbuf, cnt, rowlen, pf);
-                const int next = base + gridDim.x * blockDim.x;
-                if (next < N) stage_issue(shs + (size_t)next * rowlen, min((int)blockDim.x, N - next), rowlen, pf);
-            } else {
-                stage_rows_in(shs + (size_t)base * rowlen, shbuf, cnt, rowlen);
-            }
-            __syncthreads();
-        }
+    for (int base = blockIdx.x * 256; base < N; base += gridDim.x * 256) {
         const int idx = base + threadIdx.x;
+        float mx = 0.f, my = 0.f, mz = 0.f, depth = 0.f;
+        if (idx < N) {
+            const gsr_f3 m = *reinterpret_cast<const gsr_f3u*>(means3D + 3 * (size_t)idx);
+            mx = m.x; my = m.y; mz = m.z;
+            depth = view_depth(V, mx, my, mz);
+        }
+        const bool front = (idx < N) && depth > 0.2f;
+        // phase C's inputs: requested now, consumed after phase B (their latency hides behind it)
+        float4 q_in = make_float4(1.f, 0.f, 0.f, 0.f);
+        gsr_f3 s_in = {1.f, 1.f, 1.f};
+        float op_in = 0.f;
+        if (front) {
+            op_in = opacities[idx];
+            if (!cov3D_precomp) {
+                q_in = reinterpret_cast<const float4*>(rotations)[idx];
+                s_in = *reinterpret_cast<const gsr_f3u*>(scales + 3 * (size_t)idx);
+            }
+        }
+        if (coop) {
+            // The three phases of a wave's 64 Gaussians touch only this wave's slice of the two LDS tables:
+            // no workgroup barrier, the four waves drift apart and cover each other's memory latency.
+            float* wbasis = basis + wave * 64 * GSR_K1_BPITCH;
+            float4* wcolour = colour + wave * 64;
+            // ---- phase A: basis values of this lane's Gaussian
+            if (front) {
+                float dx = mx - vc.campos[0], dy = my - vc.campos[1], dz = mz - vc.campos[2];
+                const float inv = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
+                dx *= inv; dy *= inv; dz *= inv;
+                float B[16];
+                sh_basis(vc.sh_degree, dx, dy, dz, B);
+                float* row = wbasis + lane * GSR_K1_BPITCH;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) if (k < nb) row[k] = B[k];
+            }
+            wcolour[lane].w = front ? 1.f : 0.f;
+            wave_lds_handoff();
+            // ---- phase B: 16 lanes per Gaussian, lane = coefficient; 16 groups of 4 rows
+            const int wbase = base + wave * 64;
+            for (int it0 = 0; it0 < 16; it0 += 8) {
+                // branch-free loads (address clamped into the tensors, product masked): the eight 12-byte loads of
+                // a group are all in flight before the first one is consumed
+                gsr_f3 cf[8];
+                const int ki = min(l15, nb - 1);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int gi = min(wbase + (it0 + u) * 4 + grp, N - 1);
+                    const float* src = (shs_rest && ki > 0) ? shs_rest + ((size_t)gi * (K - 1) + (ki - 1)) * 3
+                                                            : shs + ((size_t)gi * (shs_rest ? 1 : K) + ki) * 3;
+                    cf[u] = *reinterpret_cast<const gsr_f3u*>(src);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int row = (it0 + u) * 4 + grp;
+                    const bool use = wbase + row < N && l15 < nb && wcolour[row].w != 0.f;
+                    const float bk = use ? wbasis[row * GSR_K1_BPITCH + ki] : 0.f;
+                    const float pr = row_sum16(bk * cf[u].x), pg = row_sum16(bk * cf[u].y), pb = row_sum16(bk * cf[u].z);
+                    if (l15 < 3) reinterpret_cast<float*>(&wcolour[row])[l15] = l15 == 0 ? pr : (l15 == 1 ? pg : pb);
+                }
+            }
+            wave_lds_handoff();
+        }
         if (idx >= N) continue;
 
+        // ---- phase C
         SplatRec rec;
         rec.x = rec.y = rec.qa = rec.qb = rec.qc = rec.opac = rec.r = rec.g = rec.b = rec.depth = 0.f;
         rec.id = (uint32_t)idx; rec.bbx = pack16(1, 0); rec.bby = pack16(1, 0);
@@ -271,12 +323,11 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
         EmitRec em; em.rectx = 0; em.recty = 0; em.depth_bits = 0; em.mask = 0;
         int32_t radius_out = 0;
 
-        const float mx = means3D[3 * idx], my = means3D[3 * idx + 1], mz = means3D[3 * idx + 2];
         float3 pv;
         pv.x = V[0] * mx + V[4] * my + V[8] * mz + V[12];
         pv.y = V[1] * mx + V[5] * my + V[9] * mz + V[13];
-        pv.z = view_depth(V, mx, my, mz);
-        if (pv.z > 0.2f) {
+        pv.z = depth;
+        if (front) {
             const float hx = P[0] * mx + P[4] * my + P[8] * mz + P[12];
             const float hy = P[1] * mx + P[5] * my + P[9] * mz + P[13];
             const float hw = P[3] * mx + P[7] * my + P[11] * mz + P[15];
@@ -288,9 +339,8 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
                 const float* c = cov3D_precomp + 6 * (size_t)idx;
                 S.c0 = c[0]; S.c1 = c[1]; S.c2 = c[2]; S.c3 = c[3]; S.c4 = c[4]; S.c5 = c[5];
             } else {
-                float4 q = reinterpret_cast<const float4*>(rotations)[idx];
-                float3 s;
-                s.x = scales[3 * idx]; s.y = scales[3 * idx + 1]; s.z = scales[3 * idx + 2];
+                float4 q = q_in;
+                float3 s = make_float3(s_in.x, s_in.y, s_in.z);
                 if (RAW) { float inv; q = act_normalize(q, &inv); s.x = __expf(s.x); s.y = __expf(s.y); s.z = __expf(s.z); }
                 s.x *= vc.scale_modifier; s.y *= vc.scale_modifier; s.z *= vc.scale_modifier;
                 float R[9];
@@ -322,39 +372,22 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
                     float cr, cg, cb;
                     uint32_t flags = 0;
                     if (colors_precomp) {
-                        cr = colors_precomp[3 * idx]; cg = colors_precomp[3 * idx + 1]; cb = colors_precomp[3 * idx + 2];
+                        const gsr_f3 c = *reinterpret_cast<const gsr_f3u*>(colors_precomp + 3 * (size_t)idx);
+                        cr = c.x; cg = c.y; cb = c.z;
                     } else {
-                        float dx = mx - vc.campos[0], dy = my - vc.campos[1], dz = mz - vc.campos[2];
-                        const float inv = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
-                        dx *= inv; dy *= inv; dz *= inv;
-                        float B[16];
-                        sh_basis(vc.sh_degree, dx, dy, dz, B);
-                        const int nb = (vc.sh_degree + 1) * (vc.sh_degree + 1);
-                        const float* row = stage ? (shbuf + threadIdx.x * (rowlen + 1)) : (shs + (size_t)idx * rowlen);
-                        float coef[48];
-                        if (!stage && (rowlen & 3) == 0) {          // 16-byte aligned rows: wide loads
-                            const float4* __restrict__ r4 = reinterpret_cast<const float4*>(row);
-#pragma unroll
-                            for (int q = 0; q < 12; ++q) {
-                                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                                if (4 * q < 3 * nb) v = r4[q];
-                                coef[4 * q] = v.x; coef[4 * q + 1] = v.y; coef[4 * q + 2] = v.z; coef[4 * q + 3] = v.w;
-                            }
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 48; ++e) coef[e] = (e < 3 * nb) ? row[e] : 0.f;
-                        }
-                        cr = cg = cb = 0.f;
-#pragma unroll
-                        for (int k = 0; k < 16; ++k) {   // static indices: B[] and coef[] stay in registers
-                            if (k < nb) { cr += B[k] * coef[3 * k]; cg += B[k] * coef[3 * k + 1]; cb += B[k] * coef[3 * k + 2]; }
+                        if (coop) {
+                            const float4 c = colour[threadIdx.x];      // (= this wave's slice, row = lane)
+                            cr = c.x; cg = c.y; cb = c.z;
+                        } else {                            // degree 0: one 12-byte load per lane, no direction
+                            const gsr_f3 c = *reinterpret_cast<const gsr_f3u*>(shs + (size_t)idx * (shs_rest ? 1 : K) * 3);
+                            cr = SH_C0 * c.x; cg = SH_C0 * c.y; cb = SH_C0 * c.z;
                         }
                         cr += 0.5f; cg += 0.5f; cb += 0.5f;
                         if (cr < 0.f) { flags |= 1u; cr = 0.f; }
                         if (cg < 0.f) { flags |= 2u; cg = 0.f; }
                         if (cb < 0.f) { flags |= 4u; cb = 0.f; }
                     }
-                    const float op = RAW ? act_sigmoid(opacities[idx]) : opacities[idx];
+                    const float op = RAW ? act_sigmoid(op_in) : op_in;
                     rec.x = px; rec.y = py;
                     rec.qa = -0.5f * cA * GSR_LOG2E; rec.qb = -cB * GSR_LOG2E; rec.qc = -0.5f * cC * GSR_LOG2E;
                     rec.opac = op; rec.r = cr; rec.g = cg; rec.b = cb; rec.depth = pv.z;
@@ -457,6 +490,8 @@ template <bool RAW>   // RAW: inputs are the raw parameters (fused sigmoid / exp
 __global__ void __launch_bounds__(256)
 gsr_preprocess_bwd(ViewConst vc, int N, int K,
                    const float* __restrict__ means3D, const float* __restrict__ shs,
+                   const float* __restrict__ shs_rest /* split layout (GsrView.shs_rest) or NULL */,
+                   float* __restrict__ dL_dshs_rest,
                    const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
                    const float* __restrict__ scales, const float* __restrict__ rotations,
                    const float* __restrict__ cov3D_precomp, const int32_t* __restrict__ radii,
@@ -477,7 +512,8 @@ gsr_preprocess_bwd(ViewConst vc, int N, int K,
         const int cnt = min((int)blockDim.x, N - base);
         if (stage) {
             __syncthreads();
-            stage_rows_in(shs + (size_t)base * rowlen, shbuf, cnt, rowlen);
+            if (shs_rest) stage_rows_in_split(shs + (size_t)base * 3, shs_rest + (size_t)base * (rowlen - 3), shbuf, cnt, rowlen);
+            else stage_rows_in(shs + (size_t)base * rowlen, shbuf, cnt, rowlen);
             __syncthreads();
         }
         const int idx = base + threadIdx.x;
@@ -688,13 +724,14 @@ gsr_preprocess_bwd(ViewConst vc, int N, int K,
         }
         if (stage) {
             __syncthreads();
-            stage_rows_out(dL_dshs + (size_t)base * rowlen, shbuf, cnt, rowlen);
+            if (shs_rest) stage_rows_out_split(dL_dshs + (size_t)base * 3, dL_dshs_rest + (size_t)base * (rowlen - 3), shbuf, cnt, rowlen);
+            else stage_rows_out(dL_dshs + (size_t)base * rowlen, shbuf, cnt, rowlen);
         }
     }
 }
 
-template __global__ void gsr_preprocess_bwd<false>(ViewConst, int, int, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const int32_t*, const uint8_t*, const float*, float*, float*, float*, float*, float*, float*, float*, float*);
-template __global__ void gsr_preprocess_bwd<true>(ViewConst, int, int, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const int32_t*, const uint8_t*, const float*, float*, float*, float*, float*, float*, float*, float*, float*);
+template __global__ void gsr_preprocess_bwd<false>(ViewConst, int, int, const float*, const float*, const float*, float*, const float*, const float*, const float*, const float*, const float*, const int32_t*, const uint8_t*, const float*, float*, float*, float*, float*, float*, float*, float*, float*);
+template __global__ void gsr_preprocess_bwd<true>(ViewConst, int, int, const float*, const float*, const float*, float*, const float*, const float*, const float*, const float*, const float*, const int32_t*, const uint8_t*, const float*, float*, float*, float*, float*, float*, float*, float*, float*);
 
 // visible[i] = view-space z > 0.2  (frustum rule of A.3)
 extern "C" __global__ void __launch_bounds__(256)

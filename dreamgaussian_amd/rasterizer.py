@@ -69,7 +69,7 @@ def _view_struct(rs: GaussianRasterizationSettings, device, raw: bool = False):
                      float(rs.tanfovy), float(rs.scale_modifier), int(rs.sh_degree),
                      int(bool(rs.prefiltered)), int(bool(rs.debug)),
                      keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(), keep[3].data_ptr(),
-                     1 if raw else 0, 0)
+                     1 if raw else 0, 0, None, None)
     return v, keep
 
 
@@ -83,7 +83,7 @@ def _require_gpu(t: torch.Tensor):
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                cov3Ds_precomp, raster_settings, raw=False):
+                cov3Ds_precomp, raster_settings, raw=False, sh_rest=None):
         _require_gpu(means3D)
         ctx.raw = bool(raw)
         lib = _lib.load()
@@ -103,6 +103,11 @@ class _RasterizeGaussians(torch.autograd.Function):
         K = int(shc.shape[1]) if shc is not None else 0
         if shc is not None and (shc.dim() != 3 or shc.shape[0] != N or shc.shape[2] != 3):
             raise RuntimeError("shs must have dimensions (num_points, num_coeffs, 3)")
+        rest = _f32c(sh_rest, dev)                       # split layout: sh = features_dc [N,1,3], sh_rest = features_rest [N,K-1,3]
+        if rest is not None:
+            if shc is None or K != 1 or rest.dim() != 3 or rest.shape[0] != N or rest.shape[2] != 3:
+                raise RuntimeError("split SH input needs features_dc (num_points, 1, 3) and features_rest (num_points, K-1, 3)")
+            K = 1 + int(rest.shape[1])
 
         color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
         depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
@@ -112,6 +117,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         stats = _lib.GsrStats()
         with torch.cuda.device(dev):
             view, keep = _view_struct(rs, dev, ctx.raw)
+            if rest is not None:
+                view.shs_rest = rest.data_ptr()
+                keep.append(rest)
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             rc = lib.gsr_forward(C.byref(view), N, K, _lib.ptr(m3), _lib.ptr(shc), _lib.ptr(col),
                                  _lib.ptr(op), _lib.ptr(sc), _lib.ptr(rot), _lib.ptr(cov),
@@ -127,6 +135,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.dims = (N, K)
         ctx.fwd_stats = stats
         ctx.present = (shc is not None, col is not None, sc is not None, cov is not None)
+        ctx.k_rest = 0 if rest is None else int(rest.shape[1])
+        ctx.rest_shape = None if rest is None else sh_rest.shape
         empty = torch.empty(0, device=dev)
         ctx.save_for_backward(m3 if m3 is not None else empty, shc if shc is not None else empty,
                               col if col is not None else empty, op if op is not None else empty, sc if sc is not None else empty,
@@ -154,8 +164,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         gc, gd, ga = z(grad_color, (3, H, W)), z(grad_depth, (1, H, W)), z(grad_alpha, (1, H, W))
         # K6 writes every element of every gradient (exact zeros for culled Gaussians): no memset
         # one allocation for all gradients, each carved out at a 256-byte boundary
-        widths = [3, 3, 1, 3 * K if has_sh else 0, 3 if has_col else 0, 3 if has_sr else 0, 4 if has_sr else 0,
-                  6 if has_cov else 0]
+        k_rest = ctx.k_rest                              # split SH: dL/dfeatures_dc and dL/dfeatures_rest are separate tensors
+        k_sh = K - k_rest
+        widths = [3, 3, 1, 3 * k_sh if has_sh else 0, 3 if has_col else 0, 3 if has_sr else 0, 4 if has_sr else 0,
+                  6 if has_cov else 0, 3 * k_rest]
         offs, total = [], 0
         for w_ in widths:
             offs.append(total)
@@ -163,7 +175,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         flat = (torch.empty if N > 0 else torch.zeros)(max(total, 1), dtype=torch.float32, device=dev)
         part = lambda i, *shape: flat[offs[i]:offs[i] + N * widths[i]].view(*shape)
         d_m3, d_m2, d_op = part(0, N, 3), part(1, N, 3), part(2, N, 1)
-        d_sh = part(3, N, K, 3) if has_sh else None
+        d_sh = part(3, N, k_sh, 3) if has_sh else None
+        d_rest = part(8, N, k_rest, 3) if k_rest else None
         d_col = part(4, N, 3) if has_col else None
         d_sc = part(5, N, 3) if has_sr else None
         d_rot = part(6, N, 4) if has_sr else None
@@ -172,6 +185,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             tmp = _lib.Scratch(dev)
             with torch.cuda.device(dev):
                 view, keep = ctx.view
+                if d_rest is not None:
+                    view.dL_dshs_rest = d_rest.data_ptr()
                 stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
                 P = _lib.ptr
                 rc = lib.gsr_backward(
@@ -186,7 +201,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs_ = lambda g, shape: None if g is None or shape is None else g.reshape(shape)
         return (rs_(d_m3, s[0]), rs_(d_m2, s[1]) if tuple(s[1]) == (N, 3) else None, rs_(d_sh, s[2]),
                 rs_(d_col, s[3]), rs_(d_op, s[4]), rs_(d_sc, s[5]), rs_(d_rot, s[6]), rs_(d_cov, s[7]),
-                None, None)
+                None, None, rs_(d_rest, ctx.rest_shape))
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
@@ -203,6 +218,16 @@ def rasterize_gaussians_raw(means3D, means2D, sh, opacity_raw, scaling_raw, rota
     `rasterize_gaussians(means3D, means2D, sh, None, sigmoid(o), exp(s), normalize(q), None, settings)`."""
     return _RasterizeGaussians.apply(means3D, means2D, sh, None, opacity_raw, scaling_raw, rotation_raw,
                                      None, raster_settings, True)
+
+
+def rasterize_gaussians_split(means3D, means2D, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw,
+                              raster_settings):
+    """The whole opt-in front end of SURVEY 8(f) rank 2: RAW parameters as `rasterize_gaussians_raw` AND the two SH
+    tensors DreamGaussian keeps (`_features_dc` [N,1,3], `_features_rest` [N,K-1,3]) read where they are -- no
+    `torch.cat` copy per render (gs_renderer.py:209-212), gradients written straight into two tensors of the same
+    shapes. Same outputs as `rasterize_gaussians_raw(means3D, means2D, cat((features_dc, features_rest), 1), ...)`."""
+    return _RasterizeGaussians.apply(means3D, means2D, features_dc, None, opacity_raw, scaling_raw, rotation_raw,
+                                     None, raster_settings, True, features_rest)
 
 
 class GaussianRasterizer(nn.Module):

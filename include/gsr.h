@@ -58,6 +58,13 @@ typedef struct GsrView {
                               * (_opacity, _scaling, _rotation): sigmoid / exp / normalise (gs_renderer.py:134-142,
                               * 196-216) and their backward run inside the per-Gaussian kernels */
     int32_t reserved;
+    /* Split SH input (the `cat`-free half): when shs_rest != NULL the `shs` argument of
+     * gsr_forward / gsr_backward is DreamGaussian's `_features_dc` [N,1,3] and shs_rest its `_features_rest`
+     * [N,K-1,3] (K still counts all coefficients): the kernels read the two tensors where they are instead of
+     * the torch.cat copy of `get_features` (gs_renderer.py:209-212). In the backward dL_dshs then receives
+     * the [N,1,3] part and dL_dshs_rest (required) the [N,K-1,3] part. NULL = the drop-in layout. */
+    const float* shs_rest;
+    float* dL_dshs_rest;
 } GsrView;
 
 /* Scratch allocator: resize(ctx, bytes) must return a device pointer, 256-byte aligned, to

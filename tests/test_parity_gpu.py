@@ -297,3 +297,37 @@ def test_fused_raw_activations(gpu):
     assert_forward_close([c.detach().cpu(), r.cpu(), d.detach().cpu(), a.detach().cpu()], [oc.detach(), orr, od.detach(), oa.detach()], aux)
     floors = {"rotation": (og["scaling"].abs().max()).item()}
     assert_grads_close(hg, og, aux, floors=floors)
+
+
+def test_split_sh_input_matches_concatenated(gpu):
+    """rasterize_gaussians_split (features_dc / features_rest read where they are) against
+    rasterize_gaussians_raw on the torch.cat of the two tensors (gs_renderer.py:209-212): same kernels, same
+    arithmetic -> identical forward, gradients equal up to the order of the backward's fp32 atomics."""
+    N, deg, W, H = 2500, 3, 176, 128
+    base = O.make_scene(N, deg, 5, "trained")
+    raw = dict(means3D=base["means3D"], dc=base["shs"][:, :1].contiguous(), rest=base["shs"][:, 1:].contiguous(),
+               opacity=torch.logit(base["opacities"].clamp(0.02, 0.98)), scaling=torch.log(base["scales"]),
+               rotation=base["rotations"] * 1.3)
+    S = settings_to(O.make_settings(O.orbit_pose(8.0, -40.0, 2.0), W, H, sh_degree=deg), gpu)
+    w = [x.to(gpu) for x in weights_for(H, W, seed=9)]
+
+    def run(split):
+        t = {k: v.to(gpu).requires_grad_(True) for k, v in raw.items()}
+        m2d = torch.zeros(N, 3, device=gpu, requires_grad=True)
+        if split:
+            out = D.rasterize_gaussians_split(t["means3D"], m2d, t["dc"], t["rest"], t["opacity"], t["scaling"], t["rotation"], S)
+        else:
+            out = D.rasterize_gaussians_raw(t["means3D"], m2d, torch.cat((t["dc"], t["rest"]), 1), t["opacity"], t["scaling"],
+                                            t["rotation"], S)
+        torch.autograd.backward([out[0], out[2], out[3]], w)
+        g = {k: v.grad.detach().cpu() for k, v in t.items()}
+        g["means2D"] = m2d.grad.detach().cpu()
+        return [o.detach().cpu() for o in out], g
+    oa, ga = run(True)
+    ob, gb = run(False)
+    for i in range(4):
+        assert torch.equal(oa[i], ob[i]), i
+    assert tuple(ga["dc"].shape) == (N, 1, 3) and tuple(ga["rest"].shape) == (N, 15, 3)
+    for k in ga:
+        scale = gb[k].abs().max().item() + 1e-30
+        assert (ga[k] - gb[k]).abs().max().item() <= 1e-4 * scale, k
