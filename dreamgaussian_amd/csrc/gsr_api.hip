@@ -183,7 +183,7 @@ constexpr int kHistLdsMaxTiles = 16384;   // 64 KiB of LDS histogram
 
 // Environment switches kept for same-box A/B measurements (defaults = the shipped path):
 //   GSR_BWD=f2b|q2|quad   backward compositing kernel (gsr_render.hip / gsr_render_exp.hip)
-//   GSR_FWD=u4            experimental forward with four entries per trip (gsr_render_exp.hip)
+//   GSR_FWD=q|block|u4    forward with quad lists / 8x8 block lists (default: chosen per scene) / four entries per trip
 //   GSR_TILE_ORDER=off    forward compositing tiles in row-major instead of heaviest-first order
 //   GSR_SEG_SHIFT=6..8    log2 of the backward segment length in list positions
 bool use_tile_order_off() {
@@ -211,6 +211,16 @@ int bwd_kernel() {
 }
 bool use_fwd_u4() {
     static const bool v = [] { const char* e = getenv("GSR_FWD"); return e && strcmp(e, "u4") == 0; }();
+    return v;
+}
+// forward compositing kernel: 0 = per scene (below), 1 = 8x8 block lists, 2 = quad lists
+int fwd_kernel_env() {
+    static const int v = [] {
+        const char* e = getenv("GSR_FWD");
+        if (e && strcmp(e, "q") == 0) return 2;
+        if (e && strcmp(e, "block") == 0) return 1;
+        return 0;
+    }();
     return v;
 }
 
@@ -407,7 +417,14 @@ extern "C" int gsr_forward_finish(const GsrView* view, int32_t N, int32_t K,
         }
     }
     prof_begin(stream);
-    if (use_fwd_u4())
+    // Quad lists pay when splats are small against an 8x8 block (few of its 64 lanes blend a given Gaussian):
+    // measured -2% / -7% / -9% at 1M blob / 1M trained / 250k-512^2 (4.2-4.3 reference tiles per Gaussian) and +7% at
+    // 100k-800^2 (10.4): the scene statistic the host already holds decides.
+    const bool fwd_q = fwd_kernel_env() == 2 || (fwd_kernel_env() == 0 && V > 0 && M_ref <= 6ull * V);
+    if (fwd_q)
+        hipLaunchKernelGGL(gsr_render_fwd_q, dim3(T), dim3(256), 0, stream, tile_off, recs, sorted_ids, view->bg, W, H, vc.gx,
+                           out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, tile_order, seg_shift(), tile_last);
+    else if (use_fwd_u4())
         hipLaunchKernelGGL(gsr_render_fwd_u4, dim3(T), dim3(256), 0, stream, tile_off, recs, sorted_ids, view->bg, W, H, vc.gx,
                            out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, tile_order, seg_shift(), tile_last);
     else

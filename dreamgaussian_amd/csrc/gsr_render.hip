@@ -159,6 +159,163 @@ gsr_render_fwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict
     }
 }
 
+// -----------------------------------------------------------------------------------------
+// K5 with quad lists (GSR_FWD=q): the forward counterpart of gsr_render_bwd_q2's pass 1. Every 16-lane row of a
+// wave owns a 4x4 pixel quad with its own list of staged slots (exact ellipse-vs-quad tests, quad_max_powers);
+// the wave loops to the longest of the four lists, and a quad whose sixteen pixels have all stopped drops out.
+// Same arithmetic per (pixel, Gaussian) as gsr_render_fwd: bit-identical images.
+// -----------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+gsr_render_fwd_q(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict__ recs,
+                 const uint32_t* __restrict__ ids,
+                 const float* __restrict__ bg, int W, int H, int gx,
+                 float* __restrict__ out_color, float* __restrict__ out_depth,
+                 float* __restrict__ out_alpha, float* __restrict__ final_T,
+                 uint32_t* __restrict__ n_contrib, float* __restrict__ totals /*[5][H*W]*/,
+                 float* __restrict__ ckpt, const uint32_t* __restrict__ tile_seg,
+                 const uint32_t* __restrict__ tile_order /* heaviest tile first, or NULL */,
+                 int seg_shift, uint32_t* __restrict__ tile_last /* max list position blended in the tile */) {
+    __shared__ float4 stage[4][3][GSR_RB];                                   // slot = fetching lane
+    __shared__ __attribute__((aligned(8))) uint8_t qlist[4][4][80];          // [wave][quad][k] = staged slot of the quad's k-th entry
+    const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int row = lane >> 4, l15 = lane & 15;
+    const int bx = (tile % gx) * GSR_TILE + (wave & 1) * 8;
+    const int by = (tile / gx) * GSR_TILE + (wave >> 1) * 8;
+    if (bx >= W || by >= H) return;                       // whole block outside the image
+    const int lx = (row & 1) * 4 + (l15 & 3), ly = (row >> 1) * 4 + (l15 >> 2);
+    const int px = bx + lx, py = by + ly;
+    const bool inside = (px < W) && (py < H);
+    const float pxf = (float)px, pyf = (float)py;
+    const int cidx = wave * 64 + ly * 8 + lx;             // checkpoint slot (row-major 8x8: the backward's layout)
+    const uint32_t start = tile_off[tile], end = tile_off[tile + 1];
+    float4* __restrict__ sa = stage[wave][0];
+    float4* __restrict__ sb = stage[wave][1];
+    float4* __restrict__ sc = stage[wave][2];
+    const uint8_t* __restrict__ ql = qlist[wave][row];
+    for (int q = lane; q < 4 * 80 / 4; q += 64) reinterpret_cast<uint32_t*>(&qlist[wave][0][0])[q] = 0u;   // stale reads stay inside the stage
+    for (int q = lane; q < 3 * GSR_RB; q += 64) (&stage[wave][0][0])[q] = make_float4(0.f, 0.f, 0.f, 0.f);  // ... and finite
+    wave_lds_handoff();
+
+    float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, A = 0.f;
+    uint32_t last = 0;
+    bool done = !inside;
+    const float bx0 = (float)bx, by0 = (float)by;
+
+    // ea = x y qa qb | eb = qc opac r g | ec = b depth - - ; kpos = 1-based list position (row-uniform)
+#define GSR_FWDQ_ENTRY(ea, eb, ec, kpos, valid)                                                \
+    {                                                                                          \
+        const float dx = ea.x - pxf, dy = ea.y - pyf;                                          \
+        const float power = ea.z * dx * dx + eb.x * dy * dy + ea.w * dx * dy; /* log2 units */ \
+        const float alpha = fminf(0.99f, eb.y * fast_exp2(power));                             \
+        const bool ok = (valid) && !done && (power <= 0.f) && (alpha >= (1.0f / 255.0f));      \
+        const float test_T = T * (1.f - alpha);                                                \
+        const bool stop = ok && (test_T < 0.0001f);                                            \
+        const bool acc = ok && !stop;                                                          \
+        const float w = acc ? alpha * T : 0.f;                                                 \
+        C0 += eb.z * w; C1 += eb.w * w; C2 += ec.x * w;                                        \
+        D += ec.y * w; A += w;                                                                 \
+        T = acc ? test_T : T;                                                                  \
+        last = acc ? (kpos) : last;                                                            \
+        done = done || stop;                                                                   \
+    }
+
+    const uint32_t seg_slot0 = tile_seg[tile];
+    // three-deep fetch pipeline as gsr_render_fwd
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra, na = ra, nb = ra, nc = ra;
+    uint32_t id_next = 0;
+    if (start + lane < end) {
+        const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + ids[start + lane]);
+        ra = p[0]; rb = p[1]; rc = p[2];
+    }
+    if (start + GSR_RB + lane < end) {
+        const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + ids[start + GSR_RB + lane]);
+        na = p[0]; nb = p[1]; nc = p[2];
+    }
+    if (start + 2 * GSR_RB + lane < end) id_next = ids[start + 2 * GSR_RB + lane];
+    for (uint32_t base = start; base < end; base += GSR_RB) {
+        const unsigned long long alive = __ballot(!done);
+        if (alive == 0ull) break;
+        float4 ma = make_float4(0.f, 0.f, 0.f, 0.f), mb = ma, mc = ma;
+        uint32_t id_next2 = 0;
+        {
+            const uint32_t i2 = base + 2 * GSR_RB + lane;
+            if (i2 < end) {
+                const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + id_next);
+                ma = p[0]; mb = p[1]; mc = p[2];
+            }
+            const uint32_t i3 = base + 3 * GSR_RB + lane;
+            if (i3 < end) id_next2 = ids[i3];
+        }
+        const uint32_t rel = base - start;
+        if (rel != 0u && (rel & ((1u << seg_shift) - 1u)) == 0u) {    // segment cut: checkpoint for the backward
+            float* c = ckpt + (size_t)(seg_slot0 + (rel >> seg_shift) - 1u) * GSR_CKPT_FLOATS + cidx;
+            c[0] = T; c[256] = C0; c[512] = C1; c[768] = C2; c[1024] = D; c[1280] = A;
+        }
+        const uint32_t i = base + lane;
+        bool h0 = false, h1 = false, h2 = false, h3 = false;
+        if (i < end) {
+            const float thr = min_visible_power(rb.y);
+            float qp[4];
+            quad_max_powers(ra.x, ra.y, ra.z, ra.w, rb.x, bx0, by0, qp);
+            // a quad whose pixels have all stopped takes no more entries
+            h0 = ((alive & 0x000000000000ffffull) != 0ull) && qp[0] >= thr;
+            h1 = ((alive & 0x00000000ffff0000ull) != 0ull) && qp[1] >= thr;
+            h2 = ((alive & 0x0000ffff00000000ull) != 0ull) && qp[2] >= thr;
+            h3 = ((alive & 0xffff000000000000ull) != 0ull) && qp[3] >= thr;
+        }
+        const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
+        if ((m0 | m1 | m2 | m3) != 0ull) {
+            if (h0 | h1 | h2 | h3) { sa[lane] = ra; sb[lane] = rb; sc[lane] = rc; }
+            if (h0) qlist[wave][0][lanes_below(m0)] = (uint8_t)lane;
+            if (h1) qlist[wave][1][lanes_below(m1)] = (uint8_t)lane;
+            if (h2) qlist[wave][2][lanes_below(m2)] = (uint8_t)lane;
+            if (h3) qlist[wave][3][lanes_below(m3)] = (uint8_t)lane;
+            const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
+            const int nmax = max(max(n0, n1), max(n2, n3));
+            const int nmine = row == 0 ? n0 : (row == 1 ? n1 : (row == 2 ? n2 : n3));
+            const uint32_t pos1 = rel + 1u;               // 1-based list position of staged slot 0
+            wave_lds_handoff();
+            for (int jb = 0; jb < nmax; jb += 8) {
+                const uint2 sl = *reinterpret_cast<const uint2*>(ql + jb);
+                uint32_t slot[8];
+#pragma unroll
+                for (int b = 0; b < 8; ++b) slot[b] = ((b < 4 ? sl.x : sl.y) >> (8 * (b & 3))) & 0xffu;
+                float4 ea = sa[slot[0]], eb = sb[slot[0]], ec = sc[slot[0]];
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    if (jb + b < nmax) {                  // wave-uniform
+                        float4 xa = ea, xb = eb, xc = ec;
+                        if (b + 1 < 8) { xa = sa[slot[b + 1]]; xb = sb[slot[b + 1]]; xc = sc[slot[b + 1]]; }   // in flight during entry b
+                        GSR_FWDQ_ENTRY(ea, eb, ec, pos1 + slot[b], jb + b < nmine)
+                        ea = xa; eb = xb; ec = xc;
+                    }
+                }
+            }
+            wave_lds_handoff();                           // reads above precede the next round's writes
+        }
+        ra = na; rb = nb; rc = nc; na = ma; nb = mb; nc = mc; id_next = id_next2;
+    }
+#undef GSR_FWDQ_ENTRY
+    {   // how deep the backward has to walk this tile's list
+        const uint32_t wl = wave_max_u32(last);
+        if (lane == 0 && wl != 0u) atomicMax(&tile_last[tile], wl);
+    }
+    if (inside) {
+        const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
+        final_T[pix] = T;
+        n_contrib[pix] = last;
+        out_color[pix] = C0 + T * bg[0];
+        out_color[HW + pix] = C1 + T * bg[1];
+        out_color[2 * HW + pix] = C2 + T * bg[2];
+        out_depth[pix] = D;
+        out_alpha[pix] = A;
+        totals[pix] = C0; totals[HW + pix] = C1; totals[2 * HW + pix] = C2;   // sums without background
+        totals[3 * HW + pix] = D; totals[4 * HW + pix] = A;
+    }
+}
+
 // =========================================================================================
 // Backward, FRONT TO BACK and depth-segmented.
 //
@@ -405,7 +562,9 @@ __device__ __forceinline__ unsigned long long to_fixed(float v, int e) {
     return ((unsigned long long)(uint32_t)(int32_t)hi << 32) | (unsigned long long)(uint32_t)lo;
 }
 __device__ __forceinline__ float from_fixed(unsigned long long v, int e) {
-    return ldexpf((float)(long long)v, -e);
+    // two conversions + one fma instead of the 13-instruction i64 -> f32 sequence (double rounding: <= 1 ulp)
+    const float hi = (float)(int32_t)(uint32_t)(v >> 32), lo = (float)(uint32_t)v;
+    return ldexpf(fmaf(hi, 4294967296.f, lo), -e);
 }
 // exponent with 2^result > R for the per-row scale of the moments; the SAME expression in pass 2 and in the flush
 __device__ __forceinline__ int row_radius_exp(float gx, float gy, float tcx, float tcy) {
