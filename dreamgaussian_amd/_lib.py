@@ -37,7 +37,7 @@ class GsrAlloc(C.Structure):
 
 class GsrStats(C.Structure):
     _fields_ = [("num_instances", C.c_int64), ("num_instances_ref", C.c_int64),
-                ("num_visible", C.c_int64), ("max_tile_count", C.c_int64)]
+                ("num_visible", C.c_int64), ("max_tile_count", C.c_int64), ("bin_capacity", C.c_int64)]
 
 
 _lock = threading.Lock()

@@ -22,7 +22,8 @@ namespace {
 
 thread_local char g_err[512] = "";
 thread_local unsigned long long* g_pinned = nullptr;   // 8 x u64 host-pinned scratch
-thread_local size_t g_bin_hint = 0;                    // bin scratch of this thread's previous gsr_forward + 25%
+struct FwdHint { bool valid = false; int N = 0, H = 0, W = 0; unsigned long long M = 0, maxc = 0, M_ref = 0, V = 0; };
+thread_local FwdHint g_hint;                            // this thread's previous gsr_forward: predicts the next one's list sizes
 thread_local hipEvent_t g_copied_own = nullptr;        // this thread's "counters copied" event (gsr_forward)
 thread_local hipEvent_t g_copied = nullptr;            // set while gsr_forward drives gsr_forward_begin
 
@@ -340,17 +341,21 @@ extern "C" int gsr_forward_begin(const GsrView* view, int32_t N, int32_t K,
     return 0;
 }
 
-extern "C" int gsr_forward_finish(const GsrView* view, int32_t N, int32_t K,
-                                  float* out_color, float* out_depth, float* out_alpha,
-                                  void* geom_ptr, void* img_ptr, GsrAlloc bin,
-                                  const uint64_t* host_counters, GsrStats* stats, gsr_stream_t stream_) {
+namespace {
+int sort_class(unsigned long long maxc) { return maxc <= 2048 ? 0 : (maxc <= 8192 ? 1 : (maxc <= 16384 ? 2 : 3)); }
+
+// Binning, sort and compositing for lists of up to `cap` instances whose longest is assumed <= `maxc`.
+// cap / maxc are either the exact counters (the host has waited for them) or gsr_forward's prediction; in the
+// second case M_ref / V steer only the per-scene kernel choice and the kernels themselves check the true M.
+int finish_impl(const GsrView* view, int32_t N, float* out_color, float* out_depth, float* out_alpha,
+                void* geom_ptr, void* img_ptr, GsrAlloc bin, unsigned long long M_ref, unsigned long long V,
+                unsigned long long cap, unsigned long long maxc, gsr_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (int rc = check_view(view)) return rc;
     if (!out_color || !out_depth || !out_alpha) return fail(-1, "output pointers are required%s", "");
-    if (!geom_ptr || !img_ptr || !bin.resize || !host_counters) return fail(-1, "forward_begin state is required%s", "");
+    if (!geom_ptr || !img_ptr || !bin.resize) return fail(-1, "forward_begin state is required%s", "");
     char* gbuf = (char*)geom_ptr;
     char* ibuf = (char*)img_ptr;
-    (void)K;
     const ViewConst vc = make_view(view);
     const int H = vc.H, W = vc.W;
     const GeomLayout GL = geom_layout(N, H, W);
@@ -371,9 +376,8 @@ extern "C" int gsr_forward_finish(const GsrView* view, int32_t N, int32_t K,
 
     const int hist_in_lds = T <= kHistLdsMaxTiles;
     const int grid_n = N > 0 ? (int)fmin((double)((N + 255) / 256), 512.0) : 0;
-    (void)emit; (void)tile_count; (void)counters;
-    const unsigned long long M_ref = host_counters[0], V = host_counters[1], M = host_counters[2], maxc = host_counters[3];
-    if (stats) { stats->num_instances = (int64_t)M; stats->num_instances_ref = (int64_t)M_ref; stats->num_visible = (int64_t)V; stats->max_tile_count = (int64_t)maxc; }
+    (void)tile_count;
+    const unsigned long long M = cap;
     if (M >= 0xfffffff0ull) return fail(-5, "too many tile instances (%s%lld)", "", (long long)M);
 
     const BinLayout BL = bin_layout((size_t)M, T);
@@ -390,7 +394,7 @@ extern "C" int gsr_forward_finish(const GsrView* view, int32_t N, int32_t K,
         static const int scatter_grid = [] { const char* e = getenv("GSR_SCATTER_GRID"); const int g = e ? atoi(e) : 512; return g < 1 ? 1 : (g > 4096 ? 4096 : g); }();
         const int grid_sc = (int)fmin((double)((N + 255) / 256), (double)scatter_grid);
         prof_begin(stream); hipLaunchKernelGGL(gsr_scatter, dim3(grid_sc), dim3(256), lds, stream, N, emit, tile_off, cursor, entries,
-                           vc.gx, T, hist_in_lds, (uint32_t)M);
+                           vc.gx, T, hist_in_lds, (uint32_t)M, counters);
         LAUNCH_CHECK(view, stream, "scatter");
         // per-tile sort, size classes by list length
         constexpr size_t lds_s = 2048 * 8 + (512 + 1 + 512 + 40) * 4;
@@ -401,18 +405,18 @@ extern "C" int gsr_forward_finish(const GsrView* view, int32_t N, int32_t K,
                 if (e != hipSuccess) return e;
                 return hipFuncSetAttribute((const void*)gsr_tile_sort_bucket<16384, 1024, 2048>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l);
             })) return rc;
-        prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<2048, 256, 512>), dim3(T), dim3(256), lds_s, stream, tile_off, entries, sorted_ids, 0u, 2048u);
+        prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<2048, 256, 512>), dim3(T), dim3(256), lds_s, stream, tile_off, entries, sorted_ids, 0u, 2048u, counters, (uint32_t)M);
         LAUNCH_CHECK(view, stream, "tile_sort_small");
         if (maxc > 2048) {
-            prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<8192, 1024, 2048>), dim3(T), dim3(1024), lds_m, stream, tile_off, entries, sorted_ids, 2048u, 8192u);
+            prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<8192, 1024, 2048>), dim3(T), dim3(1024), lds_m, stream, tile_off, entries, sorted_ids, 2048u, 8192u, counters, (uint32_t)M);
             LAUNCH_CHECK(view, stream, "tile_sort_medium");
         }
         if (maxc > 8192) {
-            prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<16384, 1024, 2048>), dim3(T), dim3(1024), lds_l, stream, tile_off, entries, sorted_ids, 8192u, 16384u);
+            prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<16384, 1024, 2048>), dim3(T), dim3(1024), lds_l, stream, tile_off, entries, sorted_ids, 8192u, 16384u, counters, (uint32_t)M);
             LAUNCH_CHECK(view, stream, "tile_sort_large");
         }
         if (maxc > 16384) {
-            prof_begin(stream); hipLaunchKernelGGL(gsr_tile_sort_global_ids, dim3(T), dim3(1024), 0, stream, tile_off, entries, sorted_ids, 16384u);
+            prof_begin(stream); hipLaunchKernelGGL(gsr_tile_sort_global_ids, dim3(T), dim3(1024), 0, stream, tile_off, entries, sorted_ids, 16384u, counters, (uint32_t)M);
             LAUNCH_CHECK(view, stream, "tile_sort_global");
         }
     }
@@ -423,17 +427,29 @@ extern "C" int gsr_forward_finish(const GsrView* view, int32_t N, int32_t K,
     const bool fwd_q = fwd_kernel_env() == 2 || (fwd_kernel_env() == 0 && V > 0 && M_ref <= 6ull * V);
     if (fwd_q)
         hipLaunchKernelGGL(gsr_render_fwd_q, dim3(T), dim3(256), 0, stream, tile_off, recs, sorted_ids, view->bg, W, H, vc.gx,
-                           out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, tile_order, seg_shift(), tile_last);
+                           out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, tile_order, seg_shift(), tile_last, counters, (uint32_t)M);
     else if (use_fwd_u4())
         hipLaunchKernelGGL(gsr_render_fwd_u4, dim3(T), dim3(256), 0, stream, tile_off, recs, sorted_ids, view->bg, W, H, vc.gx,
-                           out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, tile_order, seg_shift(), tile_last);
+                           out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, tile_order, seg_shift(), tile_last, counters, (uint32_t)M);
     else
         hipLaunchKernelGGL(gsr_render_fwd, dim3(T), dim3(256), 0, stream, tile_off, recs, sorted_ids, view->bg, W, H, vc.gx,
-                           out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, tile_order, seg_shift(), tile_last);
+                           out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, tile_order, seg_shift(), tile_last, counters, (uint32_t)M);
     LAUNCH_CHECK(view, stream, "render_fwd");
     return 0;
 }
+}  // namespace
 
+extern "C" int gsr_forward_finish(const GsrView* view, int32_t N, int32_t K,
+                                  float* out_color, float* out_depth, float* out_alpha,
+                                  void* geom_ptr, void* img_ptr, GsrAlloc bin,
+                                  const uint64_t* host_counters, GsrStats* stats, gsr_stream_t stream_) {
+    (void)K;
+    if (!host_counters) return fail(-1, "forward_begin state is required%s", "");
+    const unsigned long long M_ref = host_counters[0], V = host_counters[1], M = host_counters[2], maxc = host_counters[3];
+    if (stats) { stats->num_instances = (int64_t)M; stats->num_instances_ref = (int64_t)M_ref; stats->num_visible = (int64_t)V;
+                 stats->max_tile_count = (int64_t)maxc; stats->bin_capacity = (int64_t)M; }
+    return finish_impl(view, N, out_color, out_depth, out_alpha, geom_ptr, img_ptr, bin, M_ref, V, M, maxc, stream_);
+}
 
 extern "C" int gsr_forward(const GsrView* view, int32_t N, int32_t K,
                            const float* means3D, const float* shs, const float* colors_precomp,
@@ -459,23 +475,40 @@ extern "C" int gsr_forward(const GsrView* view, int32_t N, int32_t K,
                                            radii, ag, ai, (uint64_t*)g_pinned, stream_);
     g_copied = nullptr;
     if (rc_begin) return rc_begin;
-    // While the per-Gaussian stage runs: ask for the bin scratch with last call's size + 25% (the host is
-    // about to wait anyway); the real request after the round trip is served from it when it fits.
-    struct BinPre { GsrAlloc inner; void* pre; size_t cap; };
-    BinPre bp{bin, nullptr, 0};
-    if (g_bin_hint) { bp.pre = bin.resize(bin.ctx, g_bin_hint); bp.cap = bp.pre ? g_bin_hint : 0; }
-    auto bin_tramp = [](void* ctx, size_t bytes) -> void* {
-        BinPre* b = (BinPre*)ctx;
-        return (b->pre && bytes <= b->cap) ? b->pre : b->inner.resize(b->inner.ctx, bytes);
-    };
-    HIP_TRY(hipEventSynchronize(ev));
-    const int rc = gsr_forward_finish(view, N, K, out_color, out_depth, out_alpha, cg.ptr, ci.ptr, GsrAlloc{&bp, bin_tramp},
-                                      (const uint64_t*)g_pinned, stats, stream_);
-    if (rc == 0) {
-        const ViewConst vc = make_view(view);
-        const size_t need = bin_layout((size_t)g_pinned[2], geom_layout(N, vc.H, vc.W).nTiles).total;
-        g_bin_hint = need + need / 4;
+    const ViewConst vcs = make_view(view);
+    const GeomLayout GLs = geom_layout(N, vcs.H, vcs.W);
+    // Speculation (GSR_SPECULATE=1, off by default): the previous call of this thread on the same problem shape predicts
+    // M (+25 %) and the sort classes; binning / sort / compositing are enqueued at once, the host waits for the counters
+    // only afterwards and repeats the tail when the prediction was too small (the kernels refuse to touch lists that do
+    // not fit: gsr_scatter). Correct (tests/test_parity_gpu.py::test_speculative_forward_recovers_from_mispredictions) but
+    // MEASURED SLOWER on the MI355X: 250k / 512^2 0.361 -> 0.441 ms per fwd+bwd, 100k / 800^2 0.347 -> 0.401, 5k / 256^2
+    // and 1M / 800^2 unchanged -- hipEventSynchronize on the early event returns only when the work enqueued behind it has
+    // drained, so the backward's launches start late. The default keeps the early wait (K1 + scan only ahead of it).
+    static const bool spec_on = [] { const char* e = getenv("GSR_SPECULATE"); return e && e[0] == '1'; }();
+    const bool spec = spec_on && g_hint.valid && g_hint.N == N && g_hint.H == vcs.H && g_hint.W == vcs.W && N > 0;
+    unsigned long long cap = 0, capc = 0;
+    int rc = 0;
+    if (spec) {
+        cap = g_hint.M + g_hint.M / 4 + 4096;
+        const unsigned long long c = g_hint.maxc + g_hint.maxc / 4 + 64;
+        capc = c <= 2048 ? 2048 : (c <= 8192 ? 8192 : (c <= 16384 ? 16384 : ~0ull));
+        rc = finish_impl(view, N, out_color, out_depth, out_alpha, cg.ptr, ci.ptr, bin, g_hint.M_ref, g_hint.V, cap, capc, stream_);
+        if (rc) return rc;
     }
+    HIP_TRY(hipEventSynchronize(ev));
+    const unsigned long long M_ref = g_pinned[0], V = g_pinned[1], M = g_pinned[2], maxc = g_pinned[3];
+    if (spec && (M > cap || sort_class(maxc) > sort_class(capc))) {
+        // misprediction: the kernels above left without writing; clear what the scatter / forward accumulate into
+        HIP_TRY(hipMemsetAsync((char*)cg.ptr + GLs.cursor, 0, GLs.counters - GLs.cursor, (hipStream_t)stream_));
+        cap = 0;
+    }
+    if (!spec || cap == 0) {
+        cap = M;
+        rc = finish_impl(view, N, out_color, out_depth, out_alpha, cg.ptr, ci.ptr, bin, M_ref, V, M, maxc, stream_);
+    }
+    if (stats) { stats->num_instances = (int64_t)M; stats->num_instances_ref = (int64_t)M_ref; stats->num_visible = (int64_t)V;
+                 stats->max_tile_count = (int64_t)maxc; stats->bin_capacity = (int64_t)cap; }
+    if (rc == 0) { g_hint.valid = true; g_hint.N = N; g_hint.H = vcs.H; g_hint.W = vcs.W; g_hint.M = M; g_hint.maxc = maxc; g_hint.M_ref = M_ref; g_hint.V = V; }
     return rc;
 }
 
@@ -514,15 +547,16 @@ extern "C" int gsr_backward(const GsrView* view, int32_t N, int32_t K,
     const uint32_t* tile_seg = (const uint32_t*)(gbuf + GL.tile_seg);
     // M and the longest tile list of the matching forward (for the checkpoint offset and the
     // segment grid): from the caller's GsrStats, else read back from the device (blocking)
-    unsigned long long M = 0, maxc = 0;
-    if (fwd_stats) { M = (unsigned long long)fwd_stats->num_instances; maxc = (unsigned long long)fwd_stats->max_tile_count; }
+    // the layout of `bin` follows the capacity it was sized for (>= M): from the caller's GsrStats, else read back
+    // from the device (blocking): counters[6], left there by the forward's scatter kernel
+    unsigned long long M = 0;
+    if (fwd_stats) M = (unsigned long long)(fwd_stats->num_instances > 0 ? fwd_stats->bin_capacity : 0);
     else {
-        unsigned long long h[4];
+        unsigned long long h[8];
         HIP_TRY(hipMemcpyAsync(h, counters, sizeof(h), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        M = h[2]; maxc = h[3];
+        M = h[2] > 0 ? h[6] : 0;
     }
-    (void)maxc;
     const uint32_t* sorted_ids = (const uint32_t*)bin;    // BinLayout.ids == 0
 
     float* g2d = (float*)tmp.resize(tmp.ctx, align_up((size_t)N * GSR_G2D_STRIDE * 4));

@@ -118,9 +118,13 @@ gsr_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ ti
 extern "C" __global__ void __launch_bounds__(256)
 gsr_scatter(int N, const EmitRec* __restrict__ emit, const uint32_t* __restrict__ tile_off,
             uint32_t* __restrict__ cursor, unsigned long long* __restrict__ entries,
-            int gx, int nTiles, int hist_in_lds, uint32_t capacity) {
+            int gx, int nTiles, int hist_in_lds, uint32_t capacity, unsigned long long* __restrict__ counters) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem_raw);
+    // The scratch may have been sized BEFORE the host knew M (gsr_forward: previous call + 25 %). M is on the
+    // device: every consumer of the lists leaves at once when they do not fit, and the host repeats the tail.
+    if (counters[2] > (unsigned long long)capacity) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) counters[6] = capacity;    // for a backward called without GsrStats
     if (hist_in_lds) {
         for (int t = threadIdx.x; t < nTiles; t += blockDim.x) hist[t] = 0;
         __syncthreads();
@@ -264,7 +268,9 @@ __device__ __forceinline__ void block_excl_scan_u32(uint32_t* a, int n, uint32_t
 template <int CAP, int NT, int NBMAX>
 __global__ void __launch_bounds__(NT)
 gsr_tile_sort_bucket(const uint32_t* __restrict__ tile_off, const unsigned long long* __restrict__ entries,
-                     uint32_t* __restrict__ out_ids, uint32_t lo_excl, uint32_t hi_incl) {
+                     uint32_t* __restrict__ out_ids, uint32_t lo_excl, uint32_t hi_incl,
+                     const unsigned long long* __restrict__ counters, uint32_t capacity) {
+    if (counters[2] > (unsigned long long)capacity) return;            // lists do not fit the scratch (see gsr_scatter)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem_raw);
     uint32_t* off = reinterpret_cast<uint32_t*>(smem_raw + (size_t)CAP * 8);
@@ -362,7 +368,9 @@ gsr_tile_sort_bucket(const uint32_t* __restrict__ tile_off, const unsigned long 
 // lists longer than the largest LDS class: network in place in HBM, then the same outputs
 extern "C" __global__ void __launch_bounds__(1024)
 gsr_tile_sort_global_ids(const uint32_t* __restrict__ tile_off, unsigned long long* __restrict__ entries,
-                         uint32_t* __restrict__ out_ids, uint32_t lo_excl) {
+                         uint32_t* __restrict__ out_ids, uint32_t lo_excl,
+                         const unsigned long long* __restrict__ counters, uint32_t capacity) {
+    if (counters[2] > (unsigned long long)capacity) return;
     const uint32_t s = tile_off[blockIdx.x];
     const uint32_t n = tile_off[blockIdx.x + 1] - s;
     if (n <= lo_excl) return;
@@ -370,6 +378,6 @@ gsr_tile_sort_global_ids(const uint32_t* __restrict__ tile_off, unsigned long lo
     for (uint32_t i = threadIdx.x; i < n; i += 1024) out_ids[s + i] = (uint32_t)entries[s + i];
 }
 
-template __global__ void gsr_tile_sort_bucket<2048, 256, 512>(const uint32_t*, const unsigned long long*, uint32_t*, uint32_t, uint32_t);
-template __global__ void gsr_tile_sort_bucket<8192, 1024, 2048>(const uint32_t*, const unsigned long long*, uint32_t*, uint32_t, uint32_t);
-template __global__ void gsr_tile_sort_bucket<16384, 1024, 2048>(const uint32_t*, const unsigned long long*, uint32_t*, uint32_t, uint32_t);
+template __global__ void gsr_tile_sort_bucket<2048, 256, 512>(const uint32_t*, const unsigned long long*, uint32_t*, uint32_t, uint32_t, const unsigned long long*, uint32_t);
+template __global__ void gsr_tile_sort_bucket<8192, 1024, 2048>(const uint32_t*, const unsigned long long*, uint32_t*, uint32_t, uint32_t, const unsigned long long*, uint32_t);
+template __global__ void gsr_tile_sort_bucket<16384, 1024, 2048>(const uint32_t*, const unsigned long long*, uint32_t*, uint32_t, uint32_t, const unsigned long long*, uint32_t);

@@ -39,7 +39,9 @@ gsr_render_fwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict
                uint32_t* __restrict__ n_contrib, float* __restrict__ totals /*[5][H*W]*/,
                float* __restrict__ ckpt, const uint32_t* __restrict__ tile_seg,
                const uint32_t* __restrict__ tile_order /* heaviest tile first, or NULL */,
-               int seg_shift, uint32_t* __restrict__ tile_last /* max list position blended in the tile */) {
+               int seg_shift, uint32_t* __restrict__ tile_last /* max list position blended in the tile */,
+               const unsigned long long* __restrict__ counters, uint32_t capacity) {
+    if (counters[2] > (unsigned long long)capacity) return;   // lists do not fit the scratch: the host repeats the tail (gsr_scatter)
     __shared__ float4 stage[4][3][GSR_RB + 2];             // 12.4 KiB: [wave][field group][slot (+2 pad)]
     const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -174,7 +176,9 @@ gsr_render_fwd_q(const uint32_t* __restrict__ tile_off, const SplatRec* __restri
                  uint32_t* __restrict__ n_contrib, float* __restrict__ totals /*[5][H*W]*/,
                  float* __restrict__ ckpt, const uint32_t* __restrict__ tile_seg,
                  const uint32_t* __restrict__ tile_order /* heaviest tile first, or NULL */,
-                 int seg_shift, uint32_t* __restrict__ tile_last /* max list position blended in the tile */) {
+                 int seg_shift, uint32_t* __restrict__ tile_last /* max list position blended in the tile */,
+               const unsigned long long* __restrict__ counters, uint32_t capacity) {
+    if (counters[2] > (unsigned long long)capacity) return;   // lists do not fit the scratch: the host repeats the tail (gsr_scatter)
     __shared__ float4 stage[4][3][GSR_RB];                                   // slot = fetching lane
     __shared__ __attribute__((aligned(8))) uint8_t qlist[4][4][80];          // [wave][quad][k] = staged slot of the quad's k-th entry
     const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;

@@ -228,7 +228,9 @@ gsr_render_fwd_u4(const uint32_t* __restrict__ tile_off, const SplatRec* __restr
                uint32_t* __restrict__ n_contrib, float* __restrict__ totals /*[5][H*W]*/,
                float* __restrict__ ckpt, const uint32_t* __restrict__ tile_seg,
                const uint32_t* __restrict__ tile_order /* heaviest tile first, or NULL */,
-               int seg_shift, uint32_t* __restrict__ tile_last /* max list position blended in the tile */) {
+               int seg_shift, uint32_t* __restrict__ tile_last /* max list position blended in the tile */,
+               const unsigned long long* __restrict__ counters, uint32_t capacity) {
+    if (counters[2] > (unsigned long long)capacity) return;
     __shared__ float4 stage[4][3][GSR_RB + 4];             // [wave][field group][slot (+4 zero pad slots)]
     const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

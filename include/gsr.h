@@ -81,6 +81,8 @@ typedef struct GsrStats {
     int64_t num_instances_ref;  /* M: pairs under the reference's 3-sigma rect rule */
     int64_t num_visible;        /* V: Gaussians with radii > 0 */
     int64_t max_tile_count;     /* longest per-tile list */
+    int64_t bin_capacity;       /* instances the `bin` scratch was laid out for (>= num_instances): gsr_forward sizes it
+                                 * from the previous call (+25 %) so that nothing waits for the host; the backward needs it */
 } GsrStats;
 
 /* Forward.

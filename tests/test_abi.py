@@ -33,7 +33,7 @@ def test_struct_layout_matches_header():
     from dreamgaussian_amd import _lib
     assert ctypes.sizeof(_lib.GsrView) == 8 * 4 + 4 * 8 + 2 * 4 + 2 * 8
     assert ctypes.sizeof(_lib.GsrAlloc) == 16
-    assert ctypes.sizeof(_lib.GsrStats) == 32
+    assert ctypes.sizeof(_lib.GsrStats) == 40
 
 
 def test_c_argument_errors_without_gpu():

@@ -331,3 +331,23 @@ def test_split_sh_input_matches_concatenated(gpu):
     for k in ga:
         scale = gb[k].abs().max().item() + 1e-30
         assert (ga[k] - gb[k]).abs().max().item() <= 1e-4 * scale, k
+
+
+def test_speculative_forward_recovers_from_mispredictions(gpu):
+    """gsr_forward sizes the list scratch and picks the sort classes from the previous call on the same (N, H, W)
+    without waiting for the instance count (include/gsr.h: GsrStats.bin_capacity). A next frame with far more
+    instances (M > prediction) or with a far longer list (larger sort class) must be detected and redone: the
+    results of every frame equal the oracle's, whatever came before."""
+    W = H = 64
+    S = O.make_settings(O.orbit_pose(0, 0, 2.0), W, H, sh_degree=0)
+    w = weights_for(H, W)
+    N = 12000
+    spread_out = _cluster_scene(N, 1.2, 0.0, False, seed=3)          # short lists, few instances per Gaussian
+    big = dict(spread_out); big["scales"] = spread_out["scales"] * 4.0    # same N: ~10x the instances (M misprediction)
+    one_tile = _cluster_scene(N, 0.15, 0.229, False, seed=4)         # same N: one 12000-entry list (sort-class misprediction)
+    for name, sc in (("spread", spread_out), ("big", big), ("spread again", spread_out), ("one tile", one_tile), ("big again", big)):
+        ho, hg, st = run_hip(sc, S, gpu, w)
+        oo, og, aux = run_oracle(sc, S, w, torch.float64)
+        assert abs(st["M_ref"] - aux["M"]) <= 1e-4 * aux["M"] + 8, name
+        assert_forward_close(ho, oo, aux)
+        assert_grads_close(hg, og, aux, floors=grad_floors(sc, og))
