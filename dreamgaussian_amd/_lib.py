@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSR_LIB") or os.path.join(_HERE, "libgsr.so")
 
 EXPORTS = ("gsr_forward", "gsr_forward_begin", "gsr_forward_finish", "gsr_backward", "gsr_mark_visible", "gsr_dist2", "gsr_extract_fields", "gsr_densify_stats",
+           "gsr_adam_step", "gsr_mask_compact", "gsr_gather_rows",
            "gsr_profile_enable", "gsr_profile_read", "gsr_profile_reset",
            "gsr_geom_bytes", "gsr_img_bytes", "gsr_last_error", "gsr_version")
 
@@ -33,6 +34,15 @@ RESIZE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
 class GsrAlloc(C.Structure):
     _fields_ = [("ctx", C.c_void_p), ("resize", RESIZE_FN)]
+
+
+class GsrAdamTensor(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("n", C.c_int64), ("lr", C.c_double)]
+
+
+class GsrGatherTensor(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("width", C.c_int32), ("reserved", C.c_int32)]
 
 
 class GsrStats(C.Structure):
@@ -79,6 +89,12 @@ def load() -> C.CDLL:
         lib.gsr_densify_stats.argtypes = [i32, p, p, p, p, p, vp]
         lib.gsr_extract_fields.restype = C.c_int
         lib.gsr_extract_fields.argtypes = [i32, p, p, p, p, i32, i32, i32, p, p, p, p, p, GsrAlloc, vp]
+        lib.gsr_adam_step.restype = C.c_int
+        lib.gsr_adam_step.argtypes = [i32, C.POINTER(GsrAdamTensor), i32, C.c_double, C.c_double, C.c_double, vp]
+        lib.gsr_mask_compact.restype = C.c_int
+        lib.gsr_mask_compact.argtypes = [i32, p, p, p, GsrAlloc, vp]
+        lib.gsr_gather_rows.restype = C.c_int
+        lib.gsr_gather_rows.argtypes = [i32, C.POINTER(GsrGatherTensor), i32, p, vp]
         lib.gsr_geom_bytes.restype = C.c_size_t
         lib.gsr_geom_bytes.argtypes = [i32, i32, i32]
         lib.gsr_img_bytes.restype = C.c_size_t

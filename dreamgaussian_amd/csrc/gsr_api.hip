@@ -10,6 +10,7 @@
 #include "gsr_knn.hip"
 #include "gsr_fields.hip"
 #include "gsr_densify.hip"
+#include "gsr_optim.hip"
 
 #include <stdio.h>
 #include <string.h>
@@ -677,6 +678,80 @@ extern "C" int gsr_densify_stats(int32_t N, const float* grad_means2D, const int
     prof_begin(stream); hipLaunchKernelGGL(gsr_densify_stats_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, N, grad_means2D, radii,
                        xyz_gradient_accum, denom, max_radii2D);
     LAUNCH_CHECK(&dbg, stream, "densify_stats");
+    return 0;
+}
+
+extern "C" int gsr_adam_step(int32_t count, const GsrAdamTensor* tensors, int32_t step, double beta1, double beta2, double eps,
+                             gsr_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (count < 0 || count > GSR_ADAM_MAX_TENSORS) return fail(-1, "gsr_adam_step takes 0..8 tensors per call%s", "");
+    if (count == 0) return 0;
+    if (!tensors || step < 1) return fail(-1, "tensors are required and step counts from 1%s", "");
+    AdamArgs a;
+    memset(&a, 0, sizeof(a));
+    unsigned int blocks = 0;
+    int k = 0;
+    for (int i = 0; i < count; ++i) {
+        const GsrAdamTensor& t = tensors[i];
+        if (t.n < 0) return fail(-1, "negative tensor size%s", "");
+        if (t.n == 0) continue;
+        if (!t.param || !t.grad || !t.exp_avg || !t.exp_avg_sq) return fail(-1, "param, grad, exp_avg and exp_avg_sq are required%s", "");
+        a.seg[k].param = t.param; a.seg[k].grad = t.grad; a.seg[k].exp_avg = t.exp_avg; a.seg[k].exp_avg_sq = t.exp_avg_sq;
+        a.seg[k].n = (unsigned long long)t.n; a.seg[k].first_block = blocks;
+        a.seg[k].neg_step_size = (float)(-((double)t.lr / (1.0 - pow((double)beta1, (double)step))));
+        blocks += (unsigned int)((t.n + GSR_ADAM_PER_BLOCK - 1) / GSR_ADAM_PER_BLOCK);
+        ++k;
+    }
+    if (k == 0) return 0;
+    // torch takes these differences / quotients on Python floats (doubles) and hands the kernels the rounded result
+    a.count = k; a.beta2 = (float)beta2; a.eps = (float)eps;
+    a.w1 = (float)(1.0 - beta1); a.w2 = (float)(1.0 - beta2);
+    a.bias_correction2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
+    GsrView dbg; memset(&dbg, 0, sizeof(dbg));
+    prof_begin(stream); hipLaunchKernelGGL(gsr_adam_kernel, dim3(blocks), dim3(256), 0, stream, a);
+    LAUNCH_CHECK(&dbg, stream, "adam_step");
+    return 0;
+}
+
+extern "C" int gsr_mask_compact(int32_t N, const uint8_t* mask, uint32_t* idx, uint64_t* count, GsrAlloc tmp, gsr_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N < 0) return fail(-1, "N must be >= 0%s", "");
+    if (!count) return fail(-1, "count is required%s", "");
+    if (N == 0) { HIP_TRY(hipMemsetAsync(count, 0, 8, stream)); return 0; }
+    if (!mask || !idx || !tmp.resize) return fail(-1, "mask, idx and the tmp allocator are required%s", "");
+    const int nblocks = (N + 1023) / 1024;
+    uint32_t* bc = (uint32_t*)tmp.resize(tmp.ctx, align_up((size_t)nblocks * 4));
+    if (!bc) return fail(-4, "tmp scratch allocation failed%s", "");
+    GsrView dbg; memset(&dbg, 0, sizeof(dbg));
+    prof_begin(stream); hipLaunchKernelGGL(gsr_mask_count_kernel, dim3(nblocks), dim3(1024), 0, stream, N, mask, bc);
+    LAUNCH_CHECK(&dbg, stream, "mask_count");
+    prof_begin(stream); hipLaunchKernelGGL(gsr_mask_scan_kernel, dim3(1), dim3(1024), 0, stream, nblocks, bc, (unsigned long long*)count);
+    LAUNCH_CHECK(&dbg, stream, "mask_scan");
+    prof_begin(stream); hipLaunchKernelGGL(gsr_mask_write_kernel, dim3(nblocks), dim3(1024), 0, stream, N, mask, bc, idx);
+    LAUNCH_CHECK(&dbg, stream, "mask_write");
+    return 0;
+}
+
+extern "C" int gsr_gather_rows(int32_t count, const GsrGatherTensor* tensors, int32_t rows, const uint32_t* idx, gsr_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (count < 0 || count > GSR_GATHER_MAX_TENSORS) return fail(-1, "gsr_gather_rows takes 0..24 tensors per call%s", "");
+    if (rows < 0) return fail(-1, "rows must be >= 0%s", "");
+    if (count == 0 || rows == 0) return 0;
+    if (!tensors || !idx) return fail(-1, "tensors and idx are required%s", "");
+    GatherArgs a;
+    memset(&a, 0, sizeof(a));
+    int wmax = 1;
+    for (int i = 0; i < count; ++i) {
+        if (!tensors[i].src || !tensors[i].dst || tensors[i].width < 1) return fail(-1, "src, dst and width >= 1 are required%s", "");
+        a.seg[i].src = tensors[i].src; a.seg[i].dst = tensors[i].dst; a.seg[i].width = tensors[i].width;
+        if (tensors[i].width > wmax) wmax = tensors[i].width;
+    }
+    a.count = count; a.rows = rows;
+    const long long total = (long long)rows * wmax;
+    const int gx = (int)fmin((double)((total + 255) / 256), 4096.0);
+    GsrView dbg; memset(&dbg, 0, sizeof(dbg));
+    prof_begin(stream); hipLaunchKernelGGL(gsr_gather_rows_kernel, dim3(gx, count), dim3(256), 0, stream, a, idx);
+    LAUNCH_CHECK(&dbg, stream, "gather_rows");
     return 0;
 }
 

@@ -180,6 +180,32 @@ int gsr_extract_fields(int32_t N, const float* xyz, const float* opacity, const 
 int gsr_densify_stats(int32_t N, const float* grad_means2D, const int32_t* radii,
                       float* xyz_gradient_accum, float* denom, float* max_radii2D, gsr_stream_t stream);
 
+/* Optimiser step of GaussianModel.training_setup's Adam (gs_renderer.py:356-374; torch.optim.Adam, amsgrad off,
+ * no weight decay) for up to 8 tensors in ONE launch, in torch's arithmetic order:
+ *   exp_avg += (1 - beta1) (grad - exp_avg);  exp_avg_sq = exp_avg_sq beta2 + (1 - beta2) grad grad;
+ *   param -= lr / (1 - beta1^step) * exp_avg / (sqrt(exp_avg_sq) / sqrt(1 - beta2^step) + eps).
+ * `step` counts from 1 (torch increments state["step"] before the update). All pointers are device pointers to
+ * contiguous fp32; the state tensors are torch's own (`optimizer.state[p]["exp_avg"]`, ...), so the reference's
+ * optimiser-state surgery in densify_and_prune (gs_renderer.py:464-545) keeps working on them. */
+typedef struct GsrAdamTensor {
+    float* param; const float* grad; float* exp_avg; float* exp_avg_sq;
+    int64_t n;      /* elements */
+    double lr;      /* the group's learning rate (a Python float) */
+} GsrAdamTensor;
+int gsr_adam_step(int32_t count, const GsrAdamTensor* tensors /* [host] */, int32_t step, double beta1, double beta2, double eps,
+                  gsr_stream_t stream);
+
+/* prune_points / densify selections (gs_renderer.py:479-609) without one nonzero() per tensor:
+ * gsr_mask_compact: stable compaction of a byte mask [N] (0 / non-0): idx[j] = index of the j-th set element
+ *   (idx must hold N entries), count[0] (device, 8 bytes) = number of set elements. No host synchronisation; the
+ *   caller reads `count` once to size the new tensors.
+ * gsr_gather_rows: dst_t[j, :] = src_t[idx[j], :], j < rows, for up to 24 fp32 tensors of row width width_t, in one
+ *   launch (the six parameters, their two Adam moments each and the three densification accumulators). */
+int gsr_mask_compact(int32_t N, const uint8_t* mask, uint32_t* idx, uint64_t* count, GsrAlloc tmp, gsr_stream_t stream);
+typedef struct GsrGatherTensor { const float* src; float* dst; int32_t width; int32_t reserved; } GsrGatherTensor;
+int gsr_gather_rows(int32_t count, const GsrGatherTensor* tensors /* [host] */, int32_t rows, const uint32_t* idx,
+                    gsr_stream_t stream);
+
 /* Bytes of scratch the forward will request for geom / img (bin is data dependent). */
 size_t gsr_geom_bytes(int32_t N, int32_t image_height, int32_t image_width);
 size_t gsr_img_bytes(int32_t image_height, int32_t image_width);
