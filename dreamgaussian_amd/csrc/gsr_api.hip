@@ -6,7 +6,6 @@
 #include "gsr_preprocess.hip"
 #include "gsr_binning.hip"
 #include "gsr_render.hip"
-#include "gsr_render_exp.hip"
 #include "gsr_knn.hip"
 #include "gsr_fields.hip"
 #include "gsr_densify.hip"
@@ -127,7 +126,6 @@ GeomLayout geom_layout(int N, int H, int W) {
     return L;
 }
 int seg_shift();
-#define GSR_BWD_DEFAULT kBwdQ2
 struct BinLayout { size_t entries, ids, ckpt, plan_tile, plan_cap, total; };
 BinLayout bin_layout(size_t M, int nTiles) {
     BinLayout L;
@@ -184,8 +182,7 @@ int check_inputs(int N, int K, const GsrView* v, const float* means3D, const flo
 constexpr int kHistLdsMaxTiles = 16384;   // 64 KiB of LDS histogram
 
 // Environment switches kept for same-box A/B measurements (defaults = the shipped path):
-//   GSR_BWD=f2b|q2|quad   backward compositing kernel (gsr_render.hip / gsr_render_exp.hip)
-//   GSR_FWD=q|block|u4    forward with quad lists / 8x8 block lists (default: chosen per scene) / four entries per trip
+//   GSR_FWD=q|block       forward with quad lists / 8x8 block lists (default: chosen per scene)
 //   GSR_TILE_ORDER=off    forward compositing tiles in row-major instead of heaviest-first order
 //   GSR_SEG_SHIFT=6..8    log2 of the backward segment length in list positions
 bool use_tile_order_off() {
@@ -198,21 +195,6 @@ int seg_shift() {
         const int s = e ? atoi(e) : GSR_SEG_SHIFT_DEFAULT;
         return (s < 6 || s > 8) ? GSR_SEG_SHIFT_DEFAULT : s;       // multiples of the 64-entry fetch round; LDS table = 48 B << shift
     }();
-    return v;
-}
-enum BwdKernel { kBwdF2b = 0, kBwdQ2 = 1, kBwdQuad = 2 };
-int bwd_kernel() {
-    static const int v = [] {
-        const char* e = getenv("GSR_BWD");
-        if (e && strcmp(e, "q2") == 0) return (int)kBwdQ2;
-        if (e && strcmp(e, "quad") == 0) return (int)kBwdQuad;
-        if (e && strcmp(e, "f2b") == 0) return (int)kBwdF2b;
-        return (int)GSR_BWD_DEFAULT;
-    }();
-    return v;
-}
-bool use_fwd_u4() {
-    static const bool v = [] { const char* e = getenv("GSR_FWD"); return e && strcmp(e, "u4") == 0; }();
     return v;
 }
 // forward compositing kernel: 0 = per scene (below), 1 = 8x8 block lists, 2 = quad lists
@@ -429,9 +411,6 @@ int finish_impl(const GsrView* view, int32_t N, float* out_color, float* out_dep
     if (fwd_q)
         hipLaunchKernelGGL(gsr_render_fwd_q, dim3(T), dim3(256), 0, stream, tile_off, recs, sorted_ids, view->bg, W, H, vc.gx,
                            out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, tile_order, seg_shift(), tile_last, counters, (uint32_t)M);
-    else if (use_fwd_u4())
-        hipLaunchKernelGGL(gsr_render_fwd_u4, dim3(T), dim3(256), 0, stream, tile_off, recs, sorted_ids, view->bg, W, H, vc.gx,
-                           out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, tile_order, seg_shift(), tile_last, counters, (uint32_t)M);
     else
         hipLaunchKernelGGL(gsr_render_fwd, dim3(T), dim3(256), 0, stream, tile_off, recs, sorted_ids, view->bg, W, H, vc.gx,
                            out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, tile_order, seg_shift(), tile_last, counters, (uint32_t)M);
@@ -580,17 +559,13 @@ extern "C" int gsr_backward(const GsrView* view, int32_t N, int32_t K,
         LAUNCH_CHECK(view, stream, "bwd_plan");
         prof_begin(stream);
         const unsigned grid = (unsigned)BL.plan_cap;
-        // workgroup table: [2^shift][12] floats, or [2^shift][10] 64-bit fixed-point sums for the q2 kernel
-        const size_t dyn = (bwd_kernel() == kBwdQ2 ? (size_t)GSR_Q2_ROW * 8 : (size_t)GSR_G2D_STRIDE * 4) << seg_shift();
+        // workgroup table: [2^shift][10] 64-bit fixed-point sums
+        const size_t dyn = ((size_t)GSR_Q2_ROW * 8) << seg_shift();
 #define GSR_LAUNCH_BWD(KERNEL)                                                                          \
         hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(256), dyn, stream, tile_off, recs, sorted_ids, view->bg, W, H, vc.gx, \
                            final_T, n_contrib, totals, ckpt, tile_seg, dL_dcolor, dL_ddepth, dL_dalpha, g2d, seg_shift(), \
                            plan_tile, plan_off, plan_total)
-        switch (bwd_kernel()) {
-            case kBwdQ2: GSR_LAUNCH_BWD(gsr_render_bwd_q2); break;
-            case kBwdQuad: GSR_LAUNCH_BWD(gsr_render_bwd_f2b_quad); break;
-            default: GSR_LAUNCH_BWD(gsr_render_bwd_f2b); break;
-        }
+        GSR_LAUNCH_BWD(gsr_render_bwd_q2);
 #undef GSR_LAUNCH_BWD
     } else prof_begin(stream);
     LAUNCH_CHECK(view, stream, "render_bwd");

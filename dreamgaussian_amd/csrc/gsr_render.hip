@@ -340,34 +340,6 @@ gsr_render_fwd_q(const uint32_t* __restrict__ tile_off, const SplatRec* __restri
 // atomics execute at the memory side on this multi-XCD part: one request per cache line here
 // instead of three per (8x8 block, Gaussian)).
 // =========================================================================================
-__device__ __forceinline__ void bwd_flush(float* acc, uint32_t len, uint32_t list0 /* start + seg_lo */,
-                                          const SplatRec* __restrict__ recs, const uint32_t* __restrict__ ids,
-                                          float* __restrict__ g2d) {
-    __syncthreads();
-    for (uint32_t r = threadIdx.x; r < len; r += 256) {
-        float* a = acc + r * GSR_G2D_STRIDE;
-        const float S0 = a[5];
-        if (S0 != 0.f || a[0] != 0.f || a[1] != 0.f || a[2] != 0.f || a[3] != 0.f || a[4] != 0.f) {
-            const SplatRec* __restrict__ g = recs + ids[list0 + r];
-            const float qa = g->qa, qb = g->qb, qc = g->qc, op = g->opac;
-            const float Sx = a[0], Sy = a[1];
-            a[0] = 2.f * qa * Sx + qb * Sy;               // mean2D.x (ln2 * 0.5 W applied in K6)
-            a[1] = 2.f * qc * Sy + qb * Sx;
-            a[2] *= -0.5f; a[3] = -a[3]; a[4] *= -0.5f;   // true conic A, B, C
-            a[5] = op != 0.f ? S0 / op : 0.f;             // opacity
-        }
-    }
-    __syncthreads();
-    // consecutive threads = consecutive slots of consecutive list positions
-    for (uint32_t e = threadIdx.x; e < len * GSR_G2D_STRIDE; e += 256) {
-        const float v = acc[e];
-        if (v != 0.f) {
-            const uint32_t r = e / GSR_G2D_STRIDE, slot = e - r * GSR_G2D_STRIDE;
-            atomicAdd(g2d + (size_t)ids[list0 + r] * GSR_G2D_STRIDE + slot, v);
-        }
-    }
-}
-
 #define GSR_BWD_PARAMS                                                                            \
     const uint32_t* __restrict__ tile_off, const SplatRec* __restrict__ recs,                     \
     const uint32_t* __restrict__ ids, const float* __restrict__ bg, int W, int H, int gx,         \
@@ -379,138 +351,7 @@ __device__ __forceinline__ void bwd_flush(float* acc, uint32_t len, uint32_t lis
     const uint32_t* __restrict__ plan_off, const unsigned long long* __restrict__ plan_total
 
 // -----------------------------------------------------------------------------------------
-// K5b (round-1 kernel, kept as GSR_BWD=f2b for A/B): one list per 8x8 block, the ten sums leave
-// the wave through a v_permlane32_swap / v_permlane16_swap transposing reduction.
-// -----------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256, 8)
-gsr_render_bwd_f2b(GSR_BWD_PARAMS) {
-    __shared__ float4 stage[4][3][GSR_RB + 2];
-    extern __shared__ __attribute__((aligned(16))) float acc[];   // [(1 << seg_shift) * GSR_G2D_STRIDE]
-    if (blockIdx.x >= (uint32_t)plan_total[0]) return;
-    const int tile = (int)plan_tile[blockIdx.x];
-    const uint32_t seg = blockIdx.x - plan_off[tile];
-    const uint32_t start = tile_off[tile];
-    const uint32_t n = tile_off[tile + 1] - start;
-    const uint32_t seg_lo = seg << seg_shift;              // this workgroup: list positions (seg_lo, seg_hi]
-    if (seg_lo >= n) return;                              // (block-uniform)
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const int bx = (tile % gx) * GSR_TILE + (wave & 1) * 8;
-    const int by = (tile / gx) * GSR_TILE + (wave >> 1) * 8;
-    for (int q = threadIdx.x; q < (GSR_G2D_STRIDE << seg_shift); q += 256) acc[q] = 0.f;
-    __syncthreads();
-    bool active = (bx < W) && (by < H);                   // wave-uniform; no early return: barrier below
-    const int px = bx + (lane & 7), py = by + (lane >> 3);
-    const bool inside = (px < W) && (py < H);
-    const float pxf = (float)px, pyf = (float)py;
-    float4* __restrict__ sa = stage[wave][0];
-    float4* __restrict__ sb = stage[wave][1];
-    float4* __restrict__ sc = stage[wave][2];
-
-    float T_final = 1.f, gC0 = 0.f, gC1 = 0.f, gC2 = 0.f, gD = 0.f, gA = 0.f, Cg_total = 0.f;
-    uint32_t last_contrib = 0;
-    if (inside) {
-        const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
-        T_final = final_T[pix];
-        last_contrib = n_contrib[pix];
-        gC0 = dL_dcolor[pix]; gC1 = dL_dcolor[HW + pix]; gC2 = dL_dcolor[2 * HW + pix];
-        gD = dL_ddepth[pix]; gA = dL_dalpha[pix];
-        Cg_total = totals[pix] * gC0 + totals[HW + pix] * gC1 + totals[2 * HW + pix] * gC2
-                 + totals[3 * HW + pix] * gD + totals[4 * HW + pix] * gA;
-    }
-    const uint32_t wave_last = __builtin_amdgcn_readfirstlane(wave_max_u32(last_contrib));
-    active = active && (wave_last > seg_lo);              // else nothing in this segment was blended here
-    const uint32_t seg_hi = active ? min(seg_lo + (1u << seg_shift), wave_last) : seg_lo;
-    // everything behind entry i: (total + T_final bg.g) - prefix_i - w_i (c_i.g)
-    const float Cg_behind0 = Cg_total + T_final * (bg[0] * gC0 + bg[1] * gC1 + bg[2] * gC2);
-
-    float T = 1.f, Cgf = 0.f;                             // transmittance and c.g prefix before the segment
-    if (seg > 0) {
-        const float* c = ckpt + (size_t)(tile_seg[tile] + seg - 1u) * GSR_CKPT_FLOATS + (wave * 64 + lane);
-        T = c[0];
-        Cgf = c[256] * gC0 + c[512] * gC1 + c[768] * gC2 + c[1024] * gD + c[1280] * gA;
-    }
-
-    const uint32_t slot0 = tag16(tag32(0u, 5u), tag32(1u, 6u));
-    const uint32_t slot1 = tag16(tag32(2u, 7u), tag32(3u, 8u));
-    const uint32_t slot2 = tag16(tag32(4u, 9u), tag32(10u, 11u));   // 10, 11: padding slots (zeros)
-    // lanes 0,1,2 of every 16-lane row carry t0,t1,t2 -> one ds_add for all ten sums
-    const uint32_t l15 = (uint32_t)lane & 15u;
-    const uint32_t myslot = l15 == 0u ? slot0 : (l15 == 1u ? slot1 : slot2);
-    const bool lds_lane = (l15 < 3u) && (myslot < 10u);
-
-    // ea = x y qa qb | eb = qc opac r g | ec = b depth pos -
-#define GSR_F2B_ENTRY(ea, eb, ec, valid)                                                         \
-    {                                                                                            \
-        const float qa = ea.z, qb = ea.w, qc = eb.x, opac = eb.y;                                \
-        const uint32_t kpos = __float_as_uint(ec.z);                                             \
-        const float dx = ea.x - pxf, dy = ea.y - pyf;                                            \
-        const float power = qa * dx * dx + qc * dy * dy + qb * dx * dy;                          \
-        const float G = fast_exp2(power);                                                        \
-        const float alpha = fminf(0.99f, opac * G);                                              \
-        const bool ok = (valid) && (kpos <= last_contrib) && (power <= 0.f) && (alpha >= (1.0f / 255.0f)); \
-        if (__ballot(ok) != 0ull) {                       /* somebody in this block blended it */ \
-            float dL_dal = 0.f, w = 0.f;                  /* stay 0 in lanes that did not blend */  \
-            if (ok) {                                                                            \
-                const float cgi = eb.z * gC0 + eb.w * gC1 + ec.x * gC2 + ec.y * gD + gA;         \
-                const float oma = 1.f - alpha;                                                   \
-                w = alpha * T;                                                                   \
-                const float wc = w * cgi;                                                        \
-                dL_dal = T * cgi - (Cg_behind0 - Cgf - wc) * fast_rcp(oma);                       \
-                Cgf += wc;                                                                       \
-                T *= oma;                                                                        \
-            }                                                                                    \
-            const float Gm = ok ? G : 0.f;                /* G may be inf where power > 0 */      \
-            const float v5 = (opac * dL_dal) * Gm;                          /* S_0 */            \
-            const float v0 = v5 * dx, v1 = v5 * dy;                         /* S_x, S_y */       \
-            const float v2 = v0 * dx, v3 = v0 * dy, v4 = v1 * dy;           /* S_xx, S_xy, S_yy */ \
-            const float v6 = w * gC0, v7 = w * gC1, v8 = w * gC2;           /* dL/drgb */        \
-            const float v9 = w * gD;                                        /* dL/ddepth */      \
-            const float t0 = row_sum16(red16(red32(v0, v5), red32(v1, v6)));                     \
-            const float t1 = row_sum16(red16(red32(v2, v7), red32(v3, v8)));                     \
-            const float t2 = row_sum16(red16(red32(v4, v9), 0.f));                               \
-            const float tv = l15 == 0u ? t0 : (l15 == 1u ? t1 : t2);                              \
-            if (lds_lane) atomicAdd(&acc[(kpos - 1u - seg_lo) * GSR_G2D_STRIDE + myslot], tv);   \
-        }                                                                                        \
-    }
-
-    for (int q = lane; q < 3 * (GSR_RB + 2); q += 64) (&stage[wave][0][0])[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    wave_lds_handoff();
-    for (uint32_t pos0 = seg_lo; pos0 < seg_hi; pos0 += GSR_RB) {   // 0-based positions pos0 .. pos0+63
-        const uint32_t i = pos0 + lane;
-        bool hit = false;
-        float4 ra, rb, rc;
-        if (i < seg_hi) {
-            const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + ids[start + i]);
-            ra = p[0]; rb = p[1]; rc = p[2];
-            hit = rect_max_power(ra.x, ra.y, ra.z, ra.w, rb.x, (float)bx, (float)(bx + 7), (float)by, (float)(by + 7))
-                  >= min_visible_power(rb.y);
-        }
-        const unsigned long long mask = __ballot(hit);
-        if (mask != 0ull) {
-            const int cnt = __popcll(mask);
-            if (hit) {
-                const uint32_t pos = lanes_below(mask);   // ascending lane = ascending list position
-                rc.z = __uint_as_float(i + 1u);           // 1-based list position
-                sa[pos] = ra; sb[pos] = rb; sc[pos] = rc;
-            }
-            wave_lds_handoff();
-            float4 e0a = sa[0], e0b = sb[0], e0c = sc[0];
-            for (int j = 0; j < cnt; j += 2) {            // slots cnt, cnt+1 are padding: read, never used
-                const float4 e1a = sa[j + 1], e1b = sb[j + 1], e1c = sc[j + 1];
-                GSR_F2B_ENTRY(e0a, e0b, e0c, true)
-                e0a = sa[j + 2]; e0b = sb[j + 2]; e0c = sc[j + 2];
-                GSR_F2B_ENTRY(e1a, e1b, e1c, j + 1 < cnt)
-            }
-            wave_lds_handoff();
-        }
-    }
-#undef GSR_F2B_ENTRY
-    bwd_flush(acc, min(1u << seg_shift, n - seg_lo), start + seg_lo, recs, ids, g2d);
-}
-
-// -----------------------------------------------------------------------------------------
-// K5b (default): quad lists + two passes + fixed-point accumulation.
+// K5b: quad lists + two passes + fixed-point accumulation.
 //
 // Every 16-lane DPP row of a wave owns a 4x4 pixel quad (row r: quad (r & 1, r >> 1) of the 8x8
 // block, lane l15: pixel (l15 & 3, l15 >> 2) of the quad). A fetched record is tested exactly

@@ -11,10 +11,10 @@ tests)
   grep -a "fragile:\|passed\|failed\|FAILED\|Error" gpurun_out/pytest_gpu.log | tail -30;;
 variants)
   # parity of every env-selectable kernel variant + same-box 1M bench
-  for v in ${VARIANTS:-"GSR_BWD=q2" "GSR_BWD=quad" "GSR_FWD=u4"}; do
+  for v in ${VARIANTS:-"GSR_FWD=q" "GSR_FWD=block"}; do
     echo "== variant [$v] parity"; env $v timeout 900 python -m pytest tests/test_parity_gpu.py tests/test_fuzz_gpu.py tests/test_views_gpu.py -m gpu -q -s -p no:cacheprovider --tb=short -x 2>&1 | grep -a "fragile:\|passed\|failed\|FAILED\|Error\|assert" | tail -12
   done
-  for v in "GSR_X=0" ${VARIANTS:-"GSR_BWD=q2" "GSR_BWD=quad" "GSR_FWD=u4"}; do
+  for v in "GSR_X=0" ${VARIANTS:-"GSR_FWD=q" "GSR_FWD=block"}; do
     echo "== variant [$v] bench 1M blob"; env $v timeout 300 python bench.py --cpu-budget 0 2>gpurun_out/ab_err.log | benchline
     echo "== variant [$v] bench 1M trained"; env $v timeout 300 python bench.py --cpu-budget 0 --kind trained 2>>gpurun_out/ab_err.log | benchline
     echo "== variant [$v] bench 100k"; env $v timeout 300 python bench.py --cpu-budget 0 --workload 100k-800-sh3 2>>gpurun_out/ab_err.log | benchline
@@ -50,7 +50,7 @@ views)
   done;;
 pmcv)
   # SQ / LDS / L2 counters per env-selectable variant (one bench run per pass)
-  for v in ${VARIANTS:-"GSR_BWD=f2b" "GSR_BWD=q2"}; do
+  for v in ${VARIANTS:-"GSR_SEG_SHIFT=6" "GSR_SEG_SHIFT=7"}; do
     tagv=$(echo $v | tr '= ' '__')
     i=0
     for c in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum GRBM_GUI_ACTIVE"; do
@@ -60,7 +60,7 @@ pmcv)
     echo "== PMC variant [$v]"; python tools/pmc_summary.py gpurun_out/pmcv_$tagv 2>&1 | grep "render\|preprocess\|scatter\|tile_sort" | cut -c1-900
   done;;
 abq)
-  for v in ${VARIANTS:-"GSR_BWD=q2p" "GSR_BWD=q2 GSR_SEG_SHIFT=8" "GSR_BWD=f2b GSR_SEG_SHIFT=8" "GSR_BWD=q2p GSR_SEG_SHIFT=8"}; do
+  for v in ${VARIANTS:-"GSR_SEG_SHIFT=8"}; do
     echo "== variant [$v] bench 1M blob"; env $v timeout 300 python bench.py --cpu-budget 0 2>gpurun_out/ab_err.log | benchline
     echo "== variant [$v] bench 100k"; env $v timeout 300 python bench.py --cpu-budget 0 --workload 100k-800-sh3 2>>gpurun_out/ab_err.log | benchline
   done;;
