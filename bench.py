@@ -237,6 +237,8 @@ def main():
                     help="cameras per step on each GPU (B > 1: dreamgaussian_amd.rasterize_views keeps them in flight "
                          "together; --views-serial renders them one after the other like the reference's loop)")
     ap.add_argument("--views-serial", action="store_true")
+    ap.add_argument("--views-mode", default="chain", choices=["chain", "streams"],
+                    help="rasterize_views: one launch chain for all views (default) or one HIP stream per view")
     ap.add_argument("--activations", default="none", choices=["none", "torch", "fused"],
                     help="what the timed step does about DreamGaussian's parameter activations (gs_renderer.py:134-142): "
                          "none = the rasterizer alone on activated inputs (the headline metric); torch = sigmoid/exp/normalize "
@@ -297,6 +299,8 @@ def main():
         m2d_l = [torch.zeros(wl["N"], 3, device=dev, requires_grad=True) for _ in range(a.views)]
         rasts = [D.GaussianRasterizer(raster_settings=x) for x in vs]
 
+    gout_views = [g.unsqueeze(0).expand(a.views, *g.shape).contiguous() for g in gout] if a.views > 1 else None
+
     def step_views():
         for v in t.values():
             v.grad = None
@@ -308,8 +312,9 @@ def main():
                 torch.autograd.backward([c, d, al], gout)
         else:
             m2d_b.grad = None
-            c, r, d, al = D.rasterize_views(t["means3D"], m2d_b, t["opacities"], vs, shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
-            torch.autograd.backward([c, d, al], [g.unsqueeze(0).expand(a.views, *g.shape).contiguous() for g in gout])
+            c, r, d, al = D.rasterize_views(t["means3D"], m2d_b, t["opacities"], vs, shs=t["shs"], scales=t["scales"], rotations=t["rotations"],
+                                            mode=a.views_mode)
+            torch.autograd.backward([c, d, al], gout_views)
 
     if a.activations != "none":      # raw parameters whose activations reproduce the scene
         raw = dict(opacity=torch.logit(sc["opacities"].clamp(1e-4, 1 - 1e-4)), scaling=torch.log(sc["scales"]),
@@ -448,7 +453,7 @@ def main():
             "config": {"workload": f"BASELINE.json configs[{wl['cfg']}]: {wl['N']} Gaussians, SH degree "
                                    f"{wl['deg']}, {wl['W']}x{wl['H']}, fwd+bwd, scene '{a.kind}' seed 0, "
                                    f"orbit camera r=2 fovy=49.1",
-                       "views_per_step": world * a.views, "activations": a.activations, "views_mode": ("single" if a.views == 1 else ("serial loop" if a.views_serial else "rasterize_views")), "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU",
+                       "views_per_step": world * a.views, "activations": a.activations, "views_mode": ("single" if a.views == 1 else ("serial loop" if a.views_serial else "rasterize_views/" + a.views_mode)), "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU",
                        "N": wl["N"], "K": K, "V": st.get("V"), "M": st.get("M_ref"), "M_emitted": st.get("M"),
                        "max_tile_list": st.get("max_tile")},
             "roofline": roof, "path_roofline": path_roof, "cpu_baseline": cpu,

@@ -12,7 +12,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GSR_LIB=<path> loads another build of the same ABI (A/B measurements of two source revisions)
 LIB_PATH = os.environ.get("GSR_LIB") or os.path.join(_HERE, "libgsr.so")
 
-EXPORTS = ("gsr_forward", "gsr_forward_begin", "gsr_forward_finish", "gsr_backward", "gsr_mark_visible", "gsr_dist2", "gsr_extract_fields", "gsr_densify_stats",
+GSR_MAX_VIEWS = 16      # include/gsr.h
+
+EXPORTS = ("gsr_forward", "gsr_forward_begin", "gsr_forward_finish", "gsr_backward", "gsr_forward_views", "gsr_backward_views", "gsr_mark_visible", "gsr_dist2", "gsr_extract_fields", "gsr_densify_stats",
            "gsr_adam_step", "gsr_mask_compact", "gsr_gather_rows",
            "gsr_profile_enable", "gsr_profile_read", "gsr_profile_reset",
            "gsr_geom_bytes", "gsr_img_bytes", "gsr_last_error", "gsr_version")
@@ -80,6 +82,12 @@ def load() -> C.CDLL:
                                                                                 C.POINTER(GsrStats), vp]
         lib.gsr_backward.restype = C.c_int
         lib.gsr_backward.argtypes = [C.POINTER(GsrView), i32, i32] + [p] * 7 + [p] + [p] * 3 + \
+            [p] * 3 + [C.POINTER(GsrStats)] + [p] * 8 + [GsrAlloc, vp]
+        lib.gsr_forward_views.restype = C.c_int
+        lib.gsr_forward_views.argtypes = [C.POINTER(GsrView), i32, i32, i32] + [p] * 7 + [p] * 4 + \
+            [GsrAlloc, GsrAlloc, GsrAlloc, C.POINTER(GsrStats), vp]
+        lib.gsr_backward_views.restype = C.c_int
+        lib.gsr_backward_views.argtypes = [C.POINTER(GsrView), i32, i32, i32] + [p] * 7 + [p] + [p] * 3 + \
             [p] * 3 + [C.POINTER(GsrStats)] + [p] * 8 + [GsrAlloc, vp]
         lib.gsr_mark_visible.restype = C.c_int
         lib.gsr_mark_visible.argtypes = [C.POINTER(GsrView), i32, p, p, vp]

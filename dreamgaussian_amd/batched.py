@@ -1,17 +1,21 @@
-"""Several views of the same Gaussians in flight together on ONE GPU.
+"""Several views of the same Gaussians on ONE GPU.
 
 The reference renders the cameras of one optimisation step in a serial Python loop
 (main.py:219-255: `for _ in range(batch_size): out = renderer.render(cam) ...; torch.cat(images)`),
 paying one host round trip (the instance count) and one under-filled set of launches per view --
 at 512x512 a view has 1024 tiles, a third of them non-empty, on a 256-CU chip.
-`rasterize_views` renders B cameras through the two-phase C ABI (`gsr_forward_begin` /
-`gsr_forward_finish`, include/gsr.h): every view gets its own HIP stream, all per-Gaussian stages
-are enqueued first, the host waits once per batch instead of once per view, and the binning /
-sort / compositing kernels of different views overlap on the device. The backward does the
-same and sums the per-view gradients of the shared Gaussians.
 
-Same arithmetic, same kernels as `GaussianRasterizer`: outputs are bit-identical to B single-view
-calls (gradients up to the order of fp32 atomics).
+`rasterize_views` renders B cameras with ONE launch chain (`gsr_forward_views` / `gsr_backward_views`,
+include/gsr.h): the per-Gaussian kernels run with grid.y = view, binning / sort / compositing run over all
+B * tiles tiles at once (heaviest tile first across views), the host waits once per batch, and the backward adds
+the views' parameter gradients into one [N,...] tensor in the order autograd would (no [B,N,...] + sum).
+
+Same arithmetic, same kernels as `GaussianRasterizer`: images, depth, alpha, radii and the per-view means2D
+gradients are bit-identical to B single-view calls; the summed parameter gradients equal the serial loop's up to
+the order of the fp32 atomics inside each view.
+
+`mode="streams"` keeps the round-1 scheme (one HIP stream per view through `gsr_forward_begin` / `_finish`) for
+A/B measurements.
 """
 from __future__ import annotations
 
@@ -41,7 +45,7 @@ def _host_counters(dev, n):
     return _pinned[key]
 
 
-class _RasterizeViews(torch.autograd.Function):
+class _RasterizeViewsStreams(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings):
         _require_gpu(means3D)
@@ -168,13 +172,115 @@ class _RasterizeViews(torch.autograd.Function):
                 total(d_sc, sh_[4]), total(d_rot, sh_[5]), total(d_cov, sh_[6]), None)
 
 
+class _RasterizeViews(torch.autograd.Function):
+    """Up to GSR_MAX_VIEWS cameras through gsr_forward_views / gsr_backward_views."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings):
+        _require_gpu(means3D)
+        lib = _lib.load()
+        dev = means3D.device
+        B = len(settings)
+        H, W = int(settings[0].image_height), int(settings[0].image_width)
+        for rs in settings:
+            if (int(rs.image_height), int(rs.image_width)) != (H, W):
+                raise RuntimeError("rasterize_views: all views must share one image size")
+        N = int(means3D.shape[0])
+        if tuple(means2D.shape) != (B, N, 3):
+            raise RuntimeError("means2D must have dimensions (num_views, num_points, 3)")
+        m3, shc, col = _f32c(means3D, dev), _f32c(sh, dev), _f32c(colors_precomp, dev)
+        op, sc, rot, cov = _f32c(opacities, dev), _f32c(scales, dev), _f32c(rotations, dev), _f32c(cov3Ds_precomp, dev)
+        K = int(shc.shape[1]) if shc is not None else 0
+        if (shc is None) == (col is None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((sc is None or rot is None) and cov is None) or ((sc is not None or rot is not None) and cov is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        color = torch.empty(B, 3, H, W, dtype=torch.float32, device=dev)
+        depth = torch.empty(B, 1, H, W, dtype=torch.float32, device=dev)
+        alpha = torch.empty(B, 1, H, W, dtype=torch.float32, device=dev)
+        radii = torch.empty(B, N, dtype=torch.int32, device=dev)
+        views = (_lib.GsrView * B)()
+        keeps = []
+        for v in range(B):
+            views[v], keep = _view_struct(settings[v], dev)
+            keeps.append(keep)
+        geom, binb, img, st = _lib.Scratch(dev), _lib.Scratch(dev), _lib.Scratch(dev), _lib.GsrStats()
+        P = _lib.ptr
+        with torch.cuda.device(dev):
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            rc = lib.gsr_forward_views(views, B, N, K, P(m3), P(shc), P(col), P(op), P(sc), P(rot), P(cov),
+                                       P(color), P(depth), P(alpha), P(radii), geom.alloc, binb.alloc, img.alloc,
+                                       C.byref(st), stream)
+        geom.release(); binb.release(); img.release()
+        _lib.check(rc, "gsr_forward_views")
+        ctx.views, ctx.keeps, ctx.stats = views, keeps, st
+        ctx.dims = (B, N, K, H, W)
+        ctx.present = (shc is not None, col is not None, sc is not None, cov is not None)
+        empty = torch.empty(0, device=dev)
+        ctx.save_for_backward(*[t if t is not None else empty for t in (m3, shc, col, op, sc, rot, cov)], radii,
+                              geom.tensor, binb.tensor, img.tensor)
+        ctx.shapes = (means3D.shape, None if sh is None else sh.shape,
+                      None if colors_precomp is None else colors_precomp.shape, opacities.shape,
+                      None if scales is None else scales.shape, None if rotations is None else rotations.shape,
+                      None if cov3Ds_precomp is None else cov3Ds_precomp.shape)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, depth, alpha
+
+    @staticmethod
+    def backward(ctx, g_color, g_radii, g_depth, g_alpha):
+        lib = _lib.load()
+        B, N, K, H, W = ctx.dims
+        m3, shc, col, op, sc, rot, cov, radii, geom, binb, img = ctx.saved_tensors
+        has_sh, has_col, has_sr, has_cov = ctx.present
+        dev = radii.device
+        z = lambda g, shape: (torch.zeros(shape, dtype=torch.float32, device=dev) if g is None
+                              else g.to(torch.float32).contiguous())
+        gc, gd, ga = z(g_color, (B, 3, H, W)), z(g_depth, (B, 1, H, W)), z(g_alpha, (B, 1, H, W))
+        f = lambda *s: (torch.empty if N > 0 else torch.zeros)(*s, dtype=torch.float32, device=dev)
+        d_m3, d_m2, d_op = f(N, 3), f(B, N, 3), f(N, 1)
+        d_sh = f(N, K, 3) if has_sh else None
+        d_col = f(N, 3) if has_col else None
+        d_sc, d_rot = (f(N, 3), f(N, 4)) if has_sr else (None, None)
+        d_cov = f(N, 6) if has_cov else None
+        if N > 0:
+            P = _lib.ptr
+            tmp = _lib.Scratch(dev)
+            with torch.cuda.device(dev):
+                stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+                rc = lib.gsr_backward_views(
+                    ctx.views, B, N, K, P(m3), P(shc) if has_sh else None, P(col) if has_col else None,
+                    P(op), P(sc) if has_sr else None, P(rot) if has_sr else None, P(cov) if has_cov else None,
+                    P(radii), P(gc), P(gd), P(ga), P(geom), P(binb), P(img), C.byref(ctx.stats),
+                    P(d_m3), P(d_m2), P(d_sh), P(d_col), P(d_op), P(d_sc), P(d_rot), P(d_cov), tmp.alloc, stream)
+            tmp.release()
+            _lib.check(rc, "gsr_backward_views")
+        sh_ = ctx.shapes
+        r = lambda g, shape: None if g is None or shape is None else g.reshape(shape)
+        return (r(d_m3, sh_[0]), d_m2, r(d_sh, sh_[1]), r(d_col, sh_[2]), r(d_op, sh_[3]),
+                r(d_sc, sh_[4]), r(d_rot, sh_[5]), r(d_cov, sh_[6]), None)
+
+
 def rasterize_views(means3D, means2D, opacities, raster_settings: Sequence[GaussianRasterizationSettings],
-                    shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None):
+                    shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, mode: str = "chain"):
     """Render `len(raster_settings)` cameras of the same Gaussians.
 
     Arguments as `GaussianRasterizer.forward` (gs_renderer.py:800-809) except `means2D`, the
     screen-space gradient holder, which is `[B, N, 3]` (one `[N,3]` holder per view, as the reference
     creates one per render: gs_renderer.py:727-739). Returns `(color [B,3,H,W], radii [B,N] int32,
-    depth [B,1,H,W], alpha [B,1,H,W])`; gradients of the shared inputs are summed over the views."""
-    return _RasterizeViews.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                 cov3D_precomp, tuple(raster_settings))
+    depth [B,1,H,W], alpha [B,1,H,W])`; gradients of the shared inputs are summed over the views.
+    More than GSR_MAX_VIEWS (16) cameras are rendered in chunks of 16."""
+    settings = tuple(raster_settings)
+    if mode == "streams":
+        return _RasterizeViewsStreams.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                            cov3D_precomp, settings)
+    if mode != "chain":
+        raise ValueError("mode must be 'chain' or 'streams'")
+    if len(settings) <= _lib.GSR_MAX_VIEWS:
+        return _RasterizeViews.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                     cov3D_precomp, settings)
+    parts = []
+    for i0 in range(0, len(settings), _lib.GSR_MAX_VIEWS):
+        sl = slice(i0, i0 + _lib.GSR_MAX_VIEWS)
+        parts.append(_RasterizeViews.apply(means3D, means2D[sl], shs, colors_precomp, opacities, scales, rotations,
+                                           cov3D_precomp, settings[sl]))
+    return tuple(torch.cat([p[i] for p in parts], 0) for i in range(4))

@@ -21,8 +21,9 @@
 namespace {
 
 thread_local char g_err[512] = "";
-thread_local unsigned long long* g_pinned = nullptr;   // 8 x u64 host-pinned scratch
-struct FwdHint { bool valid = false; int N = 0, H = 0, W = 0; unsigned long long M = 0, maxc = 0, M_ref = 0, V = 0; };
+thread_local unsigned long long* g_pinned = nullptr;   // kCounterWords x u64 host-pinned scratch
+constexpr int kCounterWords = 8 + 2 * GSR_MAX_VIEWS;  // device counters: 8 totals, then (M_ref, V) per view
+struct FwdHint { bool valid = false; int N = 0, H = 0, W = 0, B = 0; unsigned long long M = 0, maxc = 0, M_ref = 0, V = 0; };
 thread_local FwdHint g_hint;                            // this thread's previous gsr_forward: predicts the next one's list sizes
 thread_local hipEvent_t g_copied_own = nullptr;        // this thread's "counters copied" event (gsr_forward)
 thread_local hipEvent_t g_copied = nullptr;            // set while gsr_forward drives gsr_forward_begin
@@ -103,25 +104,30 @@ int once_per_device(F fn) {
 
 struct GeomLayout {
     size_t recs, emit, flags8, block_stats, tile_count, cursor, tile_last, tile_off, tile_seg, tile_order, plan_off, counters, total;
-    int nTiles;
+    int nTiles;        // per view
+    int allTiles;      // views * nTiles: the per-tile arrays hold every view's tiles, view-major
 };
-GeomLayout geom_layout(int N, int H, int W) {
+// B views of the same size share one scratch block: per-view arrays are [B][N] / [B][nTiles], the lists of all
+// B * nTiles tiles live in ONE array (BinLayout) addressed through tile_off.
+GeomLayout geom_layout(int N, int H, int W, int B = 1) {
     GeomLayout L;
     const int gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE;
     L.nTiles = gx * gy;
+    L.allTiles = L.nTiles * B;
+    const size_t BN = (size_t)B * (size_t)N, BT = (size_t)L.allTiles;
     size_t o = 0;
-    L.recs = o; o += align_up((size_t)N * sizeof(SplatRec));
-    L.emit = o; o += align_up((size_t)N * sizeof(EmitRec));
-    L.flags8 = o; o += align_up((size_t)N);
-    L.block_stats = o; o += align_up(2048 * 3 * 8);       // K1 grid <= 2048 workgroups
-    L.tile_count = o; o += align_up((size_t)L.nTiles * 4);
-    L.cursor = o; o += align_up((size_t)L.nTiles * 4);
-    L.tile_last = o; o += align_up((size_t)L.nTiles * 4);
-    L.counters = o; o += align_up(8 * 8);
-    L.tile_off = o; o += align_up((size_t)(L.nTiles + 1) * 4);
-    L.tile_seg = o; o += align_up((size_t)(L.nTiles + 1) * 4);
-    L.tile_order = o; o += align_up((size_t)L.nTiles * 4);
-    L.plan_off = o; o += align_up((size_t)L.nTiles * 4);
+    L.recs = o; o += align_up(BN * sizeof(SplatRec));
+    L.emit = o; o += align_up(BN * sizeof(EmitRec));
+    L.flags8 = o; o += align_up(BN);
+    L.block_stats = o; o += align_up((size_t)B * 2048 * 3 * 8);       // K1 grid <= 2048 workgroups per view
+    L.tile_count = o; o += align_up(BT * 4);
+    L.cursor = o; o += align_up(BT * 4);
+    L.tile_last = o; o += align_up(BT * 4);
+    L.counters = o; o += align_up((8 + 2 * GSR_MAX_VIEWS) * 8);   // totals, then (M_ref, V) per view
+    L.tile_off = o; o += align_up((BT + 1) * 4);
+    L.tile_seg = o; o += align_up((BT + 1) * 4);
+    L.tile_order = o; o += align_up(BT * 4);
+    L.plan_off = o; o += align_up(BT * 4);
     L.total = o;
     return L;
 }
@@ -162,6 +168,29 @@ int check_view(const GsrView* v) {
     if (!v->bg || !v->viewmatrix || !v->projmatrix || !v->campos) return fail(-1, "bg/viewmatrix/projmatrix/campos must be device pointers%s", "");
     if (v->sh_degree < 0 || v->sh_degree > 3) return fail(-1, "sh_degree must be in 0..3%s", "");
     return 0;
+}
+
+// the B views of one launch chain: same image size, SH degree, activation mode and SH buffers (they share the kernels)
+int check_views(const GsrView* views, int B) {
+    if (!views) return fail(-1, "view is NULL%s", "");
+    if (B < 1 || B > GSR_MAX_VIEWS) return fail(-1, "the number of views per call must be in 1..%s%lld", "", (long long)GSR_MAX_VIEWS);
+    for (int v = 0; v < B; ++v) {
+        if (int rc = check_view(views + v)) return rc;
+        if (views[v].image_width != views[0].image_width || views[v].image_height != views[0].image_height ||
+            views[v].sh_degree != views[0].sh_degree || (views[v].raw_activations != 0) != (views[0].raw_activations != 0) ||
+            views[v].shs_rest != views[0].shs_rest || views[v].dL_dshs_rest != views[0].dL_dshs_rest)
+            return fail(-1, "the views of one call must agree in image size, sh_degree, raw_activations and shs_rest%s", "");
+    }
+    return 0;
+}
+
+ViewSplit make_split(const GsrView* views, int B, int N, int T, int H, int W) {
+    ViewSplit vs;
+    memset(&vs, 0, sizeof(vs));
+    vs.tiles_per_view = T; vs.N = N;
+    vs.img_stride = (unsigned long long)(align_up((size_t)H * W * 4) * 7 / 4);
+    for (int v = 0; v < B; ++v) vs.bg[v] = views[v].bg;
+    return vs;
 }
 
 int check_inputs(int N, int K, const GsrView* v, const float* means3D, const float* shs,
@@ -252,50 +281,46 @@ extern "C" size_t gsr_img_bytes(int32_t H, int32_t W) { return align_up((size_t)
 // begin : per-Gaussian stage + tile scan on `stream`, then an async copy of the four counters
 //         (M_ref, V, M, longest list) to `host_counters` (caller-owned, pinned, 4 x u64).
 // finish: once the caller has waited for that copy: binning, sort, compositing.
-// gsr_forward = begin + stream synchronize + finish; callers that keep several views in flight
-// (one stream each) issue every begin first and pay the host round trip once.
-extern "C" int gsr_forward_begin(const GsrView* view, int32_t N, int32_t K,
-                                 const float* means3D, const float* shs, const float* colors_precomp,
-                                 const float* opacities, const float* scales, const float* rotations,
-                                 const float* cov3D_precomp, int32_t* radii,
-                                 GsrAlloc geom, GsrAlloc img, uint64_t* host_counters, gsr_stream_t stream_) {
+// gsr_forward = begin + wait + finish. All of it takes B views of the same size (gsr_forward_views): ONE launch of
+// every kernel covers the B cameras, the counters are totals over the views.
+namespace {
+int begin_impl(const GsrView* views, int B, int32_t N, int32_t K,
+               const float* means3D, const float* shs, const float* colors_precomp,
+               const float* opacities, const float* scales, const float* rotations,
+               const float* cov3D_precomp, int32_t* radii,
+               GsrAlloc geom, GsrAlloc img, uint64_t* host_counters, int counter_words, gsr_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (int rc = check_view(view)) return rc;
+    if (int rc = check_views(views, B)) return rc;
+    const GsrView* view = views;
     if (int rc = check_inputs(N, K, view, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp)) return rc;
     if (N > 0 && !radii) return fail(-1, "radii is required%s", "");
     if (!geom.resize || !img.resize || !host_counters) return fail(-1, "scratch allocators and host_counters are required%s", "");
-    const ViewConst vc0 = make_view(view);
-    const GeomLayout GL0 = geom_layout(N, vc0.H, vc0.W);
-    char* gbuf = (char*)geom.resize(geom.ctx, GL0.total);
-    char* ibuf = (char*)img.resize(img.ctx, gsr_img_bytes(vc0.H, vc0.W));
-    if (!gbuf || !ibuf) return fail(-4, "scratch allocation failed%s", "");
-    const ViewConst vc = make_view(view);
+    ViewTab tab;
+    memset(&tab, 0, sizeof(tab));
+    for (int v = 0; v < B; ++v) tab.v[v] = make_view(views + v);
+    const ViewConst& vc = tab.v[0];
     const int H = vc.H, W = vc.W;
-    const GeomLayout GL = geom_layout(N, H, W);
+    const GeomLayout GL = geom_layout(N, H, W, B);
     const int T = GL.nTiles;
+    char* gbuf = (char*)geom.resize(geom.ctx, GL.total);
+    char* ibuf = (char*)img.resize(img.ctx, gsr_img_bytes(H, W) * (size_t)B);
+    if (!gbuf || !ibuf) return fail(-4, "scratch allocation failed%s", "");
 
     SplatRec* recs = (SplatRec*)(gbuf + GL.recs);
     EmitRec* emit = (EmitRec*)(gbuf + GL.emit);
     uint32_t* tile_count = (uint32_t*)(gbuf + GL.tile_count);
-    uint32_t* cursor = (uint32_t*)(gbuf + GL.cursor);
     uint32_t* tile_off = (uint32_t*)(gbuf + GL.tile_off);
     uint32_t* tile_seg = (uint32_t*)(gbuf + GL.tile_seg);
-    uint32_t* tile_last = (uint32_t*)(gbuf + GL.tile_last);
     uint32_t* tile_order = use_tile_order_off() ? nullptr : (uint32_t*)(gbuf + GL.tile_order);
     unsigned long long* counters = (unsigned long long*)(gbuf + GL.counters);
-    float* final_T = (float*)ibuf;
-    uint32_t* n_contrib = (uint32_t*)(ibuf + align_up((size_t)H * W * 4));
-    float* totals = (float*)(ibuf + 2 * align_up((size_t)H * W * 4));
 
     const int hist_in_lds = T <= kHistLdsMaxTiles;
-    const int grid_n = N > 0 ? (int)fmin((double)((N + 255) / 256), 512.0) : 0;
-    (void)cursor; (void)final_T; (void)n_contrib; (void)totals; (void)tile_last; (void)grid_n;
-    // tile_count | cursor | counters are contiguous: one memset
+    // tile_count | cursor | tile_last | counters are contiguous: one memset
     prof_begin(stream);
     HIP_TRY(hipMemsetAsync(gbuf + GL.tile_count, 0, GL.tile_off - GL.tile_count, stream));
     prof_end(stream, "memset_fwd");
 
-    static const int k1_grid = [] {   // GSR_K1_GRID: workgroups of the per-Gaussian kernel (block_stats holds 2048)
+    static const int k1_grid = [] {   // GSR_K1_GRID: workgroups of the per-Gaussian kernel (block_stats holds 2048 per view)
         const char* e = getenv("GSR_K1_GRID");
         const int g = e ? atoi(e) : 1024;
         return g < 1 ? 1 : (g > 2048 ? 2048 : g);
@@ -309,44 +334,45 @@ extern "C" int gsr_forward_begin(const GsrView* view, int32_t N, int32_t K,
         auto k1 = vc.raw_act ? gsr_preprocess_fwd<true> : gsr_preprocess_fwd<false>;
         if (lds > 48 * 1024)
             HIP_TRY(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        prof_begin(stream); hipLaunchKernelGGL(k1, dim3(grid_pre), dim3(256), lds, stream, vc, N, K, means3D, shs, view->shs_rest,
+        prof_begin(stream); hipLaunchKernelGGL(k1, dim3(grid_pre, B), dim3(256), lds, stream, tab, N, K, means3D, shs, view->shs_rest,
                            colors_precomp, opacities, scales, rotations, cov3D_precomp, recs, emit, radii,
                            tile_count, (unsigned long long*)(gbuf + GL.block_stats), hist_in_lds, (uint8_t*)(gbuf + GL.flags8));
         LAUNCH_CHECK(view, stream, "preprocess_fwd");
     }
     // one single-workgroup kernel: scan of the counts, K1's statistics, heaviest-first launch order
-    prof_begin(stream); hipLaunchKernelGGL(gsr_tile_scan, dim3(1), dim3(1024), 0, stream, tile_count, tile_off, T, counters, tile_seg, seg_shift(),
-                       (const unsigned long long*)(gbuf + GL.block_stats), N > 0 ? grid_pre : 0, tile_order);
+    prof_begin(stream); hipLaunchKernelGGL(gsr_tile_scan, dim3(1), dim3(1024), 0, stream, tile_count, tile_off, GL.allTiles, counters, tile_seg, seg_shift(),
+                       (const unsigned long long*)(gbuf + GL.block_stats), N > 0 ? grid_pre * B : 0, B, tile_order);
     LAUNCH_CHECK(view, stream, "tile_scan");
     // gsr_forward waits for THIS copy only (g_copied)
-    HIP_TRY(hipMemcpyAsync(host_counters, counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(host_counters, counters, (size_t)counter_words * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
     if (g_copied) HIP_TRY(hipEventRecord(g_copied, stream));
     return 0;
 }
 
-namespace {
 int sort_class(unsigned long long maxc) { return maxc <= 2048 ? 0 : (maxc <= 8192 ? 1 : (maxc <= 16384 ? 2 : 3)); }
 
 // Binning, sort and compositing for lists of up to `cap` instances whose longest is assumed <= `maxc`.
 // cap / maxc are either the exact counters (the host has waited for them) or gsr_forward's prediction; in the
 // second case M_ref / V steer only the per-scene kernel choice and the kernels themselves check the true M.
-int finish_impl(const GsrView* view, int32_t N, float* out_color, float* out_depth, float* out_alpha,
+int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float* out_depth, float* out_alpha,
                 void* geom_ptr, void* img_ptr, GsrAlloc bin, unsigned long long M_ref, unsigned long long V,
+                const unsigned long long* per_view /* (M_ref, V) of every view, or NULL: the totals decide for all */,
                 unsigned long long cap, unsigned long long maxc, gsr_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (int rc = check_view(view)) return rc;
+    if (int rc = check_views(views, B)) return rc;
+    const GsrView* view = views;
     if (!out_color || !out_depth || !out_alpha) return fail(-1, "output pointers are required%s", "");
     if (!geom_ptr || !img_ptr || !bin.resize) return fail(-1, "forward_begin state is required%s", "");
     char* gbuf = (char*)geom_ptr;
     char* ibuf = (char*)img_ptr;
     const ViewConst vc = make_view(view);
     const int H = vc.H, W = vc.W;
-    const GeomLayout GL = geom_layout(N, H, W);
-    const int T = GL.nTiles;
+    const GeomLayout GL = geom_layout(N, H, W, B);
+    const int T = GL.nTiles, TA = GL.allTiles;
+    ViewSplit vs = make_split(views, B, N, T, H, W);
 
     SplatRec* recs = (SplatRec*)(gbuf + GL.recs);
     EmitRec* emit = (EmitRec*)(gbuf + GL.emit);
-    uint32_t* tile_count = (uint32_t*)(gbuf + GL.tile_count);
     uint32_t* cursor = (uint32_t*)(gbuf + GL.cursor);
     uint32_t* tile_off = (uint32_t*)(gbuf + GL.tile_off);
     uint32_t* tile_seg = (uint32_t*)(gbuf + GL.tile_seg);
@@ -358,12 +384,10 @@ int finish_impl(const GsrView* view, int32_t N, float* out_color, float* out_dep
     float* totals = (float*)(ibuf + 2 * align_up((size_t)H * W * 4));
 
     const int hist_in_lds = T <= kHistLdsMaxTiles;
-    const int grid_n = N > 0 ? (int)fmin((double)((N + 255) / 256), 512.0) : 0;
-    (void)tile_count;
     const unsigned long long M = cap;
     if (M >= 0xfffffff0ull) return fail(-5, "too many tile instances (%s%lld)", "", (long long)M);
 
-    const BinLayout BL = bin_layout((size_t)M, T);
+    const BinLayout BL = bin_layout((size_t)M, TA);
     char* bbuf = (char*)bin.resize(bin.ctx, BL.total);
     if (!bbuf) return fail(-4, "bin scratch allocation failed%s", "");
     unsigned long long* entries = (unsigned long long*)(bbuf + BL.entries);
@@ -376,7 +400,7 @@ int finish_impl(const GsrView* view, int32_t N, float* out_color, float* out_dep
             HIP_TRY(hipFuncSetAttribute((const void*)gsr_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         static const int scatter_grid = [] { const char* e = getenv("GSR_SCATTER_GRID"); const int g = e ? atoi(e) : 512; return g < 1 ? 1 : (g > 4096 ? 4096 : g); }();
         const int grid_sc = (int)fmin((double)((N + 255) / 256), (double)scatter_grid);
-        prof_begin(stream); hipLaunchKernelGGL(gsr_scatter, dim3(grid_sc), dim3(256), lds, stream, N, emit, tile_off, cursor, entries,
+        prof_begin(stream); hipLaunchKernelGGL(gsr_scatter, dim3(grid_sc, B), dim3(256), lds, stream, N, emit, tile_off, cursor, entries,
                            vc.gx, T, hist_in_lds, (uint32_t)M, counters);
         LAUNCH_CHECK(view, stream, "scatter");
         // per-tile sort, size classes by list length
@@ -388,18 +412,18 @@ int finish_impl(const GsrView* view, int32_t N, float* out_color, float* out_dep
                 if (e != hipSuccess) return e;
                 return hipFuncSetAttribute((const void*)gsr_tile_sort_bucket<16384, 1024, 2048>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l);
             })) return rc;
-        prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<2048, 256, 512>), dim3(T), dim3(256), lds_s, stream, tile_off, entries, sorted_ids, 0u, 2048u, counters, (uint32_t)M);
+        prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<2048, 256, 512>), dim3(TA), dim3(256), lds_s, stream, tile_off, entries, sorted_ids, 0u, 2048u, counters, (uint32_t)M);
         LAUNCH_CHECK(view, stream, "tile_sort_small");
         if (maxc > 2048) {
-            prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<8192, 1024, 2048>), dim3(T), dim3(1024), lds_m, stream, tile_off, entries, sorted_ids, 2048u, 8192u, counters, (uint32_t)M);
+            prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<8192, 1024, 2048>), dim3(TA), dim3(1024), lds_m, stream, tile_off, entries, sorted_ids, 2048u, 8192u, counters, (uint32_t)M);
             LAUNCH_CHECK(view, stream, "tile_sort_medium");
         }
         if (maxc > 8192) {
-            prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<16384, 1024, 2048>), dim3(T), dim3(1024), lds_l, stream, tile_off, entries, sorted_ids, 8192u, 16384u, counters, (uint32_t)M);
+            prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<16384, 1024, 2048>), dim3(TA), dim3(1024), lds_l, stream, tile_off, entries, sorted_ids, 8192u, 16384u, counters, (uint32_t)M);
             LAUNCH_CHECK(view, stream, "tile_sort_large");
         }
         if (maxc > 16384) {
-            prof_begin(stream); hipLaunchKernelGGL(gsr_tile_sort_global_ids, dim3(T), dim3(1024), 0, stream, tile_off, entries, sorted_ids, 16384u, counters, (uint32_t)M);
+            prof_begin(stream); hipLaunchKernelGGL(gsr_tile_sort_global_ids, dim3(TA), dim3(1024), 0, stream, tile_off, entries, sorted_ids, 16384u, counters, (uint32_t)M);
             LAUNCH_CHECK(view, stream, "tile_sort_global");
         }
     }
@@ -407,56 +431,54 @@ int finish_impl(const GsrView* view, int32_t N, float* out_color, float* out_dep
     // Quad lists pay when splats are small against an 8x8 block (few of its 64 lanes blend a given Gaussian):
     // measured -2% / -7% / -9% at 1M blob / 1M trained / 250k-512^2 (4.2-4.3 reference tiles per Gaussian) and +7% at
     // 100k-800^2 (10.4): the scene statistic the host already holds decides.
-    const bool fwd_q = fwd_kernel_env() == 2 || (fwd_kernel_env() == 0 && V > 0 && M_ref <= 6ull * V);
-    if (fwd_q)
-        hipLaunchKernelGGL(gsr_render_fwd_q, dim3(T), dim3(256), 0, stream, tile_off, recs, sorted_ids, view->bg, W, H, vc.gx,
-                           out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, tile_order, seg_shift(), tile_last, counters, (uint32_t)M);
-    else
-        hipLaunchKernelGGL(gsr_render_fwd, dim3(T), dim3(256), 0, stream, tile_off, recs, sorted_ids, view->bg, W, H, vc.gx,
-                           out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, tile_order, seg_shift(), tile_last, counters, (uint32_t)M);
+    // Views are judged one by one (a view renders with the kernel its single-view call would use: bit-identical images).
+    uint32_t mask_q = 0;
+    for (int v = 0; v < B; ++v) {
+        const unsigned long long mr = per_view ? per_view[2 * v] : M_ref, vv = per_view ? per_view[2 * v + 1] : V;
+        if (fwd_kernel_env() == 2 || (fwd_kernel_env() == 0 && vv > 0 && mr <= 6ull * vv)) mask_q |= 1u << v;
+    }
+    const uint32_t mask_all = B >= 32 ? ~0u : ((1u << B) - 1u);
+    if (mask_q) {
+        vs.view_mask = mask_q;
+        hipLaunchKernelGGL(gsr_render_fwd_q, dim3(TA), dim3(256), 0, stream, tile_off, recs, sorted_ids, W, H, vc.gx,
+                           out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, tile_order, seg_shift(), tile_last, counters, (uint32_t)M, vs);
+    }
+    if (mask_q != mask_all) {
+        vs.view_mask = mask_all & ~mask_q;
+        hipLaunchKernelGGL(gsr_render_fwd, dim3(TA), dim3(256), 0, stream, tile_off, recs, sorted_ids, W, H, vc.gx,
+                           out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, tile_order, seg_shift(), tile_last, counters, (uint32_t)M, vs);
+    }
     LAUNCH_CHECK(view, stream, "render_fwd");
     return 0;
 }
-}  // namespace
 
-extern "C" int gsr_forward_finish(const GsrView* view, int32_t N, int32_t K,
-                                  float* out_color, float* out_depth, float* out_alpha,
-                                  void* geom_ptr, void* img_ptr, GsrAlloc bin,
-                                  const uint64_t* host_counters, GsrStats* stats, gsr_stream_t stream_) {
-    (void)K;
-    if (!host_counters) return fail(-1, "forward_begin state is required%s", "");
-    const unsigned long long M_ref = host_counters[0], V = host_counters[1], M = host_counters[2], maxc = host_counters[3];
-    if (stats) { stats->num_instances = (int64_t)M; stats->num_instances_ref = (int64_t)M_ref; stats->num_visible = (int64_t)V;
-                 stats->max_tile_count = (int64_t)maxc; stats->bin_capacity = (int64_t)M; }
-    return finish_impl(view, N, out_color, out_depth, out_alpha, geom_ptr, img_ptr, bin, M_ref, V, M, maxc, stream_);
-}
-
-extern "C" int gsr_forward(const GsrView* view, int32_t N, int32_t K,
-                           const float* means3D, const float* shs, const float* colors_precomp,
-                           const float* opacities, const float* scales, const float* rotations,
-                           const float* cov3D_precomp,
-                           float* out_color, float* out_depth, float* out_alpha, int32_t* radii,
-                           GsrAlloc geom, GsrAlloc bin, GsrAlloc img,
-                           GsrStats* stats, gsr_stream_t stream_) {
-    if (int rc = check_view(view)) return rc;
+int forward_impl(const GsrView* views, int B, int32_t N, int32_t K,
+                 const float* means3D, const float* shs, const float* colors_precomp,
+                 const float* opacities, const float* scales, const float* rotations,
+                 const float* cov3D_precomp,
+                 float* out_color, float* out_depth, float* out_alpha, int32_t* radii,
+                 GsrAlloc geom, GsrAlloc bin, GsrAlloc img,
+                 GsrStats* stats, gsr_stream_t stream_) {
+    if (int rc = check_views(views, B)) return rc;
+    const GsrView* view = views;
     if (int rc = check_inputs(N, K, view, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp)) return rc;
     if (!out_color || !out_depth || !out_alpha || (N > 0 && !radii)) return fail(-1, "output pointers are required%s", "");
     if (!geom.resize || !bin.resize || !img.resize) return fail(-1, "scratch allocators are required%s", "");
     // the one host round trip of the forward: how many (tile,Gaussian) instances to allocate
-    if (!g_pinned) HIP_TRY(hipHostMalloc((void**)&g_pinned, 8 * sizeof(unsigned long long), hipHostMallocDefault));
+    if (!g_pinned) HIP_TRY(hipHostMalloc((void**)&g_pinned, kCounterWords * sizeof(unsigned long long), hipHostMallocDefault));
     struct Capture { GsrAlloc inner; void* ptr; };
     Capture cg{geom, nullptr}, ci{img, nullptr};
     auto tramp = [](void* ctx, size_t bytes) -> void* { Capture* c = (Capture*)ctx; c->ptr = c->inner.resize(c->inner.ctx, bytes); return c->ptr; };
     GsrAlloc ag{&cg, tramp}, ai{&ci, tramp};
     if (!g_copied_own) HIP_TRY(hipEventCreateWithFlags(&g_copied_own, hipEventDisableTiming));
     hipEvent_t ev = g_copied_own;
-    g_copied = ev;                                        // gsr_forward_begin records it right after the counter copy
-    const int rc_begin = gsr_forward_begin(view, N, K, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                                           radii, ag, ai, (uint64_t*)g_pinned, stream_);
+    g_copied = ev;                                        // begin_impl records it right after the counter copy
+    const int rc_begin = begin_impl(views, B, N, K, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                    radii, ag, ai, (uint64_t*)g_pinned, 8 + 2 * B, stream_);
     g_copied = nullptr;
     if (rc_begin) return rc_begin;
     const ViewConst vcs = make_view(view);
-    const GeomLayout GLs = geom_layout(N, vcs.H, vcs.W);
+    const GeomLayout GLs = geom_layout(N, vcs.H, vcs.W, B);
     // Speculation (GSR_SPECULATE=1, off by default): the previous call of this thread on the same problem shape predicts
     // M (+25 %) and the sort classes; binning / sort / compositing are enqueued at once, the host waits for the counters
     // only afterwards and repeats the tail when the prediction was too small (the kernels refuse to touch lists that do
@@ -465,14 +487,14 @@ extern "C" int gsr_forward(const GsrView* view, int32_t N, int32_t K,
     // and 1M / 800^2 unchanged -- hipEventSynchronize on the early event returns only when the work enqueued behind it has
     // drained, so the backward's launches start late. The default keeps the early wait (K1 + scan only ahead of it).
     static const bool spec_on = [] { const char* e = getenv("GSR_SPECULATE"); return e && e[0] == '1'; }();
-    const bool spec = spec_on && g_hint.valid && g_hint.N == N && g_hint.H == vcs.H && g_hint.W == vcs.W && N > 0;
+    const bool spec = spec_on && g_hint.valid && g_hint.N == N && g_hint.H == vcs.H && g_hint.W == vcs.W && g_hint.B == B && N > 0;
     unsigned long long cap = 0, capc = 0;
     int rc = 0;
     if (spec) {
         cap = g_hint.M + g_hint.M / 4 + 4096;
         const unsigned long long c = g_hint.maxc + g_hint.maxc / 4 + 64;
         capc = c <= 2048 ? 2048 : (c <= 8192 ? 8192 : (c <= 16384 ? 16384 : ~0ull));
-        rc = finish_impl(view, N, out_color, out_depth, out_alpha, cg.ptr, ci.ptr, bin, g_hint.M_ref, g_hint.V, cap, capc, stream_);
+        rc = finish_impl(views, B, N, out_color, out_depth, out_alpha, cg.ptr, ci.ptr, bin, g_hint.M_ref, g_hint.V, nullptr, cap, capc, stream_);
         if (rc) return rc;
     }
     HIP_TRY(hipEventSynchronize(ev));
@@ -484,26 +506,27 @@ extern "C" int gsr_forward(const GsrView* view, int32_t N, int32_t K,
     }
     if (!spec || cap == 0) {
         cap = M;
-        rc = finish_impl(view, N, out_color, out_depth, out_alpha, cg.ptr, ci.ptr, bin, M_ref, V, M, maxc, stream_);
+        rc = finish_impl(views, B, N, out_color, out_depth, out_alpha, cg.ptr, ci.ptr, bin, M_ref, V, g_pinned + 8, M, maxc, stream_);
     }
     if (stats) { stats->num_instances = (int64_t)M; stats->num_instances_ref = (int64_t)M_ref; stats->num_visible = (int64_t)V;
                  stats->max_tile_count = (int64_t)maxc; stats->bin_capacity = (int64_t)cap; }
-    if (rc == 0) { g_hint.valid = true; g_hint.N = N; g_hint.H = vcs.H; g_hint.W = vcs.W; g_hint.M = M; g_hint.maxc = maxc; g_hint.M_ref = M_ref; g_hint.V = V; }
+    if (rc == 0) { g_hint.valid = true; g_hint.N = N; g_hint.H = vcs.H; g_hint.W = vcs.W; g_hint.B = B; g_hint.M = M; g_hint.maxc = maxc; g_hint.M_ref = M_ref; g_hint.V = V; }
     return rc;
 }
 
-extern "C" int gsr_backward(const GsrView* view, int32_t N, int32_t K,
-                            const float* means3D, const float* shs, const float* colors_precomp,
-                            const float* opacities, const float* scales, const float* rotations,
-                            const float* cov3D_precomp, const int32_t* radii,
-                            const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
-                            const void* geom, const void* bin, const void* img,
-                            const GsrStats* fwd_stats,
-                            float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs, float* dL_dcolors,
-                            float* dL_dopacities, float* dL_dscales, float* dL_drotations,
-                            float* dL_dcov3D, GsrAlloc tmp, gsr_stream_t stream_) {
+int backward_impl(const GsrView* views, int B, int32_t N, int32_t K,
+                  const float* means3D, const float* shs, const float* colors_precomp,
+                  const float* opacities, const float* scales, const float* rotations,
+                  const float* cov3D_precomp, const int32_t* radii,
+                  const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
+                  const void* geom, const void* bin, const void* img,
+                  const GsrStats* fwd_stats,
+                  float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs, float* dL_dcolors,
+                  float* dL_dopacities, float* dL_dscales, float* dL_drotations,
+                  float* dL_dcov3D, GsrAlloc tmp, gsr_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (int rc = check_view(view)) return rc;
+    if (int rc = check_views(views, B)) return rc;
+    const GsrView* view = views;
     if (int rc = check_inputs(N, K, view, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp)) return rc;
     if (N == 0) return 0;
     if (!geom || !bin || !img || !radii) return fail(-1, "forward state (geom/bin/img/radii) is required%s", "");
@@ -514,8 +537,9 @@ extern "C" int gsr_backward(const GsrView* view, int32_t N, int32_t K,
     if (!tmp.resize) return fail(-1, "tmp allocator is required%s", "");
     const ViewConst vc = make_view(view);
     const int H = vc.H, W = vc.W;
-    const GeomLayout GL = geom_layout(N, H, W);
-    const int T = GL.nTiles;
+    const GeomLayout GL = geom_layout(N, H, W, B);
+    const int T = GL.nTiles, TA = GL.allTiles;
+    const ViewSplit vs = make_split(views, B, N, T, H, W);
     const char* gbuf = (const char*)geom;
     const char* ibuf = (const char*)img;
     const SplatRec* recs = (const SplatRec*)(gbuf + GL.recs);
@@ -525,8 +549,6 @@ extern "C" int gsr_backward(const GsrView* view, int32_t N, int32_t K,
     const uint32_t* n_contrib = (const uint32_t*)(ibuf + align_up((size_t)H * W * 4));
     const float* totals = (const float*)(ibuf + 2 * align_up((size_t)H * W * 4));
     const uint32_t* tile_seg = (const uint32_t*)(gbuf + GL.tile_seg);
-    // M and the longest tile list of the matching forward (for the checkpoint offset and the
-    // segment grid): from the caller's GsrStats, else read back from the device (blocking)
     // the layout of `bin` follows the capacity it was sized for (>= M): from the caller's GsrStats, else read back
     // from the device (blocking): counters[6], left there by the forward's scatter kernel
     unsigned long long M = 0;
@@ -539,14 +561,15 @@ extern "C" int gsr_backward(const GsrView* view, int32_t N, int32_t K,
     }
     const uint32_t* sorted_ids = (const uint32_t*)bin;    // BinLayout.ids == 0
 
-    float* g2d = (float*)tmp.resize(tmp.ctx, align_up((size_t)N * GSR_G2D_STRIDE * 4));
+    const size_t g2d_view = (size_t)N * GSR_G2D_STRIDE;
+    float* g2d = (float*)tmp.resize(tmp.ctx, align_up(g2d_view * 4 * (size_t)B));
     if (!g2d) return fail(-4, "tmp scratch allocation failed%s", "");
     prof_begin(stream);
-    HIP_TRY(hipMemsetAsync(g2d, 0, (size_t)N * GSR_G2D_STRIDE * 4, stream));
+    HIP_TRY(hipMemsetAsync(g2d, 0, g2d_view * 4 * (size_t)B, stream));
     prof_end(stream, "memset_bwd");
 
     if (M > 0) {
-        const BinLayout BL = bin_layout((size_t)M, T);
+        const BinLayout BL = bin_layout((size_t)M, TA);
         const float* ckpt = (const float*)((const char*)bin + BL.ckpt);
         // scratch of the matching forward, written here: the backward work list
         uint32_t* plan_tile = (uint32_t*)((char*)const_cast<void*>(bin) + BL.plan_tile);
@@ -554,42 +577,112 @@ extern "C" int gsr_backward(const GsrView* view, int32_t N, int32_t K,
         unsigned long long* plan_total = const_cast<unsigned long long*>(counters) + 4;
         const uint32_t* tile_last = (const uint32_t*)(gbuf + GL.tile_last);
         prof_begin(stream);
-        hipLaunchKernelGGL(gsr_bwd_plan, dim3(1), dim3(1024), 0, stream, tile_last, T, seg_shift(), (uint32_t)BL.plan_cap,
+        hipLaunchKernelGGL(gsr_bwd_plan, dim3(1), dim3(1024), 0, stream, tile_last, TA, seg_shift(), (uint32_t)BL.plan_cap,
                            plan_off, plan_tile, plan_total);
         LAUNCH_CHECK(view, stream, "bwd_plan");
         prof_begin(stream);
         const unsigned grid = (unsigned)BL.plan_cap;
         // workgroup table: [2^shift][10] 64-bit fixed-point sums
         const size_t dyn = ((size_t)GSR_Q2_ROW * 8) << seg_shift();
-#define GSR_LAUNCH_BWD(KERNEL)                                                                          \
-        hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(256), dyn, stream, tile_off, recs, sorted_ids, view->bg, W, H, vc.gx, \
-                           final_T, n_contrib, totals, ckpt, tile_seg, dL_dcolor, dL_ddepth, dL_dalpha, g2d, seg_shift(), \
-                           plan_tile, plan_off, plan_total)
-        GSR_LAUNCH_BWD(gsr_render_bwd_q2);
-#undef GSR_LAUNCH_BWD
+        hipLaunchKernelGGL(gsr_render_bwd_q2, dim3(grid), dim3(256), dyn, stream, tile_off, recs, sorted_ids, W, H, vc.gx,
+                           final_T, n_contrib, totals, ckpt, tile_seg, dL_dcolor, dL_ddepth, dL_dalpha, g2d, seg_shift(),
+                           plan_tile, plan_off, plan_total, vs);
     } else prof_begin(stream);
     LAUNCH_CHECK(view, stream, "render_bwd");
 
     const int grid_n = (int)fmin((double)((N + 255) / 256), 2048.0);
     const size_t lds = (shs && K > 1) ? (size_t)256 * (3 * K + 1) * 4 : 0;
     if (lds > 160 * 1024) return fail(-1, "preprocess_bwd needs more than 160 KiB of LDS%s", "");
-    if (lds > 48 * 1024) {
-        HIP_TRY(hipFuncSetAttribute((const void*)gsr_preprocess_bwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)gsr_preprocess_bwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    auto k6 = vc.raw_act ? gsr_preprocess_bwd<true> : gsr_preprocess_bwd<false>;
+    if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // One launch per view, the LAST view first and the others added to it: the order in which autograd accumulates the
+    // parameter gradients of B separate rasterizer calls (the node created last runs first), so that the sums are
+    // bit-identical to the serial loop. dL_dmeans2D stays per view ([B,N,3]).
+    for (int v = B - 1; v >= 0; --v) {
+        const ViewConst vcv = make_view(views + v);
+        prof_begin(stream);
+        hipLaunchKernelGGL(k6, dim3(grid_n), dim3(256), lds, stream, vcv, N, K, means3D, shs, view->shs_rest, view->dL_dshs_rest,
+                           colors_precomp, opacities, scales, rotations, cov3D_precomp, radii + (size_t)v * N,
+                           (const uint8_t*)(gbuf + GL.flags8) + (size_t)v * N, g2d + (size_t)v * g2d_view,
+                           dL_dmeans3D, dL_dmeans2D + (size_t)v * N * 3, dL_dshs, dL_dcolors, dL_dopacities, dL_dscales,
+                           dL_drotations, dL_dcov3D, v == B - 1 ? 0 : 1);
+        LAUNCH_CHECK(view, stream, "preprocess_bwd");
     }
-    prof_begin(stream);
-    if (vc.raw_act)
-        hipLaunchKernelGGL(gsr_preprocess_bwd<true>, dim3(grid_n), dim3(256), lds, stream, vc, N, K, means3D, shs, view->shs_rest, view->dL_dshs_rest,
-                           colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, (const uint8_t*)(gbuf + GL.flags8), g2d,
-                           dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacities, dL_dscales,
-                           dL_drotations, dL_dcov3D);
-    else
-        hipLaunchKernelGGL(gsr_preprocess_bwd<false>, dim3(grid_n), dim3(256), lds, stream, vc, N, K, means3D, shs, view->shs_rest, view->dL_dshs_rest,
-                           colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, (const uint8_t*)(gbuf + GL.flags8), g2d,
-                           dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacities, dL_dscales,
-                           dL_drotations, dL_dcov3D);
-    LAUNCH_CHECK(view, stream, "preprocess_bwd");
     return 0;
+}
+}  // namespace
+
+extern "C" int gsr_forward_begin(const GsrView* view, int32_t N, int32_t K,
+                                 const float* means3D, const float* shs, const float* colors_precomp,
+                                 const float* opacities, const float* scales, const float* rotations,
+                                 const float* cov3D_precomp, int32_t* radii,
+                                 GsrAlloc geom, GsrAlloc img, uint64_t* host_counters, gsr_stream_t stream) {
+    return begin_impl(view, 1, N, K, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, geom, img, host_counters, 4, stream);
+}
+
+extern "C" int gsr_forward_finish(const GsrView* view, int32_t N, int32_t K,
+                                  float* out_color, float* out_depth, float* out_alpha,
+                                  void* geom_ptr, void* img_ptr, GsrAlloc bin,
+                                  const uint64_t* host_counters, GsrStats* stats, gsr_stream_t stream_) {
+    (void)K;
+    if (!host_counters) return fail(-1, "forward_begin state is required%s", "");
+    const unsigned long long M_ref = host_counters[0], V = host_counters[1], M = host_counters[2], maxc = host_counters[3];
+    if (stats) { stats->num_instances = (int64_t)M; stats->num_instances_ref = (int64_t)M_ref; stats->num_visible = (int64_t)V;
+                 stats->max_tile_count = (int64_t)maxc; stats->bin_capacity = (int64_t)M; }
+    return finish_impl(view, 1, N, out_color, out_depth, out_alpha, geom_ptr, img_ptr, bin, M_ref, V, nullptr, M, maxc, stream_);
+}
+
+extern "C" int gsr_forward(const GsrView* view, int32_t N, int32_t K,
+                           const float* means3D, const float* shs, const float* colors_precomp,
+                           const float* opacities, const float* scales, const float* rotations,
+                           const float* cov3D_precomp,
+                           float* out_color, float* out_depth, float* out_alpha, int32_t* radii,
+                           GsrAlloc geom, GsrAlloc bin, GsrAlloc img,
+                           GsrStats* stats, gsr_stream_t stream) {
+    return forward_impl(view, 1, N, K, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                        out_color, out_depth, out_alpha, radii, geom, bin, img, stats, stream);
+}
+
+extern "C" int gsr_backward(const GsrView* view, int32_t N, int32_t K,
+                            const float* means3D, const float* shs, const float* colors_precomp,
+                            const float* opacities, const float* scales, const float* rotations,
+                            const float* cov3D_precomp, const int32_t* radii,
+                            const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
+                            const void* geom, const void* bin, const void* img,
+                            const GsrStats* fwd_stats,
+                            float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs, float* dL_dcolors,
+                            float* dL_dopacities, float* dL_dscales, float* dL_drotations,
+                            float* dL_dcov3D, GsrAlloc tmp, gsr_stream_t stream) {
+    return backward_impl(view, 1, N, K, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii,
+                         dL_dcolor, dL_ddepth, dL_dalpha, geom, bin, img, fwd_stats, dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors,
+                         dL_dopacities, dL_dscales, dL_drotations, dL_dcov3D, tmp, stream);
+}
+
+// ---- B cameras, one launch chain (include/gsr.h) -------------------------------------------------
+extern "C" int gsr_forward_views(const GsrView* views, int32_t B, int32_t N, int32_t K,
+                                 const float* means3D, const float* shs, const float* colors_precomp,
+                                 const float* opacities, const float* scales, const float* rotations,
+                                 const float* cov3D_precomp,
+                                 float* out_color, float* out_depth, float* out_alpha, int32_t* radii,
+                                 GsrAlloc geom, GsrAlloc bin, GsrAlloc img,
+                                 GsrStats* stats, gsr_stream_t stream) {
+    return forward_impl(views, B, N, K, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                        out_color, out_depth, out_alpha, radii, geom, bin, img, stats, stream);
+}
+
+extern "C" int gsr_backward_views(const GsrView* views, int32_t B, int32_t N, int32_t K,
+                                  const float* means3D, const float* shs, const float* colors_precomp,
+                                  const float* opacities, const float* scales, const float* rotations,
+                                  const float* cov3D_precomp, const int32_t* radii,
+                                  const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
+                                  const void* geom, const void* bin, const void* img,
+                                  const GsrStats* fwd_stats,
+                                  float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs, float* dL_dcolors,
+                                  float* dL_dopacities, float* dL_dscales, float* dL_drotations,
+                                  float* dL_dcov3D, GsrAlloc tmp, gsr_stream_t stream) {
+    return backward_impl(views, B, N, K, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii,
+                         dL_dcolor, dL_ddepth, dL_dalpha, geom, bin, img, fwd_stats, dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors,
+                         dL_dopacities, dL_dscales, dL_drotations, dL_dcov3D, tmp, stream);
 }
 
 extern "C" int gsr_mark_visible(const GsrView* view, int32_t N, const float* means3D,

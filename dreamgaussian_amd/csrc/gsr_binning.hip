@@ -15,12 +15,13 @@
 
 // ---------------------------------------------------------------------------------------
 // K2: exclusive scan of the per-tile counts (single workgroup; T is a few thousand).
-// counters[0] = M_ref, [1] = V, [2] = M_emit, [3] = max per-tile count, [5] = bits of max(colour, depth).
+// counters[0] = M_ref, [1] = V, [2] = M_emit, [3] = max per-tile count, [5] = bits of max(colour, depth),
+// [8 + 2v], [9 + 2v] = M_ref, V of view v.
 // ---------------------------------------------------------------------------------------
 extern "C" __global__ void __launch_bounds__(1024)
 gsr_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_off, int T,
               unsigned long long* __restrict__ counters, uint32_t* __restrict__ tile_seg, int seg_shift,
-              const unsigned long long* __restrict__ block_stats, int nblocks,
+              const unsigned long long* __restrict__ block_stats, int nblocks /* all views */, int nviews,
               uint32_t* __restrict__ order /* heaviest-first launch order of the compositing forward, or NULL */) {
     // tile_seg[t] = index of tile t's first checkpoint slot = exclusive scan of floor((n_t-1) >> seg_shift)
     __shared__ unsigned long long wsum[16];
@@ -70,6 +71,16 @@ gsr_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ ti
             unsigned long long ta = 0, tb = 0, tc = 0;
             for (int w = 0; w < 16; ++w) { ta += sref[w]; tb += svis[w]; tc = max(tc, smax[w]); }
             counters[0] = ta; counters[1] = tb; counters[5] = tc;
+        }
+        // per view (block_stats is [view][workgroup][3]): counters[8 + 2v] = M_ref, [9 + 2v] = V -- the host picks the
+        // compositing kernel of every view from them exactly as a single-view call would
+        const int per_view = nviews > 0 ? nblocks / nviews : 0;
+        for (int v = wave; v < nviews; v += 16) {
+            unsigned long long va = 0, vb = 0;
+            for (int i = lane; i < per_view; i += 64) { va += block_stats[3 * (v * per_view + i)]; vb += block_stats[3 * (v * per_view + i) + 1]; }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) { va += __shfl_xor(va, off, 64); vb += __shfl_xor(vb, off, 64); }
+            if (lane == 0) { counters[8 + 2 * v] = va; counters[9 + 2 * v] = vb; }
         }
     }
     uint32_t maxc = 0;
@@ -124,7 +135,11 @@ gsr_scatter(int N, const EmitRec* __restrict__ emit, const uint32_t* __restrict_
     // The scratch may have been sized BEFORE the host knew M (gsr_forward: previous call + 25 %). M is on the
     // device: every consumer of the lists leaves at once when they do not fit, and the host repeats the tail.
     if (counters[2] > (unsigned long long)capacity) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0) counters[6] = capacity;    // for a backward called without GsrStats
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) counters[6] = capacity;    // for a backward called without GsrStats
+    // blockIdx.y = view: its records and its tiles (tile_off holds positions in the one list array of all views)
+    emit += (size_t)blockIdx.y * (size_t)N;
+    tile_off += (size_t)blockIdx.y * nTiles;
+    cursor += (size_t)blockIdx.y * nTiles;
     if (hist_in_lds) {
         for (int t = threadIdx.x; t < nTiles; t += blockDim.x) hist[t] = 0;
         __syncthreads();

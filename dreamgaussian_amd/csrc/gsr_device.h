@@ -62,6 +62,21 @@ struct ViewConst {           // by-value kernel argument (scalar registers)
     const float* campos;
 };
 
+// Several cameras in one launch chain (gsr_forward_views / gsr_backward_views): the per-Gaussian kernels take the
+// cameras as a by-value table and pick theirs with blockIdx.y; the per-tile kernels run over views * tiles_per_view
+// tiles and find the view of a tile by division. One view = the same kernels with a table of one.
+#ifndef GSR_MAX_VIEWS
+#define GSR_MAX_VIEWS 16       // also in include/gsr.h
+#endif
+struct ViewTab { ViewConst v[GSR_MAX_VIEWS]; };
+struct ViewSplit {
+    int tiles_per_view;                  // gx * gy
+    int N;                               // Gaussians: stride (in records) of the per-view record / gradient arrays
+    unsigned long long img_stride;       // floats between two views' per-pixel scratch planes (final_T | n_contrib | totals)
+    uint32_t view_mask;                  // forward compositing: the views THIS launch renders (bit v); the rest belong to the other kernel
+    const float* bg[GSR_MAX_VIEWS];
+};
+
 // ---------------------------------------------------------------------------------------
 // wave-level helpers (DPP; gfx9 encodings)
 // ---------------------------------------------------------------------------------------

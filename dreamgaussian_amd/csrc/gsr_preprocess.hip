@@ -168,17 +168,18 @@ __device__ __forceinline__ void stage_rows_in_split(const float* __restrict__ dc
     }
 }
 __device__ __forceinline__ void stage_rows_out_split(float* __restrict__ dc, float* __restrict__ rest, const float* lds,
-                                                     int cnt, int rowlen) {
+                                                     int cnt, int rowlen, int accumulate) {
     const int pitch = rowlen + 1, restlen = rowlen - 3;
     for (int e = threadIdx.x; e < cnt * rowlen; e += blockDim.x) {
         const int row = e / rowlen, col = e - row * rowlen;
         const float v = lds[row * pitch + col];
-        if (col < 3) dc[row * 3 + col] = v; else rest[(size_t)row * restlen + (col - 3)] = v;
+        float* o = col < 3 ? dc + (row * 3 + col) : rest + ((size_t)row * restlen + (col - 3));
+        *o = accumulate ? *o + v : v;
     }
 }
 
 __device__ __forceinline__ void stage_rows_out(float* __restrict__ dst, const float* lds,
-                                               int cnt, int rowlen) {
+                                               int cnt, int rowlen, int accumulate) {
     const int total = cnt * rowlen;
     const int pitch = rowlen + 1;
     if ((rowlen & 3) == 0) {
@@ -186,12 +187,15 @@ __device__ __forceinline__ void stage_rows_out(float* __restrict__ dst, const fl
         for (int i = threadIdx.x; i < total / 4; i += blockDim.x) {
             const int e = 4 * i, row = e / rowlen, col = e - row * rowlen;
             const float* s = lds + row * pitch + col;
-            d4[i] = make_float4(s[0], s[1], s[2], s[3]);
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (accumulate) o = d4[i];
+            d4[i] = accumulate ? make_float4(o.x + s[0], o.y + s[1], o.z + s[2], o.w + s[3]) : make_float4(s[0], s[1], s[2], s[3]);
         }
     } else {
         for (int e = threadIdx.x; e < total; e += blockDim.x) {
             const int row = e / rowlen, col = e - row * rowlen;
-            dst[e] = lds[row * pitch + col];
+            const float v = lds[row * pitch + col];
+            dst[e] = accumulate ? dst[e] + v : v;
         }
     }
 }
@@ -219,7 +223,7 @@ typedef gsr_f3 gsr_f3u __attribute__((aligned(4)));
 
 template <bool RAW>      // RAW: the inputs are DreamGaussian's raw parameters, activations fused (ViewConst.raw_act)
 __global__ void __launch_bounds__(256, 4)
-gsr_preprocess_fwd(ViewConst vc, int N, int K,
+gsr_preprocess_fwd(ViewTab views /* camera of this workgroup: views.v[blockIdx.y] */, int N, int K,
                    const float* __restrict__ means3D, const float* __restrict__ shs,
                    const float* __restrict__ shs_rest /* NULL: shs is [N,K,3]; else shs is [N,1,3] and this [N,K-1,3] */,
                    const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
@@ -231,7 +235,14 @@ gsr_preprocess_fwd(ViewConst vc, int N, int K,
                    int hist_in_lds,
                    uint8_t* __restrict__ flags8 /* colour-clamp bits for K6: 1 B instead of a 64-B record line */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_pp[];
+    const ViewConst vc = views.v[blockIdx.y];
     const int nTiles = vc.gx * vc.gy;
+    {   // per-view outputs: [views][N] records / radii / flags, [views][nTiles] counts, [views][grid][3] statistics
+        const size_t vo = (size_t)blockIdx.y * (size_t)N;
+        recs += vo; emit += vo; radii += vo; flags8 += vo;
+        tile_count += (size_t)blockIdx.y * nTiles;
+        block_stats += (size_t)blockIdx.y * gridDim.x * 3;
+    }
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem_pp);
     float* basis = reinterpret_cast<float*>(smem_pp + (hist_in_lds ? ((nTiles * 4 + 15) & ~15) : 0));
     float4* colour = reinterpret_cast<float4*>(basis + 256 * GSR_K1_BPITCH);
@@ -499,7 +510,9 @@ gsr_preprocess_bwd(ViewConst vc, int N, int K,
                    float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
                    float* __restrict__ dL_dshs, float* __restrict__ dL_dcolors,
                    float* __restrict__ dL_dopac, float* __restrict__ dL_dscales,
-                   float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D) {
+                   float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D,
+                   int accumulate /* add to the parameter gradients instead of overwriting (views after the first;
+                                     dL_dmeans2D is per view and always overwritten) */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_pp[];
     float* shbuf = reinterpret_cast<float*>(smem_pp);
     const int rowlen = 3 * K;
@@ -606,10 +619,11 @@ gsr_preprocess_bwd(ViewConst vc, int N, int K,
                 for (int k = 0; k < 16; ++k) {
                     if (k < K) {
                         const float bk = (k < nb) ? B[k] : 0.f;
-                        o[3 * k] = bk * gr; o[3 * k + 1] = bk * gg; o[3 * k + 2] = bk * gb;
+                        if (!stage && accumulate) { o[3 * k] += bk * gr; o[3 * k + 1] += bk * gg; o[3 * k + 2] += bk * gb; }   // K == 1: straight to HBM
+                        else { o[3 * k] = bk * gr; o[3 * k + 1] = bk * gg; o[3 * k + 2] = bk * gb; }
                     }
                 }
-                for (int e = 48; e < rowlen; ++e) o[e] = 0.f;   // K > 16: inactive coefficients
+                if (stage || !accumulate) for (int e = 48; e < rowlen; ++e) o[e] = 0.f;   // K > 16: inactive coefficients
             }
 
             // ---- conic -> cov2D -> (Sigma, t) -------------------------------------------
@@ -707,10 +721,21 @@ gsr_preprocess_bwd(ViewConst vc, int N, int K,
             for (int k = 0; k < 3; ++k) dm[k] += V[4 * k] * dtx + V[4 * k + 1] * dty + V[4 * k + 2] * dtz;
         } else if (idx < N && use_sh) {
             if (stage) { for (int e = 0; e < rowlen; ++e) myrow[e] = 0.f; }
-            else { float* o = dL_dshs + (size_t)idx * rowlen; for (int e = 0; e < rowlen; ++e) o[e] = 0.f; }
+            else if (!accumulate) { float* o = dL_dshs + (size_t)idx * rowlen; for (int e = 0; e < rowlen; ++e) o[e] = 0.f; }
         }
 
         if (idx < N) {
+            if (accumulate) {   // old + new, the order autograd's AccumulateGrad adds a later view's gradient in
+                dm[0] = dL_dmeans3D[3 * idx] + dm[0]; dm[1] = dL_dmeans3D[3 * idx + 1] + dm[1]; dm[2] = dL_dmeans3D[3 * idx + 2] + dm[2];
+                dop = dL_dopac[idx] + dop;
+                if (dL_dcolors) { dcol[0] = dL_dcolors[3 * idx] + dcol[0]; dcol[1] = dL_dcolors[3 * idx + 1] + dcol[1]; dcol[2] = dL_dcolors[3 * idx + 2] + dcol[2]; }
+                if (dL_dcov3D) {
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) dcov[e] = dL_dcov3D[6 * (size_t)idx + e] + dcov[e];
+                }
+                if (dL_dscales) { dsc[0] = dL_dscales[3 * idx] + dsc[0]; dsc[1] = dL_dscales[3 * idx + 1] + dsc[1]; dsc[2] = dL_dscales[3 * idx + 2] + dsc[2]; }
+                if (dL_drots) { const float4 o = reinterpret_cast<const float4*>(dL_drots)[idx]; dq[0] = o.x + dq[0]; dq[1] = o.y + dq[1]; dq[2] = o.z + dq[2]; dq[3] = o.w + dq[3]; }
+            }
             dL_dmeans3D[3 * idx] = dm[0]; dL_dmeans3D[3 * idx + 1] = dm[1]; dL_dmeans3D[3 * idx + 2] = dm[2];
             dL_dmeans2D[3 * idx] = dm2[0]; dL_dmeans2D[3 * idx + 1] = dm2[1]; dL_dmeans2D[3 * idx + 2] = 0.f;
             dL_dopac[idx] = dop;
@@ -724,14 +749,14 @@ gsr_preprocess_bwd(ViewConst vc, int N, int K,
         }
         if (stage) {
             __syncthreads();
-            if (shs_rest) stage_rows_out_split(dL_dshs + (size_t)base * 3, dL_dshs_rest + (size_t)base * (rowlen - 3), shbuf, cnt, rowlen);
-            else stage_rows_out(dL_dshs + (size_t)base * rowlen, shbuf, cnt, rowlen);
+            if (shs_rest) stage_rows_out_split(dL_dshs + (size_t)base * 3, dL_dshs_rest + (size_t)base * (rowlen - 3), shbuf, cnt, rowlen, accumulate);
+            else stage_rows_out(dL_dshs + (size_t)base * rowlen, shbuf, cnt, rowlen, accumulate);
         }
     }
 }
 
-template __global__ void gsr_preprocess_bwd<false>(ViewConst, int, int, const float*, const float*, const float*, float*, const float*, const float*, const float*, const float*, const float*, const int32_t*, const uint8_t*, const float*, float*, float*, float*, float*, float*, float*, float*, float*);
-template __global__ void gsr_preprocess_bwd<true>(ViewConst, int, int, const float*, const float*, const float*, float*, const float*, const float*, const float*, const float*, const float*, const int32_t*, const uint8_t*, const float*, float*, float*, float*, float*, float*, float*, float*, float*);
+template __global__ void gsr_preprocess_bwd<false>(ViewConst, int, int, const float*, const float*, const float*, float*, const float*, const float*, const float*, const float*, const float*, const int32_t*, const uint8_t*, const float*, float*, float*, float*, float*, float*, float*, float*, float*, int);
+template __global__ void gsr_preprocess_bwd<true>(ViewConst, int, int, const float*, const float*, const float*, float*, const float*, const float*, const float*, const float*, const float*, const int32_t*, const uint8_t*, const float*, float*, float*, float*, float*, float*, float*, float*, float*, int);
 
 // visible[i] = view-space z > 0.2  (frustum rule of A.3)
 extern "C" __global__ void __launch_bounds__(256)

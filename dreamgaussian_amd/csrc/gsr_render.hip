@@ -33,17 +33,27 @@ __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcp
 __global__ void __launch_bounds__(256)
 gsr_render_fwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict__ recs,
                const uint32_t* __restrict__ ids,
-               const float* __restrict__ bg, int W, int H, int gx,
+               int W, int H, int gx,
                float* __restrict__ out_color, float* __restrict__ out_depth,
                float* __restrict__ out_alpha, float* __restrict__ final_T,
                uint32_t* __restrict__ n_contrib, float* __restrict__ totals /*[5][H*W]*/,
                float* __restrict__ ckpt, const uint32_t* __restrict__ tile_seg,
                const uint32_t* __restrict__ tile_order /* heaviest tile first, or NULL */,
                int seg_shift, uint32_t* __restrict__ tile_last /* max list position blended in the tile */,
-               const unsigned long long* __restrict__ counters, uint32_t capacity) {
+               const unsigned long long* __restrict__ counters, uint32_t capacity, ViewSplit vs) {
     if (counters[2] > (unsigned long long)capacity) return;   // lists do not fit the scratch: the host repeats the tail (gsr_scatter)
     __shared__ float4 stage[4][3][GSR_RB + 2];             // 12.4 KiB: [wave][field group][slot (+2 pad)]
-    const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;
+    const int tg = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;     // tile among all views' tiles
+    const int view = tg / vs.tiles_per_view;
+    if (!((vs.view_mask >> view) & 1u)) return;           // this view composites with the other forward kernel
+    const int tile = tg - view * vs.tiles_per_view;
+    const float* __restrict__ bg = vs.bg[view];
+    {
+        const size_t HWv = (size_t)W * H;
+        recs += (size_t)view * vs.N;
+        out_color += view * 3 * HWv; out_depth += view * HWv; out_alpha += view * HWv;
+        final_T += view * vs.img_stride; n_contrib += view * vs.img_stride; totals += view * vs.img_stride;
+    }
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int bx = (tile % gx) * GSR_TILE + (wave & 1) * 8;
@@ -52,7 +62,7 @@ gsr_render_fwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict
     const int px = bx + (lane & 7), py = by + (lane >> 3);
     const bool inside = (px < W) && (py < H);
     const float pxf = (float)px, pyf = (float)py;
-    const uint32_t start = tile_off[tile], end = tile_off[tile + 1];
+    const uint32_t start = tile_off[tg], end = tile_off[tg + 1];
     float4* __restrict__ sa = stage[wave][0];
     float4* __restrict__ sb = stage[wave][1];
     float4* __restrict__ sc = stage[wave][2];
@@ -79,7 +89,7 @@ gsr_render_fwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict
         done = done || stop;                                                                   \
     }
 
-    const uint32_t seg_slot0 = tile_seg[tile];
+    const uint32_t seg_slot0 = tile_seg[tg];
     // padding slots are read (never used): keep them finite so that 0 * garbage stays 0
     for (int q = lane; q < 3 * (GSR_RB + 2); q += 64) (&stage[wave][0][0])[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     wave_lds_handoff();
@@ -145,7 +155,7 @@ gsr_render_fwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict
 #undef GSR_FWD_ENTRY
     {   // how deep the backward has to walk this tile's list
         const uint32_t wl = wave_max_u32(last);
-        if (lane == 0 && wl != 0u) atomicMax(&tile_last[tile], wl);
+        if (lane == 0 && wl != 0u) atomicMax(&tile_last[tg], wl);
     }
     if (inside) {
         const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
@@ -170,18 +180,28 @@ gsr_render_fwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict
 __global__ void __launch_bounds__(256)
 gsr_render_fwd_q(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict__ recs,
                  const uint32_t* __restrict__ ids,
-                 const float* __restrict__ bg, int W, int H, int gx,
+                 int W, int H, int gx,
                  float* __restrict__ out_color, float* __restrict__ out_depth,
                  float* __restrict__ out_alpha, float* __restrict__ final_T,
                  uint32_t* __restrict__ n_contrib, float* __restrict__ totals /*[5][H*W]*/,
                  float* __restrict__ ckpt, const uint32_t* __restrict__ tile_seg,
                  const uint32_t* __restrict__ tile_order /* heaviest tile first, or NULL */,
                  int seg_shift, uint32_t* __restrict__ tile_last /* max list position blended in the tile */,
-               const unsigned long long* __restrict__ counters, uint32_t capacity) {
+               const unsigned long long* __restrict__ counters, uint32_t capacity, ViewSplit vs) {
     if (counters[2] > (unsigned long long)capacity) return;   // lists do not fit the scratch: the host repeats the tail (gsr_scatter)
     __shared__ float4 stage[4][3][GSR_RB];                                   // slot = fetching lane
     __shared__ __attribute__((aligned(8))) uint8_t qlist[4][4][80];          // [wave][quad][k] = staged slot of the quad's k-th entry
-    const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;
+    const int tg = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;     // tile among all views' tiles
+    const int view = tg / vs.tiles_per_view;
+    if (!((vs.view_mask >> view) & 1u)) return;           // this view composites with the other forward kernel
+    const int tile = tg - view * vs.tiles_per_view;
+    const float* __restrict__ bg = vs.bg[view];
+    {
+        const size_t HWv = (size_t)W * H;
+        recs += (size_t)view * vs.N;
+        out_color += view * 3 * HWv; out_depth += view * HWv; out_alpha += view * HWv;
+        final_T += view * vs.img_stride; n_contrib += view * vs.img_stride; totals += view * vs.img_stride;
+    }
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int row = lane >> 4, l15 = lane & 15;
@@ -193,7 +213,7 @@ gsr_render_fwd_q(const uint32_t* __restrict__ tile_off, const SplatRec* __restri
     const bool inside = (px < W) && (py < H);
     const float pxf = (float)px, pyf = (float)py;
     const int cidx = wave * 64 + ly * 8 + lx;             // checkpoint slot (row-major 8x8: the backward's layout)
-    const uint32_t start = tile_off[tile], end = tile_off[tile + 1];
+    const uint32_t start = tile_off[tg], end = tile_off[tg + 1];
     float4* __restrict__ sa = stage[wave][0];
     float4* __restrict__ sb = stage[wave][1];
     float4* __restrict__ sc = stage[wave][2];
@@ -225,7 +245,7 @@ gsr_render_fwd_q(const uint32_t* __restrict__ tile_off, const SplatRec* __restri
         done = done || stop;                                                                   \
     }
 
-    const uint32_t seg_slot0 = tile_seg[tile];
+    const uint32_t seg_slot0 = tile_seg[tg];
     // three-deep fetch pipeline as gsr_render_fwd
     float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra, na = ra, nb = ra, nc = ra;
     uint32_t id_next = 0;
@@ -304,7 +324,7 @@ gsr_render_fwd_q(const uint32_t* __restrict__ tile_off, const SplatRec* __restri
 #undef GSR_FWDQ_ENTRY
     {   // how deep the backward has to walk this tile's list
         const uint32_t wl = wave_max_u32(last);
-        if (lane == 0 && wl != 0u) atomicMax(&tile_last[tile], wl);
+        if (lane == 0 && wl != 0u) atomicMax(&tile_last[tg], wl);
     }
     if (inside) {
         const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
@@ -342,13 +362,14 @@ gsr_render_fwd_q(const uint32_t* __restrict__ tile_off, const SplatRec* __restri
 // =========================================================================================
 #define GSR_BWD_PARAMS                                                                            \
     const uint32_t* __restrict__ tile_off, const SplatRec* __restrict__ recs,                     \
-    const uint32_t* __restrict__ ids, const float* __restrict__ bg, int W, int H, int gx,         \
+    const uint32_t* __restrict__ ids, int W, int H, int gx,                                       \
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,                    \
     const float* __restrict__ totals, const float* __restrict__ ckpt,                             \
     const uint32_t* __restrict__ tile_seg, const float* __restrict__ dL_dcolor,                   \
     const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha,                     \
     float* __restrict__ g2d, int seg_shift, const uint32_t* __restrict__ plan_tile,               \
-    const uint32_t* __restrict__ plan_off, const unsigned long long* __restrict__ plan_total
+    const uint32_t* __restrict__ plan_off, const unsigned long long* __restrict__ plan_total,     \
+    ViewSplit vs
 
 // -----------------------------------------------------------------------------------------
 // K5b: quad lists + two passes + fixed-point accumulation.
@@ -424,10 +445,20 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
     __shared__ uint32_t gmax_bits;                                           // max over the tile of gsum (bits of a non-negative float)
     extern __shared__ __attribute__((aligned(16))) unsigned long long acc64[];   // [(1 << seg_shift) * GSR_Q2_ROW]
     if (blockIdx.x >= (uint32_t)plan_total[0]) return;
-    const int tile = (int)plan_tile[blockIdx.x];
-    const uint32_t seg = blockIdx.x - plan_off[tile];
-    const uint32_t start = tile_off[tile];
-    const uint32_t n = tile_off[tile + 1] - start;
+    const int tg = (int)plan_tile[blockIdx.x];            // tile among all views' tiles
+    const uint32_t seg = blockIdx.x - plan_off[tg];
+    const uint32_t start = tile_off[tg];
+    const uint32_t n = tile_off[tg + 1] - start;
+    const int view = tg / vs.tiles_per_view;
+    const int tile = tg - view * vs.tiles_per_view;
+    const float* __restrict__ bg = vs.bg[view];
+    {
+        const size_t HWv = (size_t)W * H;
+        recs += (size_t)view * vs.N;
+        g2d += (size_t)view * vs.N * GSR_G2D_STRIDE;
+        dL_dcolor += view * 3 * HWv; dL_ddepth += view * HWv; dL_dalpha += view * HWv;
+        final_T += view * vs.img_stride; n_contrib += view * vs.img_stride; totals += view * vs.img_stride;
+    }
     const uint32_t seg_lo = seg << seg_shift;
     if (seg_lo >= n) return;                              // (block-uniform)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -495,7 +526,7 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
 
     float T = 1.f, Cgf = 0.f;
     if (seg > 0) {
-        const float* c = ckpt + (size_t)(tile_seg[tile] + seg - 1u) * GSR_CKPT_FLOATS + cidx;
+        const float* c = ckpt + (size_t)(tile_seg[tg] + seg - 1u) * GSR_CKPT_FLOATS + cidx;
         T = c[0];
         Cgf = c[256] * gC0 + c[512] * gC1 + c[768] * gC2 + c[1024] * gD + c[1280] * gA;
     }

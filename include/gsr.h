@@ -12,7 +12,9 @@
  * Reference interfaces each entry point replaces (file:line in /root/reference):
  *   gsr_forward       <- GaussianRasterizer(raster_settings)(means3D, means2D, shs, ...)
  *                        gs_renderer.py:760,800-809  (ext: _C.rasterize_gaussians)
- *   gsr_forward_begin / _finish <- the serial per-view render loop main.py:219-255 (several views in flight)
+ *   gsr_forward_views / gsr_backward_views <- the serial per-view render loop main.py:219-255 (B cameras, one launch chain)
+ *   gsr_forward_begin / _finish <- the same loop, one stream per view (superseded by gsr_forward_views; kept for callers
+ *                        that must overlap views of DIFFERENT sizes)
  *   gsr_backward      <- loss.backward() through that call, main.py:273
  *                        (ext: _C.rasterize_gaussians_backward)
  *   gsr_mark_visible  <- GaussianRasterizer.markVisible (ext: _C.mark_visible; never called
@@ -141,6 +143,36 @@ int gsr_backward(const GsrView* view, int32_t N, int32_t K,
                  float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs, float* dL_dcolors,
                  float* dL_dopacities, float* dL_dscales, float* dL_drotations,
                  float* dL_dcov3D, GsrAlloc tmp, gsr_stream_t stream);
+
+/* B cameras of the same Gaussians in ONE launch chain (replaces the serial per-view render loop main.py:219-255,
+ * `for _ in range(batch_size): out = renderer.render(cam)`): every kernel of gsr_forward / gsr_backward is launched
+ * once over the B views (per-Gaussian kernels: grid.y = view; per-tile kernels: B * tiles tiles, heaviest first across
+ * views), one host round trip for the whole batch, one list array. `views` [host] = B structs, 1 <= B <= GSR_MAX_VIEWS,
+ * which must agree in image size, sh_degree, raw_activations and shs_rest / dL_dshs_rest (cameras, tan-fov, bg and
+ * scale_modifier may differ).
+ *   out_color [B,3,H,W]  out_depth [B,H,W]  out_alpha [B,H,W]  radii [B,N]       (contiguous, view-major)
+ *   dL_dcolor [B,3,H,W]  dL_ddepth [B,H,W]  dL_dalpha [B,H,W]  dL_dmeans2D [B,N,3]
+ *   dL_dmeans3D, dL_dshs, ... [N,...]: the SUM over the views, accumulated in the order autograd adds the gradients
+ *   of B separate calls (last view first), without a [B,N,...] intermediate
+ *   stats: totals over the B views. Images and per-view outputs are bit-identical to B gsr_forward calls. */
+#define GSR_MAX_VIEWS 16
+int gsr_forward_views(const GsrView* views, int32_t B, int32_t N, int32_t K,
+                      const float* means3D, const float* shs, const float* colors_precomp,
+                      const float* opacities, const float* scales, const float* rotations,
+                      const float* cov3D_precomp,
+                      float* out_color, float* out_depth, float* out_alpha, int32_t* radii,
+                      GsrAlloc geom, GsrAlloc bin, GsrAlloc img,
+                      GsrStats* stats, gsr_stream_t stream);
+int gsr_backward_views(const GsrView* views, int32_t B, int32_t N, int32_t K,
+                       const float* means3D, const float* shs, const float* colors_precomp,
+                       const float* opacities, const float* scales, const float* rotations,
+                       const float* cov3D_precomp, const int32_t* radii,
+                       const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
+                       const void* geom, const void* bin, const void* img,
+                       const GsrStats* fwd_stats,
+                       float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs, float* dL_dcolors,
+                       float* dL_dopacities, float* dL_dscales, float* dL_drotations,
+                       float* dL_dcov3D, GsrAlloc tmp, gsr_stream_t stream);
 
 /* Frustum test only: visible[i] = (view-space z of means3D[i] > 0.2). */
 int gsr_mark_visible(const GsrView* view, int32_t N, const float* means3D,

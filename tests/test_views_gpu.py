@@ -1,5 +1,6 @@
-"""rasterize_views (several cameras in flight on one GPU, two-phase C ABI) must equal B single-view
-calls: forward bit for bit, gradients of the shared Gaussians = sum over views."""
+"""rasterize_views (B cameras through one launch chain, gsr_forward_views / gsr_backward_views; mode="streams": one
+stream per view through the two-phase C ABI) must equal B single-view calls: forward bit for bit, gradients of the
+shared Gaussians = sum over views."""
 import pytest
 import torch
 
@@ -10,10 +11,11 @@ import dreamgaussian_amd as D
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("deg,N,size", [(0, 3000, 128), (3, 1500, 96)])
-def test_batched_views_equal_serial(gpu, deg, N, size):
+@pytest.mark.parametrize("mode", ["chain", "streams"])
+@pytest.mark.parametrize("deg,N,size,nviews", [(0, 3000, 128, 5), (3, 1500, 96, 5), (1, 800, 80, 19)])
+def test_batched_views_equal_serial(gpu, deg, N, size, nviews, mode):
     sc = O.make_scene(N, deg, 0, "trained")
-    azs = [0.0, 70.0, 160.0, -95.0, 33.0]
+    azs = [0.0, 70.0, 160.0, -95.0, 33.0] + [20.0 * i + 5 for i in range(nviews - 5)]   # 19 views: two chunks of the chain
     S = [settings_to(O.make_settings(O.orbit_pose(-10.0 + 7 * i, az, 2.0 + 0.1 * i), size, size, sh_degree=deg), gpu)
          for i, az in enumerate(azs)]
     B = len(S)
@@ -39,11 +41,15 @@ def test_batched_views_equal_serial(gpu, deg, N, size):
     t2 = leaves()
     m2b = torch.zeros(B, N, 3, device=gpu, requires_grad=True)
     color, radii, depth, alpha = D.rasterize_views(t2["means3D"], m2b, t2["opacities"], S, shs=t2["shs"],
-                                                   scales=t2["scales"], rotations=t2["rotations"])
+                                                   scales=t2["scales"], rotations=t2["rotations"], mode=mode)
     assert color.shape == (B, 3, size, size) and radii.shape == (B, N) and depth.shape == (B, 1, size, size)
+    bad = []
     for i in range(B):
-        assert torch.equal(color[i], outs[i][0]) and torch.equal(radii[i], outs[i][1])
-        assert torch.equal(depth[i], outs[i][2]) and torch.equal(alpha[i], outs[i][3])
+        for name, got, want in (("color", color[i], outs[i][0]), ("radii", radii[i], outs[i][1]), ("depth", depth[i], outs[i][2]),
+                                ("alpha", alpha[i], outs[i][3])):
+            if not torch.equal(got, want):
+                bad.append((i, name, int((got != want).sum()), float((got.double() - want.double()).abs().max())))
+    assert not bad, f"views differing from their single-view render (view, output, elements, max |diff|): {bad}"
     lossb = sum((w[i][0] * color[i]).sum() + (w[i][1] * depth[i]).sum() + (w[i][2] * alpha[i]).sum() for i in range(B))
     lossb.backward()
     for k in ref:
@@ -52,6 +58,42 @@ def test_batched_views_equal_serial(gpu, deg, N, size):
     for i in range(B):
         scale = m2[i].grad.abs().max().item() + 1e-12
         assert (m2b.grad[i] - m2[i].grad).abs().max().item() <= 2e-5 * scale
+
+
+def test_views_chain_precomputed_colours_and_covariances(gpu):
+    """The accumulate-into-one-gradient path of the per-Gaussian backward for the other input forms: precomputed
+    colours + 3D covariances, and degree-0 SH with K == 1 (rows written straight to HBM, not through LDS)."""
+    N, size, B = 1200, 96, 4
+    sc = O.make_scene(N, 0, 0, "trained")
+    S = [settings_to(O.make_settings(O.orbit_pose(-5.0 + 6 * i, 80.0 * i, 2.1), size, size, sh_degree=0), gpu) for i in range(B)]
+    w = [[x.to(gpu) for x in weights_for(size, size, seed=30 + i)] for i in range(B)]
+    S33 = O.covariance3d(sc["scales"], 1.0, sc["rotations"])
+    cov = torch.stack([S33[:, 0, 0], S33[:, 0, 1], S33[:, 0, 2], S33[:, 1, 1], S33[:, 1, 2], S33[:, 2, 2]], 1).contiguous()
+    variants = [dict(shs=sc["shs"][:, :1].contiguous(), scales=sc["scales"], rotations=sc["rotations"]),
+                dict(colors_precomp=torch.rand(N, 3, generator=torch.Generator().manual_seed(3)), cov3D_precomp=cov)]
+    for kw in variants:
+        def leaves():
+            d = {k: v.to(gpu).requires_grad_(True) for k, v in kw.items()}
+            d["means3D"] = sc["means3D"].to(gpu).requires_grad_(True)
+            d["opacities"] = sc["opacities"].to(gpu).requires_grad_(True)
+            return d
+        t = leaves()
+        outs = []
+        for i in range(B):
+            args = dict(shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None)
+            args.update({k: t[k] for k in kw})
+            outs.append(D.GaussianRasterizer(raster_settings=S[i])(means3D=t["means3D"], means2D=torch.zeros(N, 3, device=gpu, requires_grad=True),
+                                                                   opacities=t["opacities"], **args))
+        sum((w[i][0] * outs[i][0]).sum() + (w[i][1] * outs[i][2]).sum() + (w[i][2] * outs[i][3]).sum() for i in range(B)).backward()
+        t2 = leaves()
+        color, radii, depth, alpha = D.rasterize_views(t2["means3D"], torch.zeros(B, N, 3, device=gpu, requires_grad=True), t2["opacities"], S,
+                                                       **{k: t2[k] for k in kw})
+        for i in range(B):
+            assert torch.equal(color[i], outs[i][0]) and torch.equal(radii[i], outs[i][1]) and torch.equal(alpha[i], outs[i][3])
+        sum((w[i][0] * color[i]).sum() + (w[i][1] * depth[i]).sum() + (w[i][2] * alpha[i]).sum() for i in range(B)).backward()
+        for k in t:
+            scale = t[k].grad.abs().max().item() + 1e-12
+            assert (t2[k].grad - t[k].grad).abs().max().item() <= 2e-5 * scale, (sorted(kw), k)
 
 
 def test_batched_views_argument_errors(gpu):

@@ -6,6 +6,13 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 benchline() { python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], 'Mrays/s', d['ms_per_step'], 'ms', d['kernels_ms_per_step'])"; }
 for s in "$@"; do case $s in
+quick)
+  echo "== pytest quick (views, optim, parity without the big fp64 cases)"
+  timeout 900 python -m pytest tests/test_views_gpu.py tests/test_optim_gpu.py tests/test_parity_gpu.py tests/test_fuzz_gpu.py -m gpu -q -p no:cacheprovider --tb=short -rf -k "not baseline_config" > gpurun_out/pytest_quick.log 2>&1
+  grep -a "passed\|failed\|FAILED\|Error\|assert" gpurun_out/pytest_quick.log | tail -30;;
+viewstest)
+  timeout 600 python -m pytest tests/test_views_gpu.py -m gpu -q -p no:cacheprovider --tb=short -rf > gpurun_out/pytest_views.log 2>&1
+  grep -a "passed\|failed\|FAILED\|Error\|assert\|differing" gpurun_out/pytest_views.log | cut -c1-600 | tail -20;;
 tests)
   echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -m gpu -q -s -p no:cacheprovider --tb=short -rf > gpurun_out/pytest_gpu.log 2>&1
   grep -a "fragile:\|passed\|failed\|FAILED\|Error" gpurun_out/pytest_gpu.log | tail -30;;
@@ -44,8 +51,8 @@ stage1)
   echo "== stage-1 (BASELINE configs[4]) through libgsr.so"
   timeout 1200 python tools/run_stage1.py --out gpurun_out/stage1.json $STAGE1_ARGS 2>&1 | tail -25;;
 views)
-  for m in "--views 8 --views-serial" "--views 8"; do
-    timeout 300 python bench.py --workload 250k-512-sh0 --cpu-budget 0 $m 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['config']['views_mode'], d['value'], 'Mrays/s', d['ms_per_step'], 'ms per 8 views')"
+  for m in "--views 8 --views-serial" "--views 8 --views-mode streams" "--views 8"; do
+    timeout 300 python bench.py --workload 250k-512-sh0 --cpu-budget 0 $m 2>gpurun_out/views_err.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['config']['views_mode'], d['value'], 'Mrays/s', d['ms_per_step'], 'ms per 8 views')"
     timeout 300 python bench.py --workload 5k-256-sh0 --cpu-budget 0 $m 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('5k', d['config']['views_mode'], d['value'], 'Mrays/s', d['ms_per_step'], 'ms per 8 views')"
   done;;
 pmcv)
