@@ -23,6 +23,12 @@
 namespace {
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// The exponent of a splat at a pixel (log2 units), with ONE fixed sequence of roundings: the two forward kernels and
+// the backward must agree bit for bit on it (the backward re-derives which (pixel, Gaussian) pairs blended from
+// `power <= 0 && alpha >= 1/255`), and hipcc's -ffp-contract=fast would otherwise fuse the sum differently per kernel.
+__device__ __forceinline__ float splat_power(float qa, float qb, float qc, float dx, float dy) {
+    return fmaf(__fmul_rn(qa, dx), dx, fmaf(__fmul_rn(qc, dy), dy, __fmul_rn(__fmul_rn(qb, dx), dy)));
+}
 }
 
 #define GSR_RB 64   // list entries fetched per wave per round
@@ -75,15 +81,15 @@ gsr_render_fwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict
 #define GSR_FWD_ENTRY(ea, eb, ec, valid)                                                       \
     {                                                                                          \
         const float dx = ea.x - pxf, dy = ea.y - pyf;                                          \
-        const float power = ea.z * dx * dx + eb.x * dy * dy + ea.w * dx * dy; /* log2 units */ \
+        const float power = splat_power(ea.z, ea.w, eb.x, dx, dy);            /* log2 units */ \
         const float alpha = fminf(0.99f, eb.y * fast_exp2(power));                             \
         const bool ok = (valid) && !done && (power <= 0.f) && (alpha >= (1.0f / 255.0f));      \
         const float test_T = T * (1.f - alpha);                                                \
         const bool stop = ok && (test_T < 0.0001f);                                            \
         const bool acc = ok && !stop;                                                          \
         const float w = acc ? alpha * T : 0.f;                                                 \
-        C0 += eb.z * w; C1 += eb.w * w; C2 += ec.x * w;                                        \
-        D += ec.y * w; A += w;                                                                 \
+        C0 = fmaf(eb.z, w, C0); C1 = fmaf(eb.w, w, C1); C2 = fmaf(ec.x, w, C2);                \
+        D = fmaf(ec.y, w, D); A += w;                                                          \
         T = acc ? test_T : T;                                                                  \
         last = acc ? __float_as_uint(ec.z) : last;                                             \
         done = done || stop;                                                                   \
@@ -161,9 +167,9 @@ gsr_render_fwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict
         const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
         final_T[pix] = T;
         n_contrib[pix] = last;
-        out_color[pix] = C0 + T * bg[0];
-        out_color[HW + pix] = C1 + T * bg[1];
-        out_color[2 * HW + pix] = C2 + T * bg[2];
+        out_color[pix] = fmaf(T, bg[0], C0);
+        out_color[HW + pix] = fmaf(T, bg[1], C1);
+        out_color[2 * HW + pix] = fmaf(T, bg[2], C2);
         out_depth[pix] = D;
         out_alpha[pix] = A;
         totals[pix] = C0; totals[HW + pix] = C1; totals[2 * HW + pix] = C2;   // sums without background
@@ -175,7 +181,8 @@ gsr_render_fwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict
 // K5 with quad lists (GSR_FWD=q): the forward counterpart of gsr_render_bwd_q2's pass 1. Every 16-lane row of a
 // wave owns a 4x4 pixel quad with its own list of staged slots (exact ellipse-vs-quad tests, quad_max_powers);
 // the wave loops to the longest of the four lists, and a quad whose sixteen pixels have all stopped drops out.
-// Same arithmetic per (pixel, Gaussian) as gsr_render_fwd: bit-identical images.
+// Same arithmetic per (pixel, Gaussian) as gsr_render_fwd, every rounding pinned (splat_power, explicit fmaf):
+// bit-identical images (tools/fwd_variant_hash.py).
 // -----------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 gsr_render_fwd_q(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict__ recs,
@@ -231,15 +238,15 @@ gsr_render_fwd_q(const uint32_t* __restrict__ tile_off, const SplatRec* __restri
 #define GSR_FWDQ_ENTRY(ea, eb, ec, kpos, valid)                                                \
     {                                                                                          \
         const float dx = ea.x - pxf, dy = ea.y - pyf;                                          \
-        const float power = ea.z * dx * dx + eb.x * dy * dy + ea.w * dx * dy; /* log2 units */ \
+        const float power = splat_power(ea.z, ea.w, eb.x, dx, dy);            /* log2 units */ \
         const float alpha = fminf(0.99f, eb.y * fast_exp2(power));                             \
         const bool ok = (valid) && !done && (power <= 0.f) && (alpha >= (1.0f / 255.0f));      \
         const float test_T = T * (1.f - alpha);                                                \
         const bool stop = ok && (test_T < 0.0001f);                                            \
         const bool acc = ok && !stop;                                                          \
         const float w = acc ? alpha * T : 0.f;                                                 \
-        C0 += eb.z * w; C1 += eb.w * w; C2 += ec.x * w;                                        \
-        D += ec.y * w; A += w;                                                                 \
+        C0 = fmaf(eb.z, w, C0); C1 = fmaf(eb.w, w, C1); C2 = fmaf(ec.x, w, C2);                \
+        D = fmaf(ec.y, w, D); A += w;                                                          \
         T = acc ? test_T : T;                                                                  \
         last = acc ? (kpos) : last;                                                            \
         done = done || stop;                                                                   \
@@ -330,9 +337,9 @@ gsr_render_fwd_q(const uint32_t* __restrict__ tile_off, const SplatRec* __restri
         const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
         final_T[pix] = T;
         n_contrib[pix] = last;
-        out_color[pix] = C0 + T * bg[0];
-        out_color[HW + pix] = C1 + T * bg[1];
-        out_color[2 * HW + pix] = C2 + T * bg[2];
+        out_color[pix] = fmaf(T, bg[0], C0);
+        out_color[HW + pix] = fmaf(T, bg[1], C1);
+        out_color[2 * HW + pix] = fmaf(T, bg[2], C2);
         out_depth[pix] = D;
         out_alpha[pix] = A;
         totals[pix] = C0; totals[HW + pix] = C1; totals[2 * HW + pix] = C2;   // sums without background
@@ -546,7 +553,7 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
 #define GSR_Q2_ENTRY(ea, eb, ec, kpos, valid, kslot)                                             \
     {                                                                                            \
         const float dx = ea.x - pxf, dy = ea.y - pyf;                                            \
-        const float power = ea.z * dx * dx + eb.x * dy * dy + ea.w * dx * dy;                    \
+        const float power = splat_power(ea.z, ea.w, eb.x, dx, dy);                               \
         const float G = fast_exp2(power);                                                        \
         const float alpha = fminf(0.99f, eb.y * G);                                              \
         const bool ok = (valid) && ((kpos) <= last_contrib) && (power <= 0.f) && (alpha >= (1.0f / 255.0f)); \
