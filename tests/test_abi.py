@@ -42,6 +42,16 @@ def test_c_argument_errors_without_gpu():
     rc = lib.gsr_forward(None, 0, 0, *([None] * 7), *([None] * 4), _lib.GsrAlloc(), _lib.GsrAlloc(),
                          _lib.GsrAlloc(), None, None)
     assert rc == -1 and b"view is NULL" in lib.gsr_last_error()
+    # B cameras in one chain: the view count and the agreement of the views are checked before anything touches the GPU
+    views = (_lib.GsrView * 2)()
+    for v, w in zip(views, (64, 96)):
+        v.image_height, v.image_width, v.tanfovx, v.tanfovy, v.scale_modifier = 64, w, 0.5, 0.5, 1.0
+        v.bg = v.viewmatrix = v.projmatrix = v.campos = 0x1000      # never dereferenced on this path
+    common = (0, 0, *([None] * 7), *([None] * 4), _lib.GsrAlloc(), _lib.GsrAlloc(), _lib.GsrAlloc(), None, None)
+    assert lib.gsr_forward_views(views, 0, *common) == -1 and b"number of views" in lib.gsr_last_error()
+    assert lib.gsr_forward_views(views, _lib.GSR_MAX_VIEWS + 1, *common) == -1 and b"number of views" in lib.gsr_last_error()
+    assert lib.gsr_forward_views(views, 2, *common) == -1 and b"must agree" in lib.gsr_last_error()
+    assert lib.gsr_forward_views(None, 1, *common) == -1 and b"view is NULL" in lib.gsr_last_error()
     assert lib.gsr_dist2(-1, None, None, _lib.GsrAlloc(), None) == -1
     assert lib.gsr_dist2(0, None, None, _lib.GsrAlloc(), None) == 0
     assert lib.gsr_profile_read(0, None, None, None) == 0

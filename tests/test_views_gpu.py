@@ -96,6 +96,16 @@ def test_views_chain_precomputed_colours_and_covariances(gpu):
             assert (t2[k].grad - t[k].grad).abs().max().item() <= 2e-5 * scale, (sorted(kw), k)
 
 
+def test_views_chain_without_gaussians_renders_the_backgrounds(gpu):
+    bgs = [(1.0, 1.0, 1.0), (0.0, 0.25, 0.5), (0.3, 0.0, 0.0)]
+    S = [settings_to(O.make_settings(O.orbit_pose(0, 40.0 * i, 2.0), 40, 24, bg=bg), gpu) for i, bg in enumerate(bgs)]
+    e = lambda *s: torch.zeros(*s, device=gpu)
+    color, radii, depth, alpha = D.rasterize_views(e(0, 3), e(3, 0, 3), e(0, 1), S, shs=e(0, 1, 3), scales=e(0, 3), rotations=e(0, 4))
+    assert radii.shape == (3, 0) and float(depth.abs().max()) == 0.0 and float(alpha.abs().max()) == 0.0
+    for i, bg in enumerate(bgs):
+        assert torch.equal(color[i], torch.tensor(bg, device=gpu).view(3, 1, 1).expand(3, 24, 40))
+
+
 def test_batched_views_argument_errors(gpu):
     sc = {k: v.to(gpu) for k, v in O.make_scene(50, 0, 0, "blob").items()}
     S = [settings_to(O.make_settings(O.orbit_pose(0, 0, 2.0), 32, 32), gpu),

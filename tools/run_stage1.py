@@ -103,7 +103,32 @@ def psnr_fixed_view(gui):
     return -10.0 * math.log10(max(mse, 1e-12))
 
 
-def run(ref, iters, input_path, profiled):
+def install_optin(gs_renderer):
+    """The opt-in replacements either side of the rasterizer, patched onto the reference's
+    GaussianModel from OUTSIDE (its files stay unmodified): FusedAdam for the Adam of `training_setup`
+    (gs_renderer.py:370), the fused densification statistics (gs_renderer.py:625-627) and the one-gather prune
+    (gs_renderer.py:479-511)."""
+    import dreamgaussian_amd as D
+    GM = gs_renderer.GaussianModel
+    orig_setup = GM.training_setup
+
+    def training_setup(self, training_args):
+        orig_setup(self, training_args)
+        self.optimizer = D.FusedAdam(self.optimizer.param_groups, lr=0.0, eps=1e-15)
+
+    def add_densification_stats(self, viewspace_point_tensor, update_filter):
+        # main.py:280 has already raised max_radii2D with the real radii (>= 1 where visible): max(., 1) changes nothing
+        D.add_densification_stats(viewspace_point_tensor.grad, update_filter.to(torch.int32), self.xyz_gradient_accum,
+                                  self.denom, self.max_radii2D)
+
+    def prune_points(self, mask):
+        D.prune_points(self, mask)
+    saved = (GM.training_setup, GM.add_densification_stats, GM.prune_points)
+    GM.training_setup, GM.add_densification_stats, GM.prune_points = training_setup, add_densification_stats, prune_points
+    return lambda: [setattr(GM, n, f) for n, f in zip(("training_setup", "add_densification_stats", "prune_points"), saved)]
+
+
+def run(ref, iters, input_path, profiled, optin=False):
     from dreamgaussian_amd import _lib
     for m in ("main", "gs_renderer", "sh_utils", "cam_utils", "grid_put"):
         sys.modules.pop(m, None)
@@ -111,6 +136,8 @@ def run(ref, iters, input_path, profiled):
     import gs_renderer
     import diff_gaussian_rasterization as dgr
     assert gs_renderer.GaussianRasterizer is dgr.GaussianRasterizer, "gs_renderer.py is not bound to this repository's package"
+    if optin:
+        install_optin(gs_renderer)                   # the module object is re-imported by every run(): nothing to undo
     np.random.seed(0); torch.manual_seed(0); torch.cuda.manual_seed(0)
     opt = make_opt(ref, iters, input_path)
     t_init0 = time.perf_counter()
@@ -162,6 +189,8 @@ def main():
     ap.add_argument("--iters", type=int, default=500)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "stage1.json"))
     ap.add_argument("--no-profiled-run", action="store_true")
+    ap.add_argument("--optin", action="store_true", help="one more run with FusedAdam, the fused densification statistics and the "
+                                                         "one-gather prune patched onto the reference's GaussianModel")
     a = ap.parse_args()
     ref = a.ref or next((d for d in (os.path.join(ROOT, "_ref_stage"), "/root/reference") if os.path.isdir(d)), None)
     if ref is None:
@@ -182,6 +211,10 @@ def main():
                          "plyfile -> dreamgaussian_amd.ply; save_model('geo+tex') skipped (mcubes/xatlas/nvdiffrast absent)",
            "device": torch.cuda.get_device_name(0), "torch": torch.__version__,
            "cold_run_wall_s": cold["wall_s"], "run": plain, "profiled_run": prof}
+    if a.optin:
+        out["optin_run"] = run(ref, a.iters, input_path, profiled=False, optin=True)
+        out["optin_run"]["what"] = ("same trainer, same seed; GaussianModel.training_setup -> dreamgaussian_amd.FusedAdam, "
+                                    "add_densification_stats -> the fused kernel, prune_points -> compact_mask + gather_rows")
     os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
     json.dump(out, open(a.out, "w"), indent=1)
     print(json.dumps(out, indent=1))
