@@ -62,9 +62,10 @@ class _RasterizeViewsStreams(torch.autograd.Function):
         m3, shc, col = _f32c(means3D, dev), _f32c(sh, dev), _f32c(colors_precomp, dev)
         op, sc, rot, cov = _f32c(opacities, dev), _f32c(scales, dev), _f32c(rotations, dev), _f32c(cov3Ds_precomp, dev)
         K = int(shc.shape[1]) if shc is not None else 0
-        if (shc is None) == (col is None):
+        if (sh is None) == (colors_precomp is None):
             raise Exception("Please provide excatly one of either SHs or precomputed colors!")
-        if ((sc is None or rot is None) and cov is None) or ((sc is not None or rot is not None) and cov is not None):
+        if ((scales is None or rotations is None) and cov3Ds_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3Ds_precomp is not None):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
 
         color = torch.empty(B, 3, H, W, dtype=torch.float32, device=dev)
@@ -191,9 +192,10 @@ class _RasterizeViews(torch.autograd.Function):
         m3, shc, col = _f32c(means3D, dev), _f32c(sh, dev), _f32c(colors_precomp, dev)
         op, sc, rot, cov = _f32c(opacities, dev), _f32c(scales, dev), _f32c(rotations, dev), _f32c(cov3Ds_precomp, dev)
         K = int(shc.shape[1]) if shc is not None else 0
-        if (shc is None) == (col is None):
+        if (sh is None) == (colors_precomp is None):
             raise Exception("Please provide excatly one of either SHs or precomputed colors!")
-        if ((sc is None or rot is None) and cov is None) or ((sc is not None or rot is not None) and cov is not None):
+        if ((scales is None or rotations is None) and cov3Ds_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3Ds_precomp is not None):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
         color = torch.empty(B, 3, H, W, dtype=torch.float32, device=dev)
         depth = torch.empty(B, 1, H, W, dtype=torch.float32, device=dev)

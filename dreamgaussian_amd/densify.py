@@ -73,19 +73,21 @@ def gather_rows(idx: torch.Tensor, tensors: Sequence[torch.Tensor]) -> List[torc
         return []
     dev = idx.device
     rows = int(idx.numel())
-    outs, srcs = [], []
+    outs, srcs, dsts = [], [], []
     for t in tensors:
         if t.device != dev or t.dtype is not torch.float32:
             raise RuntimeError("gather_rows takes float32 tensors on the index's device")
-        tc = t.detach().contiguous()
-        srcs.append(tc)
-        outs.append(torch.empty((rows,) + tuple(t.shape[1:]), dtype=torch.float32, device=dev))
-    if rows > 0:
+        o = torch.empty((rows,) + tuple(t.shape[1:]), dtype=torch.float32, device=dev)
+        outs.append(o)
+        if o.numel() > 0:                              # e.g. _features_rest is [N,0,3] at sh_degree 0: nothing to move
+            srcs.append(t.detach().contiguous())
+            dsts.append(o)
+    if srcs:
         lib = _lib.load()
         with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             for i0 in range(0, len(srcs), 24):
-                chunk = list(zip(srcs[i0:i0 + 24], outs[i0:i0 + 24]))
+                chunk = list(zip(srcs[i0:i0 + 24], dsts[i0:i0 + 24]))
                 arr = (_lib.GsrGatherTensor * len(chunk))()
                 for j, (a, b) in enumerate(chunk):
                     width = 1

@@ -99,3 +99,12 @@ def test_prune_points_equals_reference_algorithm(gpu):
     for p in (g["params"][0] for g in a.optimizer.param_groups):   # the optimiser keeps stepping on the new tensors
         p.grad = torch.ones_like(p)
     a.optimizer.step()
+
+
+def test_gather_rows_with_an_empty_feature_tensor(gpu):
+    """`_features_rest` is [N,0,3] at sh_degree 0 (configs/image.yaml): nothing to move, shape preserved."""
+    g = torch.Generator().manual_seed(5)
+    a, b = torch.rand(100, 3, generator=g).to(gpu), torch.zeros(100, 0, 3, device=gpu)
+    idx, count = D.compact_mask(torch.rand(100, generator=g).to(gpu) > 0.5)
+    oa, ob = D.gather_rows(idx, [a, b])
+    assert ob.shape == (count, 0, 3) and torch.equal(oa, a[idx.long()])

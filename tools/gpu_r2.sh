@@ -71,6 +71,10 @@ abq)
     echo "== variant [$v] bench 1M blob"; env $v timeout 300 python bench.py --cpu-budget 0 2>gpurun_out/ab_err.log | benchline
     echo "== variant [$v] bench 100k"; env $v timeout 300 python bench.py --cpu-budget 0 --workload 100k-800-sh3 2>>gpurun_out/ab_err.log | benchline
   done;;
+viewsprof)
+  echo "== rocprofv3 kernel trace, 8 views in one chain (250k / 512^2)"
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_views -o r02v -- python $R/bench.py --workload 250k-512-sh0 --views 8 --steps 5 --warmup 2 --cpu-budget 0 --no-roofline > $R/gpurun_out/prof_views.log 2>&1)
+  f=$(find gpurun_out/prof_views -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -16 "$f" | cut -c1-50,180-330;;
 sds)
   echo "== bench --gpus 2 on a 1-GPU box must fail loudly"; timeout 120 python bench.py --gpus 2 --steps 2 --warmup 1 2>&1 | tail -3
   echo "== bench --step sds (1 GPU)"; timeout 300 python bench.py --step sds --cpu-budget 0 2>&1 | tail -2;;
