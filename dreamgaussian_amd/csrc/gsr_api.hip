@@ -579,6 +579,8 @@ int backward_impl(const GsrView* views, int B, int32_t N, int32_t K,
         prof_begin(stream);
         hipLaunchKernelGGL(gsr_bwd_plan, dim3(1), dim3(1024), 0, stream, tile_last, TA, seg_shift(), (uint32_t)BL.plan_cap,
                            plan_off, plan_tile, plan_total);
+        hipLaunchKernelGGL(gsr_bwd_plan_fill, dim3((TA + 3) / 4), dim3(256), 0, stream, tile_last, TA, seg_shift(), (uint32_t)BL.plan_cap,
+                           plan_off, plan_tile);
         LAUNCH_CHECK(view, stream, "bwd_plan");
         prof_begin(stream);
         const unsigned grid = (unsigned)BL.plan_cap;

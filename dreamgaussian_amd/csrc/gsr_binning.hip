@@ -99,9 +99,13 @@ gsr_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ ti
     const float scale = maxc > 0 ? 255.0f / (float)maxc : 0.f;
     if (threadIdx.x < 256) cls_cnt[threadIdx.x] = 0;
     __syncthreads();
-    for (int t = threadIdx.x; t < T; t += 1024) {
-        const uint32_t c = 255u - min(255u, (uint32_t)((float)tile_count[t] * scale));   // class 0 = heaviest
-        atomicAdd(&cls_cnt[c], 1u);
+    // empty tiles (two thirds of a 512^2 view) all fall into class 255: one atomic per wave for them, not one per tile
+    for (int t0 = 0; t0 < T; t0 += 1024) {
+        const int t = t0 + (int)threadIdx.x;
+        const uint32_t n = t < T ? tile_count[t] : 0u;
+        const unsigned long long em = __ballot(t < T && n == 0u);
+        if (t < T && n != 0u) atomicAdd(&cls_cnt[255u - min(255u, (uint32_t)((float)n * scale))], 1u);   // class 0 = heaviest
+        if (em != 0ull && lane == __builtin_ctzll(em)) atomicAdd(&cls_cnt[255], (uint32_t)__popcll(em));
     }
     __syncthreads();
     if (threadIdx.x < 64) {                               // exclusive scan of 256 counters by one wave
@@ -116,9 +120,19 @@ gsr_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ ti
         for (int q = 0; q < 4; ++q) { cls_off[threadIdx.x * 4 + q] = run2; run2 += v[q]; }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < T; t += 1024) {
-        const uint32_t c = 255u - min(255u, (uint32_t)((float)tile_count[t] * scale));
-        order[atomicAdd(&cls_off[c], 1u)] = (uint32_t)t;
+    for (int t0 = 0; t0 < T; t0 += 1024) {
+        const int t = t0 + (int)threadIdx.x;
+        const uint32_t n = t < T ? tile_count[t] : 0u;
+        const bool empty = t < T && n == 0u;
+        const unsigned long long em = __ballot(empty);
+        if (t < T && n != 0u) order[atomicAdd(&cls_off[255u - min(255u, (uint32_t)((float)n * scale))], 1u)] = (uint32_t)t;
+        if (em != 0ull) {
+            const int leader = __builtin_ctzll(em);
+            uint32_t b = 0;
+            if (lane == leader) b = atomicAdd(&cls_off[255], (uint32_t)__popcll(em));
+            b = __builtin_amdgcn_readlane(b, leader);
+            if (empty) order[b + (uint32_t)__popcll(em & ((1ull << lane) - 1ull))] = (uint32_t)t;
+        }
     }
 }
 
@@ -239,13 +253,24 @@ gsr_bwd_plan(const uint32_t* __restrict__ tile_last, int T, int seg_shift, uint3
     for (int w = 0; w < wave; ++w) base += wsum[w];
     uint32_t run = base + incl - local;
     for (int i = beg; i < end; ++i) {
-        const uint32_t segs = (tile_last[i] + round) >> seg_shift;
         plan_off[i] = run;
-        for (uint32_t k = 0; k < segs; ++k)
-            if (run + k < capacity) plan_tile[run + k] = (uint32_t)i;
-        run += segs;
+        run += (tile_last[i] + round) >> seg_shift;
     }
     if (threadIdx.x == 1023) total[0] = min(base + incl, capacity);
+}
+
+// The work list itself: plan_tile[plan_off[t] + k] = t for the k-th segment of tile t. One wave per tile, coalesced
+// runs, all CUs (filled by the single scan workgroup above, the ~100k scattered 4-byte stores of an 8-view batch went
+// through ONE CU's address pipeline: 36 us; a contiguous tile range per thread also serialised the heavy tiles).
+extern "C" __global__ void __launch_bounds__(256)
+gsr_bwd_plan_fill(const uint32_t* __restrict__ tile_last, int T, int seg_shift, uint32_t capacity,
+                  const uint32_t* __restrict__ plan_off, uint32_t* __restrict__ plan_tile) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (t >= T) return;
+    const uint32_t segs = (tile_last[t] + (1u << seg_shift) - 1u) >> seg_shift;
+    const uint32_t o = plan_off[t];
+    for (uint32_t k = lane; k < segs; k += 64)
+        if (o + k < capacity) plan_tile[o + k] = (uint32_t)t;
 }
 
 // ---------------------------------------------------------------------------------------
