@@ -313,14 +313,16 @@ gsr_render_fwd_q(const uint32_t* __restrict__ tile_off, const SplatRec* __restri
                 uint32_t slot[8];
 #pragma unroll
                 for (int b = 0; b < 8; ++b) slot[b] = ((b < 4 ? sl.x : sl.y) >> (8 * (b & 3))) & 0xffu;
-                float4 ea = sa[slot[0]], eb = sb[slot[0]], ec = sc[slot[0]];
+                // two entries per trip in two fixed register sets (a rotating set cost four 64-bit moves per entry); the
+                // second is masked off past the row's own list (nmine <= nmax; stale slots read staged records)
+                float4 e0a = sa[slot[0]], e0b = sb[slot[0]], e0c = sc[slot[0]];
 #pragma unroll
-                for (int b = 0; b < 8; ++b) {
+                for (int b = 0; b < 8; b += 2) {
                     if (jb + b < nmax) {                  // wave-uniform
-                        float4 xa = ea, xb = eb, xc = ec;
-                        if (b + 1 < 8) { xa = sa[slot[b + 1]]; xb = sb[slot[b + 1]]; xc = sc[slot[b + 1]]; }   // in flight during entry b
-                        GSR_FWDQ_ENTRY(ea, eb, ec, pos1 + slot[b], jb + b < nmine)
-                        ea = xa; eb = xb; ec = xc;
+                        const float4 e1a = sa[slot[b + 1]], e1b = sb[slot[b + 1]], e1c = sc[slot[b + 1]];   // in flight during entry b
+                        GSR_FWDQ_ENTRY(e0a, e0b, e0c, pos1 + slot[b], jb + b < nmine)
+                        if (b + 2 < 8) { e0a = sa[slot[b + 2]]; e0b = sb[slot[b + 2]]; e0c = sc[slot[b + 2]]; }   // in flight during entry b+1
+                        GSR_FWDQ_ENTRY(e1a, e1b, e1c, pos1 + slot[b + 1], jb + b + 1 < nmine)
                     }
                 }
             }
