@@ -36,7 +36,7 @@ benchall)
   echo "== bench 1M trained"; timeout 300 python bench.py --kind trained --cpu-budget 0 2> gpurun_out/bench_1M_trained.err | tee gpurun_out/bench_1M_trained.json;;
 prof)
   echo "== rocprofv3 kernel trace (1M)"
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_1M -o r02 -- python $R/bench.py --steps 5 --warmup 2 --cpu-budget 0 --no-roofline > $R/gpurun_out/prof_1M.log 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_1M -o r02 -- python $R/bench.py --steps 20 --warmup 5 --cpu-budget 0 --no-roofline > $R/gpurun_out/prof_1M.log 2>&1)
   tail -2 gpurun_out/prof_1M.log
   f=$(find gpurun_out/prof_1M -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -14 "$f" | cut -c1-60,200-320;;
 pmc)
