@@ -222,7 +222,7 @@ typedef gsr_f3 gsr_f3u __attribute__((aligned(4)));
 #define GSR_K1_BPITCH 17
 
 template <bool RAW>      // RAW: the inputs are DreamGaussian's raw parameters, activations fused (ViewConst.raw_act)
-__global__ void __launch_bounds__(256, 4)
+__global__ void __launch_bounds__(256, 5)
 gsr_preprocess_fwd(ViewTab views /* camera of this workgroup: views.v[blockIdx.y] */, int N, int K,
                    const float* __restrict__ means3D, const float* __restrict__ shs,
                    const float* __restrict__ shs_rest /* NULL: shs is [N,K,3]; else shs is [N,1,3] and this [N,K-1,3] */,
