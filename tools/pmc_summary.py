@@ -60,8 +60,14 @@ def main():
             if "FETCH_SIZE" in row and "WRITE_SIZE" in row:
                 fam = k.replace("gsr_", "")
                 rd_raw, wr = row["FETCH_SIZE"] * 1024.0, row["WRITE_SIZE"] * 1024.0
-                traffic[fam] = {"read_bytes_raw": rd_raw, "read_bytes_x2": 2 * rd_raw, "write_bytes": wr,
-                                "hbm_bytes": 2 * rd_raw + wr}
+                # calibrated on this repository's access patterns (tools/fetch_calib.hip, profiles/r02_fetch_calibration.txt):
+                # coalesced reads (4 or 16 B per lane) are counted at 1/2; random 64-byte record gathers at >= 1 (the counter
+                # tallies 64-B requests and a record read as 3-4 loads draws 1.8-2.1 of them); writes at 1 (streaming) and at
+                # their 32-byte sectors (scattered 8-byte stores)
+                gather = any(t in fam for t in ("render_fwd", "render_bwd"))
+                f = 1.0 if gather else 2.0
+                traffic[fam] = {"read_bytes_raw": rd_raw, "read_bytes_x2": 2 * rd_raw, "write_bytes": wr, "read_factor": f,
+                                "hbm_bytes": f * rd_raw + wr}
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         from dreamgaussian_amd import build as _build
         dig = _build._digest()
@@ -71,8 +77,9 @@ def main():
             if doc.get("source_digest") != dig:       # counters of other kernel sources: start over
                 doc = {}
         doc["source_digest"] = dig                    # bench.py reports `traffic` only when this matches its own build
-        doc["note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), per launch; read side doubled "
-                       "(gfx950 counts 64 B per 128-B request on wide streaming reads: upper bound for gather kernels)")
+        doc["note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), per launch; read side x2 for the streaming "
+                       "kernels (gfx950 counts 64 B per 128-B request on coalesced reads), x1 for the record-gathering "
+                       "compositing kernels (calibration: profiles/r02_fetch_calibration.txt)")
         doc[key] = traffic
         json.dump(doc, open(path, "w"), indent=1, sort_keys=True)
         print("wrote", path)
