@@ -61,8 +61,12 @@ def _f32c(t: Optional[torch.Tensor], device) -> Optional[torch.Tensor]:
 
 
 def _view_struct(rs: GaussianRasterizationSettings, device, raw: bool = False):
-    keep = [torch.as_tensor(x).to(device=device, dtype=torch.float32).contiguous().reshape(-1)
-            for x in (rs.bg, rs.viewmatrix, rs.projmatrix, rs.campos)]
+    keep = []
+    for x in (rs.bg, rs.viewmatrix, rs.projmatrix, rs.campos):
+        if type(x) is torch.Tensor and x.dtype is torch.float32 and x.device == device and x.is_contiguous():
+            keep.append(x)                                # already what the kernels read: no copy, no new tensor object
+        else:                                             # e.g. the reference's viewmatrix, a transposed (non-contiguous) view
+            keep.append(torch.as_tensor(x).to(device=device, dtype=torch.float32).contiguous().reshape(-1))
     if keep[0].numel() != 3 or keep[1].numel() != 16 or keep[2].numel() != 16 or keep[3].numel() != 3:
         raise RuntimeError("bg/campos must have 3 elements and viewmatrix/projmatrix 16")
     v = _lib.GsrView(int(rs.image_height), int(rs.image_width), float(rs.tanfovx),
