@@ -409,7 +409,7 @@ def main():
             try:
                 from dreamgaussian_amd import build as _build
                 tj = json.load(open(tf))
-                if tj.get("source_digest") == _build._digest():
+                if tj.get("source_digest") == _build.kernel_digest():
                     traffic = tj.get(f"{a.workload}/{a.kind}", {}).get(dom, {}).get("hbm_bytes")
                     traffic_note = tj.get("note", "rocprofv3 PMC, same kernel sources")
                 else:

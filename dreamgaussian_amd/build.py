@@ -39,6 +39,19 @@ def _digest() -> str:
     return h.hexdigest()
 
 
+def kernel_digest() -> str:
+    """Digest of the DEVICE code only (kernel files and gsr_device.h, build flags): what hardware-counter profiles of the
+    kernels belong to. Host-side changes in gsr_api.hip / include/gsr.h leave it unchanged (profiles/pmc_traffic.json)."""
+    h = hashlib.sha256()
+    h.update(" ".join(FLAGS + [ARCH]).encode())
+    for f in _sources():
+        if os.path.basename(f) in ("gsr_api.hip", "gsr.h"):
+            continue
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def hipcc_path() -> str:
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):

@@ -21,12 +21,14 @@
 namespace {
 
 thread_local char g_err[512] = "";
-thread_local unsigned long long* g_pinned = nullptr;   // kCounterWords x u64 host-pinned scratch
+thread_local unsigned long long* g_pinned = nullptr;   // (kCounterWords + 1) x u64 host-pinned scratch: the counters, then the arrival flag
 constexpr int kCounterWords = 8 + 2 * GSR_MAX_VIEWS;  // device counters: 8 totals, then (M_ref, V) per view
 struct FwdHint { bool valid = false; int N = 0, H = 0, W = 0, B = 0; unsigned long long M = 0, maxc = 0, M_ref = 0, V = 0; };
 thread_local FwdHint g_hint;                            // this thread's previous gsr_forward: predicts the next one's list sizes
 thread_local hipEvent_t g_copied_own = nullptr;        // this thread's "counters copied" event (gsr_forward)
 thread_local hipEvent_t g_copied = nullptr;            // set while gsr_forward drives gsr_forward_begin
+thread_local volatile unsigned long long* g_flag = nullptr;   // likewise: the pinned arrival flag of the counter copy
+constexpr unsigned long long kFlagSentinel = 0xffffffffffffffffull;
 
 int fail(int code, const char* fmt, const char* a = "", long long b = 0) {
     snprintf(g_err, sizeof(g_err), fmt, a, b);
@@ -214,6 +216,8 @@ constexpr int kHistLdsMaxTiles = 16384;   // 64 KiB of LDS histogram
 //   GSR_FWD=q|block       forward with quad lists / 8x8 block lists (default: chosen per scene)
 //   GSR_TILE_ORDER=off    forward compositing tiles in row-major instead of heaviest-first order
 //   GSR_SEG_SHIFT=6..8    log2 of the backward segment length in list positions
+//   GSR_SPECULATE=0       gsr_forward waits for the instance count before binning (default: speculative, see forward_impl)
+//   GSR_WAIT=event        that wait through hipEventSynchronize instead of the pinned arrival flag
 bool use_tile_order_off() {
     static const bool v = [] { const char* e = getenv("GSR_TILE_ORDER"); return e && strcmp(e, "off") == 0; }();
     return v;
@@ -345,6 +349,11 @@ int begin_impl(const GsrView* views, int B, int32_t N, int32_t K,
     LAUNCH_CHECK(view, stream, "tile_scan");
     // gsr_forward waits for THIS copy only (g_copied)
     HIP_TRY(hipMemcpyAsync(host_counters, counters, (size_t)counter_words * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    if (g_flag) {   // second, stream-ordered copy of a word that is zero here (counters[4], written only by the backward): its arrival
+                    // over the host's sentinel says the counters above have landed (gsr_forward polls it, wait_counters)
+        *g_flag = kFlagSentinel;
+        HIP_TRY(hipMemcpyAsync((void*)g_flag, counters + 4, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    }
     if (g_copied) HIP_TRY(hipEventRecord(g_copied, stream));
     return 0;
 }
@@ -465,7 +474,7 @@ int forward_impl(const GsrView* views, int B, int32_t N, int32_t K,
     if (!out_color || !out_depth || !out_alpha || (N > 0 && !radii)) return fail(-1, "output pointers are required%s", "");
     if (!geom.resize || !bin.resize || !img.resize) return fail(-1, "scratch allocators are required%s", "");
     // the one host round trip of the forward: how many (tile,Gaussian) instances to allocate
-    if (!g_pinned) HIP_TRY(hipHostMalloc((void**)&g_pinned, kCounterWords * sizeof(unsigned long long), hipHostMallocDefault));
+    if (!g_pinned) HIP_TRY(hipHostMalloc((void**)&g_pinned, (kCounterWords + 1) * sizeof(unsigned long long), hipHostMallocDefault));
     struct Capture { GsrAlloc inner; void* ptr; };
     Capture cg{geom, nullptr}, ci{img, nullptr};
     auto tramp = [](void* ctx, size_t bytes) -> void* { Capture* c = (Capture*)ctx; c->ptr = c->inner.resize(c->inner.ctx, bytes); return c->ptr; };
@@ -473,20 +482,26 @@ int forward_impl(const GsrView* views, int B, int32_t N, int32_t K,
     if (!g_copied_own) HIP_TRY(hipEventCreateWithFlags(&g_copied_own, hipEventDisableTiming));
     hipEvent_t ev = g_copied_own;
     g_copied = ev;                                        // begin_impl records it right after the counter copy
+    static const bool spin = [] { const char* e = getenv("GSR_WAIT"); return !(e && strcmp(e, "event") == 0); }();   // GSR_WAIT=event: wait on the event only
+    g_flag = spin ? g_pinned + kCounterWords : nullptr;
     const int rc_begin = begin_impl(views, B, N, K, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                                     radii, ag, ai, (uint64_t*)g_pinned, 8 + 2 * B, stream_);
     g_copied = nullptr;
+    g_flag = nullptr;
     if (rc_begin) return rc_begin;
     const ViewConst vcs = make_view(view);
     const GeomLayout GLs = geom_layout(N, vcs.H, vcs.W, B);
-    // Speculation (GSR_SPECULATE=1, off by default): the previous call of this thread on the same problem shape predicts
-    // M (+25 %) and the sort classes; binning / sort / compositing are enqueued at once, the host waits for the counters
-    // only afterwards and repeats the tail when the prediction was too small (the kernels refuse to touch lists that do
-    // not fit: gsr_scatter). Correct (tests/test_parity_gpu.py::test_speculative_forward_recovers_from_mispredictions) but
-    // MEASURED SLOWER on the MI355X: 250k / 512^2 0.361 -> 0.441 ms per fwd+bwd, 100k / 800^2 0.347 -> 0.401, 5k / 256^2
-    // and 1M / 800^2 unchanged -- hipEventSynchronize on the early event returns only when the work enqueued behind it has
-    // drained, so the backward's launches start late. The default keeps the early wait (K1 + scan only ahead of it).
-    static const bool spec_on = [] { const char* e = getenv("GSR_SPECULATE"); return e && e[0] == '1'; }();
+    // Speculation (default; GSR_SPECULATE=0 turns it off): the previous call of this thread on the same problem shape predicts
+    // M (+25 %) and the sort classes; binning / sort / compositing are enqueued at once -- the GPU runs the forward back to
+    // back -- and only then does the host wait for the counters, repeating the tail when the prediction was too small (the
+    // kernels refuse to touch lists that do not fit: gsr_scatter; tests/test_parity_gpu.py::
+    // test_speculative_forward_recovers_from_mispredictions). The wait polls a pinned arrival flag written by a second,
+    // stream-ordered copy (GSR_WAIT=event: hipEventSynchronize instead). Measured, ms per fwd+bwd, wait-first / speculative
+    // with the event / speculative with the flag: 5k-256^2 0.402 / 0.396 / 0.313, 250k-512^2 0.366 / 0.352 / 0.354,
+    // 100k-800^2 0.369 / 0.348 / 0.350, 1M-800^2 0.751 / 0.750 / 0.747 (one box; on another box the event variant had been
+    // SLOWER than wait-first, 0.441 vs 0.361 at 250k: hipEventSynchronize returned only after the work queued behind the
+    // event had drained -- the reason for the flag).
+    static const bool spec_on = [] { const char* e = getenv("GSR_SPECULATE"); return !(e && e[0] == '0'); }();   // GSR_SPECULATE=0: wait for the counters first
     const bool spec = spec_on && g_hint.valid && g_hint.N == N && g_hint.H == vcs.H && g_hint.W == vcs.W && g_hint.B == B && N > 0;
     unsigned long long cap = 0, capc = 0;
     int rc = 0;
@@ -497,7 +512,16 @@ int forward_impl(const GsrView* views, int B, int32_t N, int32_t K,
         rc = finish_impl(views, B, N, out_color, out_depth, out_alpha, cg.ptr, ci.ptr, bin, g_hint.M_ref, g_hint.V, nullptr, cap, capc, stream_);
         if (rc) return rc;
     }
-    HIP_TRY(hipEventSynchronize(ev));
+    {   // GSR_WAIT=spin: poll the pinned arrival flag instead of waiting on the event (which, with work queued behind it,
+        // was seen to return only when that work had drained); bounded, then the event as the fallback
+        bool arrived = false;
+        if (spin) {
+            volatile unsigned long long* f = g_pinned + kCounterWords;
+            for (long it = 0; it < 20000000L && !arrived; ++it) { arrived = (*f != kFlagSentinel); if (!arrived) __builtin_ia32_pause(); }
+            __sync_synchronize();
+        }
+        if (!arrived) HIP_TRY(hipEventSynchronize(ev));
+    }
     const unsigned long long M_ref = g_pinned[0], V = g_pinned[1], M = g_pinned[2], maxc = g_pinned[3];
     if (spec && (M > cap || sort_class(maxc) > sort_class(capc))) {
         // misprediction: the kernels above left without writing; clear what the scatter / forward accumulate into

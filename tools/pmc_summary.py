@@ -70,7 +70,7 @@ def main():
                                 "hbm_bytes": f * rd_raw + wr}
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         from dreamgaussian_amd import build as _build
-        dig = _build._digest()
+        dig = _build.kernel_digest()
         doc = {}
         if os.path.exists(path):
             doc = json.load(open(path))
