@@ -94,7 +94,11 @@ typedef struct GsrStats {
  *   out_color [3,H,W] out_depth [H,W] out_alpha [H,W] radii [N] int32
  *   geom/bin/img     scratch; the three buffers must be kept and handed to gsr_backward
  *   stats            [host] optional
- * Blocks the host once (until the per-tile counts are known) like the reference ext does.
+ * The host returns once the instance counters of THIS call have arrived (GsrStats is exact), but nothing on the GPU waits for
+ * the host: the list scratch is sized from the previous call of the thread on the same (N, H, W) (+25 %), binning / sort /
+ * compositing are enqueued before the wait, and a prediction that turns out too small is detected on the device and the
+ * tail repeated (first call of a shape, GSR_SPECULATE=0: counters first, then the tail, like the reference ext's blocking
+ * read of num_rendered).
  * Returns 0, or a negative code with gsr_last_error() set. N==0 renders the background. */
 int gsr_forward(const GsrView* view, int32_t N, int32_t K,
                 const float* means3D, const float* shs, const float* colors_precomp,
