@@ -24,3 +24,39 @@ def test_workloads_are_baseline_configs():
     assert "100k Gaussians, SH degree 3, 800" in cfgs[1] and bench.WORKLOADS["100k-800-sh3"]["cfg"] == 1
     assert "250k Gaussians, 512" in cfgs[3] and bench.WORKLOADS["250k-512-sh0"]["N"] == 250_000
     assert bench.kernel_family("tile_sort_large") == "tile_sort" and bench.kernel_family("render_bwd") == "render_bwd"
+
+
+def test_traffic_stamp_follows_the_device_code_only(tmp_path, monkeypatch):
+    """profiles/pmc_traffic.json is trusted by bench.py only when it was collected with the same DEVICE code
+    (build.kernel_digest): a host-side edit of gsr_api.hip / gsr.h must not invalidate it, a kernel edit must."""
+    import shutil
+    from dreamgaussian_amd import build
+    src = os.path.dirname(build.CSRC)
+    root = tmp_path / "pkg"
+    shutil.copytree(build.CSRC, root / "dreamgaussian_amd" / "csrc")
+    (root / "include").mkdir()
+    shutil.copy(os.path.join(os.path.dirname(src), "include", "gsr.h"), root / "include" / "gsr.h")
+    monkeypatch.setattr(build, "HERE", str(root / "dreamgaussian_amd"))
+    monkeypatch.setattr(build, "CSRC", str(root / "dreamgaussian_amd" / "csrc"))
+    full0, dev0 = build._digest(), build.kernel_digest()
+    with open(root / "dreamgaussian_amd" / "csrc" / "gsr_api.hip", "a") as fh:
+        fh.write("\n// host-side edit\n")
+    assert build._digest() != full0 and build.kernel_digest() == dev0
+    with open(root / "dreamgaussian_amd" / "csrc" / "gsr_render.hip", "a") as fh:
+        fh.write("\n// kernel edit\n")
+    assert build.kernel_digest() != dev0
+
+
+def test_committed_traffic_file_uses_the_calibrated_read_factors():
+    import json
+    from dreamgaussian_amd import build
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
+    doc = json.load(open(path))
+    if doc["source_digest"] != build.kernel_digest():
+        import pytest
+        pytest.skip("profiles/pmc_traffic.json was collected with other kernel sources: bench.py reports traffic null until "
+                    "the PMC passes are re-collected (tools/gpu_r2.sh pmc)")
+    rb = doc["1M-800-sh3/blob"]["render_bwd"]
+    assert rb["read_factor"] == 1.0 and abs(rb["hbm_bytes"] - (rb["read_bytes_raw"] + rb["write_bytes"])) < 1.0
+    k6 = doc["1M-800-sh3/blob"]["preprocess_bwd<false>"]
+    assert k6["read_factor"] == 2.0
