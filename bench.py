@@ -65,7 +65,11 @@ def alg_bytes(N, K, V, M, P):
 
 
 def kernel_family(name: str) -> str:
-    return "tile_sort" if name.startswith("tile_sort") else name
+    """Kernels that share one line of alg_bytes: the sort's size classes; the forward compositing's two kernels
+    (gsr_render_fwd_seg composites the depth segments, gsr_render_fwd_combine chains them per pixel)."""
+    if name.startswith("tile_sort"):
+        return "tile_sort"
+    return "render_fwd" if name == "render_combine" else name
 
 
 def build_inputs(wl, kind, dev, azimuth):
@@ -237,8 +241,6 @@ def main():
                     help="cameras per step on each GPU (B > 1: dreamgaussian_amd.rasterize_views keeps them in flight "
                          "together; --views-serial renders them one after the other like the reference's loop)")
     ap.add_argument("--views-serial", action="store_true")
-    ap.add_argument("--views-mode", default="chain", choices=["chain", "streams"],
-                    help="rasterize_views: one launch chain for all views (default) or one HIP stream per view")
     ap.add_argument("--activations", default="none", choices=["none", "torch", "fused"],
                     help="what the timed step does about DreamGaussian's parameter activations (gs_renderer.py:134-142): "
                          "none = the rasterizer alone on activated inputs (the headline metric); torch = sigmoid/exp/normalize "
@@ -312,8 +314,7 @@ def main():
                 torch.autograd.backward([c, d, al], gout)
         else:
             m2d_b.grad = None
-            c, r, d, al = D.rasterize_views(t["means3D"], m2d_b, t["opacities"], vs, shs=t["shs"], scales=t["scales"], rotations=t["rotations"],
-                                            mode=a.views_mode)
+            c, r, d, al = D.rasterize_views(t["means3D"], m2d_b, t["opacities"], vs, shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
             torch.autograd.backward([c, d, al], gout_views)
 
     if a.activations != "none":      # raw parameters whose activations reproduce the scene
@@ -379,7 +380,7 @@ def main():
     st = D.last_stats()
 
     # ---- per-kernel durations: hipEvents around every launch, same workload, K more steps ----
-    kern, roof, path_roof, dt_prof = {}, None, None, None
+    kern, kern_raw, roof, path_roof, dt_prof = {}, {}, None, None, None
     if not a.no_roofline and rank == 0 and a.views == 1:
         _lib.profile_reset()
         _lib.profile_enable(True)
@@ -391,11 +392,14 @@ def main():
         dt_prof = time.perf_counter() - t1
         _lib.profile_enable(False)
         raw = _lib.profile_read()
+        kern_raw = {name: ms / a.steps for name, (ms, n) in raw.items()}
+        fam_launches = {}
         for name, (ms, n) in raw.items():
             fam = kernel_family(name)
             e = kern.setdefault(fam, [0.0, 0])
             e[0] += ms
             e[1] = max(e[1], n)
+            fam_launches[fam] = fam_launches.get(fam, 0) + n / a.steps
         P = wl["H"] * wl["W"]
         ab = alg_bytes(wl["N"], K, st["V"], st["M_ref"], P)
         per_step = {k: v[0] / a.steps for k, v in kern.items()}
@@ -424,7 +428,8 @@ def main():
                         alg_bytes_per_launch=ab[dom], instances_priced="M_ref (reference emission rule, SURVEY 8(d))",
                         alg_bytes_per_launch_emitted=ab_emit[dom],
                         frac_emitted=round(ab_emit[dom] / (per_step[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                        avg_launch_ms=round(per_step[dom], 4), launches_per_step=1)
+                        avg_launch_ms=round(per_step[dom], 4), launches_per_step=round(fam_launches.get(dom, 1)),
+                        kernels={k: round(v, 4) for k, v in kern_raw.items() if kernel_family(k) == dom})
         ach_p = ab["total"] / (dt / a.steps) / 1e9
         path_roof = dict(bound="hbm", achieved=round(ach_p, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                          frac=round(ach_p / HBM_PEAK_GBS, 5), alg_bytes_per_step=ab["total"],
@@ -453,11 +458,12 @@ def main():
             "config": {"workload": f"BASELINE.json configs[{wl['cfg']}]: {wl['N']} Gaussians, SH degree "
                                    f"{wl['deg']}, {wl['W']}x{wl['H']}, fwd+bwd, scene '{a.kind}' seed 0, "
                                    f"orbit camera r=2 fovy=49.1",
-                       "views_per_step": world * a.views, "activations": a.activations, "views_mode": ("single" if a.views == 1 else ("serial loop" if a.views_serial else "rasterize_views/" + a.views_mode)), "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU",
+                       "views_per_step": world * a.views, "activations": a.activations, "views_mode": ("single" if a.views == 1 else ("serial loop" if a.views_serial else "rasterize_views/chain")), "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU",
                        "N": wl["N"], "K": K, "V": st.get("V"), "M": st.get("M_ref"), "M_emitted": st.get("M"),
-                       "max_tile_list": st.get("max_tile")},
+                       "max_tile_list": st.get("max_tile"), "seg_shift": st.get("seg_shift")},
             "roofline": roof, "path_roofline": path_roof, "cpu_baseline": cpu,
             "kernels_ms_per_step": {k: round(v[0] / a.steps, 4) for k, v in sorted(kern.items())},
+            "kernels_ms_per_step_raw": {k: round(v, 4) for k, v in sorted(kern_raw.items())} if kern else {},
             "ms_per_step_with_events": None if dt_prof is None else round(dt_prof / a.steps * 1e3, 4),
         }
         if sds is not None:

@@ -13,11 +13,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSR_LIB") or os.path.join(_HERE, "libgsr.so")
 
 GSR_MAX_VIEWS = 16      # include/gsr.h
+GSR_ABI_VERSION = 3     # include/gsr.h
 
-EXPORTS = ("gsr_forward", "gsr_forward_begin", "gsr_forward_finish", "gsr_backward", "gsr_forward_views", "gsr_backward_views", "gsr_mark_visible", "gsr_dist2", "gsr_extract_fields", "gsr_densify_stats",
+EXPORTS = ("gsr_forward", "gsr_backward", "gsr_forward_views", "gsr_backward_views", "gsr_mark_visible", "gsr_dist2", "gsr_extract_fields", "gsr_densify_stats",
            "gsr_adam_step", "gsr_mask_compact", "gsr_gather_rows",
            "gsr_profile_enable", "gsr_profile_read", "gsr_profile_reset",
-           "gsr_geom_bytes", "gsr_img_bytes", "gsr_last_error", "gsr_version")
+           "gsr_geom_bytes", "gsr_img_bytes", "gsr_last_error", "gsr_version", "gsr_abi_version")
 
 
 class GsrView(C.Structure):
@@ -49,7 +50,8 @@ class GsrGatherTensor(C.Structure):
 
 class GsrStats(C.Structure):
     _fields_ = [("num_instances", C.c_int64), ("num_instances_ref", C.c_int64),
-                ("num_visible", C.c_int64), ("max_tile_count", C.c_int64), ("bin_capacity", C.c_int64)]
+                ("num_visible", C.c_int64), ("max_tile_count", C.c_int64), ("bin_capacity", C.c_int64),
+                ("seg_shift", C.c_int64)]
 
 
 _lock = threading.Lock()
@@ -70,16 +72,14 @@ def load() -> C.CDLL:
                 "`python -m dreamgaussian_amd.build` (or __graft_entry__.build()); there is no "
                 "CPU fallback for the rasterizer.")
         lib = C.CDLL(LIB_PATH)
+        lib.gsr_abi_version.restype = C.c_int
+        if lib.gsr_abi_version() != GSR_ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} reports ABI version {lib.gsr_abi_version()}, this binding is written for "
+                               f"{GSR_ABI_VERSION} (include/gsr.h): rebuild with `python -m dreamgaussian_amd.build`")
         p, i32, vp = C.c_void_p, C.c_int32, C.c_void_p
         lib.gsr_forward.restype = C.c_int
         lib.gsr_forward.argtypes = [C.POINTER(GsrView), i32, i32] + [p] * 7 + [p] * 4 + \
             [GsrAlloc, GsrAlloc, GsrAlloc, C.POINTER(GsrStats), vp]
-        lib.gsr_forward_begin.restype = C.c_int
-        lib.gsr_forward_begin.argtypes = [C.POINTER(GsrView), i32, i32] + [p] * 7 + [p] + \
-            [GsrAlloc, GsrAlloc, C.c_void_p, vp]
-        lib.gsr_forward_finish.restype = C.c_int
-        lib.gsr_forward_finish.argtypes = [C.POINTER(GsrView), i32, i32] + [p] * 3 + [p, p, GsrAlloc, C.c_void_p,
-                                                                                C.POINTER(GsrStats), vp]
         lib.gsr_backward.restype = C.c_int
         lib.gsr_backward.argtypes = [C.POINTER(GsrView), i32, i32] + [p] * 7 + [p] + [p] * 3 + \
             [p] * 3 + [C.POINTER(GsrStats)] + [p] * 8 + [GsrAlloc, vp]

@@ -13,9 +13,6 @@ the views' parameter gradients into one [N,...] tensor in the order autograd wou
 Same arithmetic, same kernels as `GaussianRasterizer`: images, depth, alpha, radii and the per-view means2D
 gradients are bit-identical to B single-view calls; the summed parameter gradients equal the serial loop's up to
 the order of the fp32 atomics inside each view.
-
-`mode="streams"` keeps the round-1 scheme (one HIP stream per view through `gsr_forward_begin` / `_finish`) for
-A/B measurements.
 """
 from __future__ import annotations
 
@@ -26,152 +23,6 @@ import torch
 
 from . import _lib
 from .rasterizer import (GaussianRasterizationSettings, _f32c, _require_gpu, _view_struct)
-
-_streams = {}
-_pinned = {}
-
-
-def _stream_pool(dev, n):
-    pool = _streams.setdefault(dev, [])
-    while len(pool) < n:
-        pool.append(torch.cuda.Stream(device=dev))
-    return pool[:n]
-
-
-def _host_counters(dev, n):
-    key = (dev, n)
-    if key not in _pinned:
-        _pinned[key] = torch.zeros(n, 4, dtype=torch.int64).pin_memory()
-    return _pinned[key]
-
-
-class _RasterizeViewsStreams(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings):
-        _require_gpu(means3D)
-        lib = _lib.load()
-        dev = means3D.device
-        B = len(settings)
-        H, W = int(settings[0].image_height), int(settings[0].image_width)
-        for rs in settings:
-            if (int(rs.image_height), int(rs.image_width)) != (H, W):
-                raise RuntimeError("rasterize_views: all views must share one image size")
-        N = int(means3D.shape[0])
-        if tuple(means2D.shape) != (B, N, 3):
-            raise RuntimeError("means2D must have dimensions (num_views, num_points, 3)")
-        m3, shc, col = _f32c(means3D, dev), _f32c(sh, dev), _f32c(colors_precomp, dev)
-        op, sc, rot, cov = _f32c(opacities, dev), _f32c(scales, dev), _f32c(rotations, dev), _f32c(cov3Ds_precomp, dev)
-        K = int(shc.shape[1]) if shc is not None else 0
-        if (sh is None) == (colors_precomp is None):
-            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
-        if ((scales is None or rotations is None) and cov3Ds_precomp is None) or \
-                ((scales is not None or rotations is not None) and cov3Ds_precomp is not None):
-            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
-
-        color = torch.empty(B, 3, H, W, dtype=torch.float32, device=dev)
-        depth = torch.empty(B, 1, H, W, dtype=torch.float32, device=dev)
-        alpha = torch.empty(B, 1, H, W, dtype=torch.float32, device=dev)
-        radii = torch.empty(B, N, dtype=torch.int32, device=dev)
-        cur = torch.cuda.current_stream(dev)
-        streams = _stream_pool(dev, B)
-        host = _host_counters(dev, B)
-        views, keeps, geoms, imgs, bins, stats, events = [], [], [], [], [], [], []
-        P = _lib.ptr
-        with torch.cuda.device(dev):
-            # every view struct first: their .to()/.contiguous() copies run on the CURRENT stream and
-            # must be ordered before the side streams fork from it
-            structs = [_view_struct(settings[v], dev) for v in range(B)]
-            for v in range(B):                       # phase 1: per-Gaussian stage of every view
-                s = streams[v]
-                s.wait_stream(cur)
-                view, keep = structs[v]
-                geom, img = _lib.Scratch(dev), _lib.Scratch(dev)
-                rc = lib.gsr_forward_begin(C.byref(view), N, K, P(m3), P(shc), P(col), P(op), P(sc), P(rot), P(cov),
-                                           C.c_void_p(radii[v].data_ptr()), geom.alloc, img.alloc,
-                                           C.c_void_p(host[v].data_ptr()), C.c_void_p(s.cuda_stream))
-                geom.release(); img.release()
-                _lib.check(rc, "gsr_forward_begin")
-                ev = torch.cuda.Event()
-                ev.record(s)
-                views.append(view); keeps.append(keep); geoms.append(geom); imgs.append(img); events.append(ev)
-            for v in range(B):                       # phase 2: binning, sort, compositing
-                events[v].synchronize()
-                s = streams[v]
-                binb, st = _lib.Scratch(dev), _lib.GsrStats()
-                rc = lib.gsr_forward_finish(C.byref(views[v]), N, K, C.c_void_p(color[v].data_ptr()),
-                                            C.c_void_p(depth[v].data_ptr()), C.c_void_p(alpha[v].data_ptr()),
-                                            P(geoms[v].tensor), P(imgs[v].tensor), binb.alloc,
-                                            C.c_void_p(host[v].data_ptr()), C.byref(st), C.c_void_p(s.cuda_stream))
-                binb.release()
-                _lib.check(rc, "gsr_forward_finish")
-                bins.append(binb); stats.append(st)
-            for s in streams:
-                cur.wait_stream(s)
-        ctx.settings = settings
-        ctx.views = list(zip(views, keeps))    # the backward reuses the structs (and keeps their device constants alive)
-        ctx.dims = (B, N, K, H, W)
-        ctx.stats = stats
-        ctx.present = (shc is not None, col is not None, sc is not None, cov is not None)
-        empty = torch.empty(0, device=dev)
-        ctx.save_for_backward(m3 if m3 is not None else empty, shc if shc is not None else empty,
-                              col if col is not None else empty, op if op is not None else empty,
-                              sc if sc is not None else empty, rot if rot is not None else empty,
-                              cov if cov is not None else empty, radii,
-                              *[g.tensor for g in geoms], *[b.tensor for b in bins], *[i.tensor for i in imgs])
-        ctx.shapes = (means3D.shape, None if sh is None else sh.shape,
-                      None if colors_precomp is None else colors_precomp.shape, opacities.shape,
-                      None if scales is None else scales.shape, None if rotations is None else rotations.shape,
-                      None if cov3Ds_precomp is None else cov3Ds_precomp.shape)
-        ctx.mark_non_differentiable(radii)
-        return color, radii, depth, alpha
-
-    @staticmethod
-    def backward(ctx, g_color, g_radii, g_depth, g_alpha):
-        lib = _lib.load()
-        B, N, K, H, W = ctx.dims
-        saved = ctx.saved_tensors
-        m3, shc, col, op, sc, rot, cov, radii = saved[:8]
-        geoms, bins, imgs = saved[8:8 + B], saved[8 + B:8 + 2 * B], saved[8 + 2 * B:8 + 3 * B]
-        has_sh, has_col, has_sr, has_cov = ctx.present
-        dev = radii.device
-        z = lambda g, shape: (torch.zeros(shape, dtype=torch.float32, device=dev) if g is None
-                              else g.to(torch.float32).contiguous())
-        gc, gd, ga = z(g_color, (B, 3, H, W)), z(g_depth, (B, 1, H, W)), z(g_alpha, (B, 1, H, W))
-        f = lambda *s: (torch.empty if N > 0 else torch.zeros)(*s, dtype=torch.float32, device=dev)
-        d_m3, d_m2, d_op = f(B, N, 3), f(B, N, 3), f(B, N, 1)
-        d_sh = f(B, N, K, 3) if has_sh else None
-        d_col = f(B, N, 3) if has_col else None
-        d_sc, d_rot = (f(B, N, 3), f(B, N, 4)) if has_sr else (None, None)
-        d_cov = f(B, N, 6) if has_cov else None
-        if N > 0:
-            cur = torch.cuda.current_stream(dev)
-            streams = _stream_pool(dev, B)
-            P = _lib.ptr
-            sl = lambda t, v: None if t is None else C.c_void_p(t[v].data_ptr())
-            keep_alive = []
-            with torch.cuda.device(dev):
-                for v in range(B):
-                    s = streams[v]
-                    s.wait_stream(cur)
-                    view, keep = ctx.views[v]
-                    tmp = _lib.Scratch(dev)
-                    rc = lib.gsr_backward(
-                        C.byref(view), N, K, P(m3), P(shc) if has_sh else None, P(col) if has_col else None,
-                        P(op), P(sc) if has_sr else None, P(rot) if has_sr else None, P(cov) if has_cov else None,
-                        C.c_void_p(radii[v].data_ptr()), sl(gc, v), sl(gd, v), sl(ga, v),
-                        P(geoms[v]), P(bins[v]), P(imgs[v]), C.byref(ctx.stats[v]),
-                        sl(d_m3, v), sl(d_m2, v), sl(d_sh, v), sl(d_col, v), sl(d_op, v), sl(d_sc, v), sl(d_rot, v),
-                        sl(d_cov, v), tmp.alloc, C.c_void_p(s.cuda_stream))
-                    tmp.release()
-                    _lib.check(rc, "gsr_backward")
-                    keep_alive.append((keep, tmp.tensor))
-                for s in streams:
-                    cur.wait_stream(s)
-        sh_ = ctx.shapes
-        total = lambda g, shape: None if g is None or shape is None else g.sum(0).reshape(shape)
-        return (total(d_m3, sh_[0]), d_m2, total(d_sh, sh_[1]), total(d_col, sh_[2]), total(d_op, sh_[3]),
-                total(d_sc, sh_[4]), total(d_rot, sh_[5]), total(d_cov, sh_[6]), None)
-
 
 class _RasterizeViews(torch.autograd.Function):
     """Up to GSR_MAX_VIEWS cameras through gsr_forward_views / gsr_backward_views."""
@@ -219,8 +70,9 @@ class _RasterizeViews(torch.autograd.Function):
         ctx.dims = (B, N, K, H, W)
         ctx.present = (shc is not None, col is not None, sc is not None, cov is not None)
         empty = torch.empty(0, device=dev)
+        # the camera constants travel as raw pointers: saved too, so that an in-place edit between forward and backward raises
         ctx.save_for_backward(*[t if t is not None else empty for t in (m3, shc, col, op, sc, rot, cov)], radii,
-                              geom.tensor, binb.tensor, img.tensor)
+                              geom.tensor, binb.tensor, img.tensor, *[t for keep in keeps for t in keep])
         ctx.shapes = (means3D.shape, None if sh is None else sh.shape,
                       None if colors_precomp is None else colors_precomp.shape, opacities.shape,
                       None if scales is None else scales.shape, None if rotations is None else rotations.shape,
@@ -232,7 +84,7 @@ class _RasterizeViews(torch.autograd.Function):
     def backward(ctx, g_color, g_radii, g_depth, g_alpha):
         lib = _lib.load()
         B, N, K, H, W = ctx.dims
-        m3, shc, col, op, sc, rot, cov, radii, geom, binb, img = ctx.saved_tensors
+        m3, shc, col, op, sc, rot, cov, radii, geom, binb, img = ctx.saved_tensors[:11]
         has_sh, has_col, has_sr, has_cov = ctx.present
         dev = radii.device
         z = lambda g, shape: (torch.zeros(shape, dtype=torch.float32, device=dev) if g is None
@@ -263,7 +115,7 @@ class _RasterizeViews(torch.autograd.Function):
 
 
 def rasterize_views(means3D, means2D, opacities, raster_settings: Sequence[GaussianRasterizationSettings],
-                    shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, mode: str = "chain"):
+                    shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None):
     """Render `len(raster_settings)` cameras of the same Gaussians.
 
     Arguments as `GaussianRasterizer.forward` (gs_renderer.py:800-809) except `means2D`, the
@@ -272,11 +124,6 @@ def rasterize_views(means3D, means2D, opacities, raster_settings: Sequence[Gauss
     depth [B,1,H,W], alpha [B,1,H,W])`; gradients of the shared inputs are summed over the views.
     More than GSR_MAX_VIEWS (16) cameras are rendered in chunks of 16."""
     settings = tuple(raster_settings)
-    if mode == "streams":
-        return _RasterizeViewsStreams.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                            cov3D_precomp, settings)
-    if mode != "chain":
-        raise ValueError("mode must be 'chain' or 'streams'")
     if len(settings) <= _lib.GSR_MAX_VIEWS:
         return _RasterizeViews.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
                                      cov3D_precomp, settings)

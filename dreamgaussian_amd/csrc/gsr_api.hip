@@ -17,17 +17,16 @@
 #include <math.h>
 #include <vector>
 #include <mutex>
+#include <atomic>
 
 namespace {
 
 thread_local char g_err[512] = "";
 thread_local unsigned long long* g_pinned = nullptr;   // (kCounterWords + 1) x u64 host-pinned scratch: the counters, then the arrival flag
 constexpr int kCounterWords = 8 + 2 * GSR_MAX_VIEWS;  // device counters: 8 totals, then (M_ref, V) per view
-struct FwdHint { bool valid = false; int N = 0, H = 0, W = 0, B = 0; unsigned long long M = 0, maxc = 0, M_ref = 0, V = 0; };
+struct FwdHint { bool valid = false; int N = 0, H = 0, W = 0, B = 0; unsigned long long M = 0, maxc = 0; unsigned long long per_view[2 * GSR_MAX_VIEWS] = {}; };
 thread_local FwdHint g_hint;                            // this thread's previous gsr_forward: predicts the next one's list sizes
-thread_local hipEvent_t g_copied_own = nullptr;        // this thread's "counters copied" event (gsr_forward)
-thread_local hipEvent_t g_copied = nullptr;            // set while gsr_forward drives gsr_forward_begin
-thread_local volatile unsigned long long* g_flag = nullptr;   // likewise: the pinned arrival flag of the counter copy
+thread_local hipEvent_t g_copied = nullptr;            // this thread's "counters copied" event
 constexpr unsigned long long kFlagSentinel = 0xffffffffffffffffull;
 
 int fail(int code, const char* fmt, const char* a = "", long long b = 0) {
@@ -105,7 +104,7 @@ int once_per_device(F fn) {
 }
 
 struct GeomLayout {
-    size_t recs, emit, flags8, block_stats, tile_count, cursor, tile_last, tile_off, tile_seg, tile_order, plan_off, counters, total;
+    size_t recs, emit, flags8, block_stats, tile_count, cursor, counters, tile_off, tile_seg, order, level_off, sat, tile_last, plan_off, total;
     int nTiles;        // per view
     int allTiles;      // views * nTiles: the per-tile arrays hold every view's tiles, view-major
 };
@@ -122,30 +121,33 @@ GeomLayout geom_layout(int N, int H, int W, int B = 1) {
     L.emit = o; o += align_up(BN * sizeof(EmitRec));
     L.flags8 = o; o += align_up(BN);
     L.block_stats = o; o += align_up((size_t)B * 2048 * 3 * 8);       // K1 grid <= 2048 workgroups per view
+    // tile_count | cursor | counters are contiguous: one memset in front of K1
     L.tile_count = o; o += align_up(BT * 4);
     L.cursor = o; o += align_up(BT * 4);
-    L.tile_last = o; o += align_up(BT * 4);
     L.counters = o; o += align_up((8 + 2 * GSR_MAX_VIEWS) * 8);   // totals, then (M_ref, V) per view
     L.tile_off = o; o += align_up((BT + 1) * 4);
     L.tile_seg = o; o += align_up((BT + 1) * 4);
-    L.tile_order = o; o += align_up(BT * 4);
+    L.order = o; o += align_up(BT * 4);
+    L.level_off = o; o += align_up((GSR_NLEV + 1) * 4);
+    L.sat = o; o += align_up(BT * 4 * 8);                         // hint word per (tile, wave) of the segment forward
+    L.tile_last = o; o += align_up(BT * 4);
     L.plan_off = o; o += align_up(BT * 4);
     L.total = o;
     return L;
 }
-int seg_shift();
-struct BinLayout { size_t entries, ids, ckpt, plan_tile, plan_cap, total; };
-BinLayout bin_layout(size_t M, int nTiles) {
+struct BinLayout { size_t entries, ids, ckpt, plan_tile, plan_cap, items, total; };
+BinLayout bin_layout(size_t M, int nTiles, int shift) {
     BinLayout L;
     size_t o = 0;
     // first: the sorted lists (4-byte Gaussian indices) -- the backward finds them at offset 0
     // without knowing M
     L.ids = o; o += align_up(M * 4);
     L.entries = o; o += align_up(M * 8);
-    // backward checkpoints: sum over tiles of floor((n_t-1) >> seg_shift) <= (M >> seg_shift) slots
-    L.ckpt = o; o += align_up(((M >> seg_shift()) + 1) * (size_t)GSR_CKPT_FLOATS * 4);
-    // backward work list: sum over tiles of ceil(last_t / 2^shift) <= (M >> shift) + nTiles entries
-    L.plan_cap = (M >> seg_shift()) + (size_t)nTiles + 1;
+    // (tile, segment) items of the forward = segment records: sum over tiles of ceil(n_t >> shift) <= (M >> shift) + nTiles
+    L.items = (M >> shift) + (size_t)nTiles;
+    L.ckpt = o; o += align_up((L.items + 1) * (size_t)GSR_CKPT_FLOATS * 4);
+    // backward work list: sum over tiles of ceil(last_t / 2^shift) <= the same bound
+    L.plan_cap = L.items + 1;
     L.plan_tile = o; o += align_up(L.plan_cap * 4);
     L.total = o < 256 ? 256 : o;
     return L;
@@ -212,34 +214,36 @@ int check_inputs(int N, int K, const GsrView* v, const float* means3D, const flo
 
 constexpr int kHistLdsMaxTiles = 16384;   // 64 KiB of LDS histogram
 
-// Environment switches kept for same-box A/B measurements (defaults = the shipped path):
-//   GSR_FWD=q|block       forward with quad lists / 8x8 block lists (default: chosen per scene)
-//   GSR_TILE_ORDER=off    forward compositing tiles in row-major instead of heaviest-first order
-//   GSR_SEG_SHIFT=6..8    log2 of the backward segment length in list positions
+// Environment switches kept for same-box A/B measurements (defaults = the shipped path), read at every call:
+//   GSR_FWD=q|block       segment forward with quad lists / 8x8 block lists (default: chosen per view from its statistics)
+//   GSR_SEG_SHIFT=6..8    log2 of the segment length in list positions (default: from N and the tile count, below)
 //   GSR_SPECULATE=0       gsr_forward waits for the instance count before binning (default: speculative, see forward_impl)
 //   GSR_WAIT=event        that wait through hipEventSynchronize instead of the pinned arrival flag
-bool use_tile_order_off() {
-    static const bool v = [] { const char* e = getenv("GSR_TILE_ORDER"); return e && strcmp(e, "off") == 0; }();
-    return v;
+// Segment length of one call. It fixes where the per-pixel sums are cut (the rounding of the results), so it must not
+// depend on anything a second call with the same inputs could see differently, nor on how many views share the call:
+// N and the per-view tile count only. Short lists (the DreamGaussian-sized scenes) want the finest cut -- their
+// forward is a latency chain; long lists amortise the per-workgroup set-up over more entries.
+int seg_shift_for(int N, int tiles_per_view) {
+    if (const char* e = getenv("GSR_SEG_SHIFT")) { const int s = atoi(e); if (s >= 6 && s <= 8) return s; }
+    const double x = 4.0 * (double)N / (double)(tiles_per_view > 0 ? tiles_per_view : 1);   // ~ list length of an average tile
+    return x <= 512.0 ? 6 : (x <= 2048.0 ? 7 : 8);
 }
-int seg_shift() {
-    static const int v = [] {
-        const char* e = getenv("GSR_SEG_SHIFT");
-        const int s = e ? atoi(e) : GSR_SEG_SHIFT_DEFAULT;
-        return (s < 6 || s > 8) ? GSR_SEG_SHIFT_DEFAULT : s;       // multiples of the 64-entry fetch round; LDS table = 48 B << shift
-    }();
-    return v;
-}
-// forward compositing kernel: 0 = per scene (below), 1 = 8x8 block lists, 2 = quad lists
+// forward compositing kernel: 0 = per view (finish_impl), 1 = 8x8 block lists, 2 = quad lists
 int fwd_kernel_env() {
-    static const int v = [] {
-        const char* e = getenv("GSR_FWD");
-        if (e && strcmp(e, "q") == 0) return 2;
-        if (e && strcmp(e, "block") == 0) return 1;
-        return 0;
-    }();
-    return v;
+    const char* e = getenv("GSR_FWD");
+    if (e && strcmp(e, "q") == 0) return 2;
+    if (e && strcmp(e, "block") == 0) return 1;
+    return 0;
 }
+//   GSR_FWD_HINTS=off|skipall   segment forward: read no hints (every segment composited) / TEST: skip every segment behind the
+//                         first of a tile, so that the chaining kernel has to walk them all (same results, bit for bit)
+int fwd_hint_env() {
+    const char* e = getenv("GSR_FWD_HINTS");
+    if (e && strcmp(e, "off") == 0) return 1;
+    if (e && strcmp(e, "skipall") == 0) return 2;
+    return 0;
+}
+std::atomic<uint32_t> g_epoch{0x5eed};                  // launch tag of the segment forward's hints
 
 }  // namespace
 
@@ -275,30 +279,27 @@ extern "C" int gsr_profile_read(int cap, const char** names, float* total_ms, in
     }
     return n;
 }
-extern "C" const char* gsr_version(void) { return "gsr 0.1 (gfx950, wave64, 16x16 bins / 8x8 wave blocks)"; }
+extern "C" const char* gsr_version(void) { return "gsr 0.3 (gfx950, wave64, 16x16 bins / 8x8 wave blocks, depth-segmented forward)"; }
+extern "C" int gsr_abi_version(void) { return GSR_ABI_VERSION; }
 
 extern "C" size_t gsr_geom_bytes(int32_t N, int32_t H, int32_t W) { return geom_layout(N, H, W).total; }
 // final_T | n_contrib | totals[5] (the five per-pixel sums without background)
 extern "C" size_t gsr_img_bytes(int32_t H, int32_t W) { return align_up((size_t)H * W * 4) * 7; }
 
-// ---- forward, two phases -------------------------------------------------------------------
-// begin : per-Gaussian stage + tile scan on `stream`, then an async copy of the four counters
-//         (M_ref, V, M, longest list) to `host_counters` (caller-owned, pinned, 4 x u64).
-// finish: once the caller has waited for that copy: binning, sort, compositing.
-// gsr_forward = begin + wait + finish. All of it takes B views of the same size (gsr_forward_views): ONE launch of
-// every kernel covers the B cameras, the counters are totals over the views.
+// ---- forward -----------------------------------------------------------------------------------
+// begin : memset, per-Gaussian stage (K1), tile scan + depth-major work list (K2) on `stream`, then an async copy of the
+//         counters (M_ref, V, M, longest list, ..., per-view M_ref / V) into this thread's pinned block, followed by a
+//         second copy that overwrites the arrival flag.
+// finish: binning, sort, segment forward (K5a), segment chaining (K5b) for lists of up to `cap` instances.
+// All of it takes B views of the same size (gsr_forward_views): ONE launch of every kernel covers the B cameras, the
+// counters are totals over the views.
 namespace {
 int begin_impl(const GsrView* views, int B, int32_t N, int32_t K,
                const float* means3D, const float* shs, const float* colors_precomp,
                const float* opacities, const float* scales, const float* rotations,
-               const float* cov3D_precomp, int32_t* radii,
-               GsrAlloc geom, GsrAlloc img, uint64_t* host_counters, int counter_words, gsr_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    if (int rc = check_views(views, B)) return rc;
+               const float* cov3D_precomp, int32_t* radii, char* gbuf, int shift,
+               unsigned long long* host_counters, int counter_words, hipStream_t stream) {
     const GsrView* view = views;
-    if (int rc = check_inputs(N, K, view, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp)) return rc;
-    if (N > 0 && !radii) return fail(-1, "radii is required%s", "");
-    if (!geom.resize || !img.resize || !host_counters) return fail(-1, "scratch allocators and host_counters are required%s", "");
     ViewTab tab;
     memset(&tab, 0, sizeof(tab));
     for (int v = 0; v < B; ++v) tab.v[v] = make_view(views + v);
@@ -306,20 +307,13 @@ int begin_impl(const GsrView* views, int B, int32_t N, int32_t K,
     const int H = vc.H, W = vc.W;
     const GeomLayout GL = geom_layout(N, H, W, B);
     const int T = GL.nTiles;
-    char* gbuf = (char*)geom.resize(geom.ctx, GL.total);
-    char* ibuf = (char*)img.resize(img.ctx, gsr_img_bytes(H, W) * (size_t)B);
-    if (!gbuf || !ibuf) return fail(-4, "scratch allocation failed%s", "");
 
     SplatRec* recs = (SplatRec*)(gbuf + GL.recs);
     EmitRec* emit = (EmitRec*)(gbuf + GL.emit);
     uint32_t* tile_count = (uint32_t*)(gbuf + GL.tile_count);
-    uint32_t* tile_off = (uint32_t*)(gbuf + GL.tile_off);
-    uint32_t* tile_seg = (uint32_t*)(gbuf + GL.tile_seg);
-    uint32_t* tile_order = use_tile_order_off() ? nullptr : (uint32_t*)(gbuf + GL.tile_order);
     unsigned long long* counters = (unsigned long long*)(gbuf + GL.counters);
 
     const int hist_in_lds = T <= kHistLdsMaxTiles;
-    // tile_count | cursor | tile_last | counters are contiguous: one memset
     prof_begin(stream);
     HIP_TRY(hipMemsetAsync(gbuf + GL.tile_count, 0, GL.tile_off - GL.tile_count, stream));
     prof_end(stream, "memset_fwd");
@@ -343,37 +337,30 @@ int begin_impl(const GsrView* views, int B, int32_t N, int32_t K,
                            tile_count, (unsigned long long*)(gbuf + GL.block_stats), hist_in_lds, (uint8_t*)(gbuf + GL.flags8));
         LAUNCH_CHECK(view, stream, "preprocess_fwd");
     }
-    // one single-workgroup kernel: scan of the counts, K1's statistics, heaviest-first launch order
-    prof_begin(stream); hipLaunchKernelGGL(gsr_tile_scan, dim3(1), dim3(1024), 0, stream, tile_count, tile_off, GL.allTiles, counters, tile_seg, seg_shift(),
-                       (const unsigned long long*)(gbuf + GL.block_stats), N > 0 ? grid_pre * B : 0, B, tile_order);
+    // one single-workgroup kernel: scan of the counts, K1's statistics, the segment forward's depth-major work list
+    prof_begin(stream); hipLaunchKernelGGL(gsr_tile_scan, dim3(1), dim3(1024), 0, stream, tile_count, (uint32_t*)(gbuf + GL.tile_off), GL.allTiles, counters,
+                       (uint32_t*)(gbuf + GL.tile_seg), shift, (const unsigned long long*)(gbuf + GL.block_stats), N > 0 ? grid_pre * B : 0, B,
+                       (uint32_t*)(gbuf + GL.order), (uint32_t*)(gbuf + GL.level_off));
     LAUNCH_CHECK(view, stream, "tile_scan");
-    // gsr_forward waits for THIS copy only (g_copied)
     HIP_TRY(hipMemcpyAsync(host_counters, counters, (size_t)counter_words * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-    if (g_flag) {   // second, stream-ordered copy of a word that is zero here (counters[4], written only by the backward): its arrival
-                    // over the host's sentinel says the counters above have landed (gsr_forward polls it, wait_counters)
-        *g_flag = kFlagSentinel;
-        HIP_TRY(hipMemcpyAsync((void*)g_flag, counters + 4, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-    }
-    if (g_copied) HIP_TRY(hipEventRecord(g_copied, stream));
+    // second, stream-ordered copy of a word that is zero here (counters[4], written only by the segment chaining, later in
+    // the stream): its arrival over the host's sentinel says the counters above have landed (forward_impl polls it)
+    host_counters[kCounterWords] = kFlagSentinel;
+    HIP_TRY(hipMemcpyAsync((void*)(host_counters + kCounterWords), counters + 4, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipEventRecord(g_copied, stream));
     return 0;
 }
 
 int sort_class(unsigned long long maxc) { return maxc <= 2048 ? 0 : (maxc <= 8192 ? 1 : (maxc <= 16384 ? 2 : 3)); }
 
 // Binning, sort and compositing for lists of up to `cap` instances whose longest is assumed <= `maxc`.
-// cap / maxc are either the exact counters (the host has waited for them) or gsr_forward's prediction; in the
-// second case M_ref / V steer only the per-scene kernel choice and the kernels themselves check the true M.
+// cap / maxc are either the exact counters (the host has waited for them) or forward_impl's prediction; in the second
+// case every kernel that touches the lists checks the true M and the true longest list and leaves when they do not fit.
 int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float* out_depth, float* out_alpha,
-                void* geom_ptr, void* img_ptr, GsrAlloc bin, unsigned long long M_ref, unsigned long long V,
-                const unsigned long long* per_view /* (M_ref, V) of every view, or NULL: the totals decide for all */,
-                unsigned long long cap, unsigned long long maxc, gsr_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    if (int rc = check_views(views, B)) return rc;
+                char* gbuf, char* ibuf, GsrAlloc bin, int shift,
+                const unsigned long long* per_view /* (M_ref, V) of every view */,
+                unsigned long long cap, unsigned long long maxc, hipStream_t stream) {
     const GsrView* view = views;
-    if (!out_color || !out_depth || !out_alpha) return fail(-1, "output pointers are required%s", "");
-    if (!geom_ptr || !img_ptr || !bin.resize) return fail(-1, "forward_begin state is required%s", "");
-    char* gbuf = (char*)geom_ptr;
-    char* ibuf = (char*)img_ptr;
     const ViewConst vc = make_view(view);
     const int H = vc.H, W = vc.W;
     const GeomLayout GL = geom_layout(N, H, W, B);
@@ -385,8 +372,7 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
     uint32_t* cursor = (uint32_t*)(gbuf + GL.cursor);
     uint32_t* tile_off = (uint32_t*)(gbuf + GL.tile_off);
     uint32_t* tile_seg = (uint32_t*)(gbuf + GL.tile_seg);
-    uint32_t* tile_last = (uint32_t*)(gbuf + GL.tile_last);
-    uint32_t* tile_order = use_tile_order_off() ? nullptr : (uint32_t*)(gbuf + GL.tile_order);
+    uint32_t* order = (uint32_t*)(gbuf + GL.order);
     unsigned long long* counters = (unsigned long long*)(gbuf + GL.counters);
     float* final_T = (float*)ibuf;
     uint32_t* n_contrib = (uint32_t*)(ibuf + align_up((size_t)H * W * 4));
@@ -395,8 +381,10 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
     const int hist_in_lds = T <= kHistLdsMaxTiles;
     const unsigned long long M = cap;
     if (M >= 0xfffffff0ull) return fail(-5, "too many tile instances (%s%lld)", "", (long long)M);
+    const uint32_t maxc_cap = maxc >= 0xffffffffull ? 0xffffffffu : (uint32_t)maxc;
 
-    const BinLayout BL = bin_layout((size_t)M, TA);
+    const BinLayout BL = bin_layout((size_t)M, TA, shift);
+    if (BL.items >= 0x7fffffffull) return fail(-5, "too many depth segments (%s%lld)", "", (long long)BL.items);
     char* bbuf = (char*)bin.resize(bin.ctx, BL.total);
     if (!bbuf) return fail(-4, "bin scratch allocation failed%s", "");
     unsigned long long* entries = (unsigned long long*)(bbuf + BL.entries);
@@ -435,29 +423,56 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
             prof_begin(stream); hipLaunchKernelGGL(gsr_tile_sort_global_ids, dim3(TA), dim3(1024), 0, stream, tile_off, entries, sorted_ids, 16384u, counters, (uint32_t)M);
             LAUNCH_CHECK(view, stream, "tile_sort_global");
         }
+        // ---- K5a: every (tile, segment) composited on its own
+        // Quad lists pay when splats are small against an 8x8 block (few of its 64 lanes blend a given Gaussian): the scene
+        // statistic M_ref / V (reference tiles per visible Gaussian) decides, view by view -- a view renders with the kernel its
+        // single-view call would use (the two give the same bits anyway: tests/test_parity_gpu.py).
+        uint32_t mask_q = 0;
+        const int fk = fwd_kernel_env();
+        for (int v = 0; v < B; ++v) {
+            const unsigned long long mr = per_view[2 * v], vv = per_view[2 * v + 1];
+            if (fk == 2 || (fk == 0 && vv > 0 && mr <= 6ull * vv)) mask_q |= 1u << v;
+        }
+        const uint32_t mask_all = B >= 32 ? ~0u : ((1u << B) - 1u);
+        const uint32_t epoch = g_epoch.fetch_add(1u) + 1u;
+        const int hint_mode = fwd_hint_env();
+        unsigned long long* sat = (unsigned long long*)(gbuf + GL.sat);
+        const uint32_t* level_off = (const uint32_t*)(gbuf + GL.level_off);
+        prof_begin(stream);
+        if (mask_q) {
+            vs.view_mask = mask_q;
+            hipLaunchKernelGGL(gsr_render_fwd_seg<true>, dim3((unsigned)BL.items), dim3(256), 0, stream, tile_off, recs, sorted_ids, W, H, vc.gx,
+                               ckpt, tile_seg, order, level_off, shift, sat, epoch, hint_mode, counters, (uint32_t)M, maxc_cap, vs);
+        }
+        if (mask_q != mask_all) {
+            vs.view_mask = mask_all & ~mask_q;
+            hipLaunchKernelGGL(gsr_render_fwd_seg<false>, dim3((unsigned)BL.items), dim3(256), 0, stream, tile_off, recs, sorted_ids, W, H, vc.gx,
+                               ckpt, tile_seg, order, level_off, shift, sat, epoch, hint_mode, counters, (uint32_t)M, maxc_cap, vs);
+        }
+        LAUNCH_CHECK(view, stream, "render_fwd");
     }
+    // ---- K5b: chain the segments per pixel, image outputs, the backward's work list
     prof_begin(stream);
-    // Quad lists pay when splats are small against an 8x8 block (few of its 64 lanes blend a given Gaussian):
-    // measured -2% / -7% / -9% at 1M blob / 1M trained / 250k-512^2 (4.2-4.3 reference tiles per Gaussian) and +7% at
-    // 100k-800^2 (10.4): the scene statistic the host already holds decides.
-    // Views are judged one by one (a view renders with the kernel its single-view call would use: bit-identical images).
-    uint32_t mask_q = 0;
-    for (int v = 0; v < B; ++v) {
-        const unsigned long long mr = per_view ? per_view[2 * v] : M_ref, vv = per_view ? per_view[2 * v + 1] : V;
-        if (fwd_kernel_env() == 2 || (fwd_kernel_env() == 0 && vv > 0 && mr <= 6ull * vv)) mask_q |= 1u << v;
+    hipLaunchKernelGGL(gsr_render_fwd_combine, dim3(TA), dim3(256), 0, stream, tile_off, recs, sorted_ids, W, H, vc.gx,
+                       out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, order, shift,
+                       (uint32_t*)(gbuf + GL.tile_last), (uint32_t*)(gbuf + GL.plan_off), (uint32_t*)(bbuf + BL.plan_tile),
+                       counters + 4, (uint32_t)BL.plan_cap, counters, (uint32_t)M, maxc_cap, vs);
+    LAUNCH_CHECK(view, stream, "render_combine");
+    return 0;
+}
+
+// waits until the counter copy behind begin_impl has landed in the thread's pinned block
+int wait_counters(volatile unsigned long long* pinned) {
+    // GSR_WAIT=event: hipEventSynchronize only. Default: poll the pinned arrival flag (with work queued behind the
+    // event, hipEventSynchronize was seen to return only when that work had drained); bounded, then the event
+    const char* e = getenv("GSR_WAIT");
+    bool arrived = false;
+    if (!(e && strcmp(e, "event") == 0)) {
+        volatile unsigned long long* f = pinned + kCounterWords;
+        for (long it = 0; it < 20000000L && !arrived; ++it) { arrived = (*f != kFlagSentinel); if (!arrived) __builtin_ia32_pause(); }
+        __sync_synchronize();
     }
-    const uint32_t mask_all = B >= 32 ? ~0u : ((1u << B) - 1u);
-    if (mask_q) {
-        vs.view_mask = mask_q;
-        hipLaunchKernelGGL(gsr_render_fwd_q, dim3(TA), dim3(256), 0, stream, tile_off, recs, sorted_ids, W, H, vc.gx,
-                           out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, tile_order, seg_shift(), tile_last, counters, (uint32_t)M, vs);
-    }
-    if (mask_q != mask_all) {
-        vs.view_mask = mask_all & ~mask_q;
-        hipLaunchKernelGGL(gsr_render_fwd, dim3(TA), dim3(256), 0, stream, tile_off, recs, sorted_ids, W, H, vc.gx,
-                           out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, tile_order, seg_shift(), tile_last, counters, (uint32_t)M, vs);
-    }
-    LAUNCH_CHECK(view, stream, "render_fwd");
+    if (!arrived) HIP_TRY(hipEventSynchronize(g_copied));
     return 0;
 }
 
@@ -468,6 +483,7 @@ int forward_impl(const GsrView* views, int B, int32_t N, int32_t K,
                  float* out_color, float* out_depth, float* out_alpha, int32_t* radii,
                  GsrAlloc geom, GsrAlloc bin, GsrAlloc img,
                  GsrStats* stats, gsr_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
     if (int rc = check_views(views, B)) return rc;
     const GsrView* view = views;
     if (int rc = check_inputs(N, K, view, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp)) return rc;
@@ -475,66 +491,53 @@ int forward_impl(const GsrView* views, int B, int32_t N, int32_t K,
     if (!geom.resize || !bin.resize || !img.resize) return fail(-1, "scratch allocators are required%s", "");
     // the one host round trip of the forward: how many (tile,Gaussian) instances to allocate
     if (!g_pinned) HIP_TRY(hipHostMalloc((void**)&g_pinned, (kCounterWords + 1) * sizeof(unsigned long long), hipHostMallocDefault));
-    struct Capture { GsrAlloc inner; void* ptr; };
-    Capture cg{geom, nullptr}, ci{img, nullptr};
-    auto tramp = [](void* ctx, size_t bytes) -> void* { Capture* c = (Capture*)ctx; c->ptr = c->inner.resize(c->inner.ctx, bytes); return c->ptr; };
-    GsrAlloc ag{&cg, tramp}, ai{&ci, tramp};
-    if (!g_copied_own) HIP_TRY(hipEventCreateWithFlags(&g_copied_own, hipEventDisableTiming));
-    hipEvent_t ev = g_copied_own;
-    g_copied = ev;                                        // begin_impl records it right after the counter copy
-    static const bool spin = [] { const char* e = getenv("GSR_WAIT"); return !(e && strcmp(e, "event") == 0); }();   // GSR_WAIT=event: wait on the event only
-    g_flag = spin ? g_pinned + kCounterWords : nullptr;
-    const int rc_begin = begin_impl(views, B, N, K, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                                    radii, ag, ai, (uint64_t*)g_pinned, 8 + 2 * B, stream_);
-    g_copied = nullptr;
-    g_flag = nullptr;
-    if (rc_begin) return rc_begin;
+    if (!g_copied) HIP_TRY(hipEventCreateWithFlags(&g_copied, hipEventDisableTiming));
     const ViewConst vcs = make_view(view);
     const GeomLayout GLs = geom_layout(N, vcs.H, vcs.W, B);
+    const int shift = seg_shift_for(N, GLs.nTiles);
+    char* gbuf = (char*)geom.resize(geom.ctx, GLs.total);
+    char* ibuf = (char*)img.resize(img.ctx, gsr_img_bytes(vcs.H, vcs.W) * (size_t)B);
+    if (!gbuf || !ibuf) return fail(-4, "scratch allocation failed%s", "");
+    if (int rc = begin_impl(views, B, N, K, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                            radii, gbuf, shift, g_pinned, 8 + 2 * B, stream)) {
+        (void)hipEventSynchronize(g_copied);              // no copy into the pinned block may be pending when the next call re-arms it
+        return rc;
+    }
     // Speculation (default; GSR_SPECULATE=0 turns it off): the previous call of this thread on the same problem shape predicts
-    // M (+25 %) and the sort classes; binning / sort / compositing are enqueued at once -- the GPU runs the forward back to
-    // back -- and only then does the host wait for the counters, repeating the tail when the prediction was too small (the
-    // kernels refuse to touch lists that do not fit: gsr_scatter; tests/test_parity_gpu.py::
-    // test_speculative_forward_recovers_from_mispredictions). The wait polls a pinned arrival flag written by a second,
-    // stream-ordered copy (GSR_WAIT=event: hipEventSynchronize instead). Measured, ms per fwd+bwd, wait-first / speculative
-    // with the event / speculative with the flag: 5k-256^2 0.402 / 0.396 / 0.313, 250k-512^2 0.366 / 0.352 / 0.354,
-    // 100k-800^2 0.369 / 0.348 / 0.350, 1M-800^2 0.751 / 0.750 / 0.747 (one box; on another box the event variant had been
-    // SLOWER than wait-first, 0.441 vs 0.361 at 250k: hipEventSynchronize returned only after the work queued behind the
-    // event had drained -- the reason for the flag).
-    static const bool spec_on = [] { const char* e = getenv("GSR_SPECULATE"); return !(e && e[0] == '0'); }();   // GSR_SPECULATE=0: wait for the counters first
-    const bool spec = spec_on && g_hint.valid && g_hint.N == N && g_hint.H == vcs.H && g_hint.W == vcs.W && g_hint.B == B && N > 0;
+    // M (+25 %), the sort classes and each view's kernel; binning / sort / compositing are enqueued at once -- the GPU runs the
+    // forward back to back -- and only then does the host wait for the counters, repeating the tail when the prediction was too
+    // small (every kernel that touches the lists leaves when the true M or the true longest list exceeds what was launched for:
+    // tests/test_parity_gpu.py::test_speculative_forward_recovers_from_mispredictions). Measured, ms per fwd+bwd, wait-first /
+    // speculative with the event / speculative with the flag: 5k-256^2 0.402 / 0.396 / 0.313, 250k-512^2 0.366 / 0.352 / 0.354,
+    // 100k-800^2 0.369 / 0.348 / 0.350, 1M-800^2 0.751 / 0.750 / 0.747 (round 2).
+    const char* se = getenv("GSR_SPECULATE");
+    const bool spec = !(se && se[0] == '0') && g_hint.valid && g_hint.N == N && g_hint.H == vcs.H && g_hint.W == vcs.W && g_hint.B == B && N > 0;
     unsigned long long cap = 0, capc = 0;
     int rc = 0;
     if (spec) {
         cap = g_hint.M + g_hint.M / 4 + 4096;
         const unsigned long long c = g_hint.maxc + g_hint.maxc / 4 + 64;
         capc = c <= 2048 ? 2048 : (c <= 8192 ? 8192 : (c <= 16384 ? 16384 : ~0ull));
-        rc = finish_impl(views, B, N, out_color, out_depth, out_alpha, cg.ptr, ci.ptr, bin, g_hint.M_ref, g_hint.V, nullptr, cap, capc, stream_);
-        if (rc) return rc;
+        rc = finish_impl(views, B, N, out_color, out_depth, out_alpha, gbuf, ibuf, bin, shift, g_hint.per_view, cap, capc, stream);
     }
-    {   // GSR_WAIT=spin: poll the pinned arrival flag instead of waiting on the event (which, with work queued behind it,
-        // was seen to return only when that work had drained); bounded, then the event as the fallback
-        bool arrived = false;
-        if (spin) {
-            volatile unsigned long long* f = g_pinned + kCounterWords;
-            for (long it = 0; it < 20000000L && !arrived; ++it) { arrived = (*f != kFlagSentinel); if (!arrived) __builtin_ia32_pause(); }
-            __sync_synchronize();
-        }
-        if (!arrived) HIP_TRY(hipEventSynchronize(ev));
-    }
+    if (int rcw = wait_counters(g_pinned)) return rcw;    // also on a failed tail: nothing may stay pending on the pinned block
+    if (rc) return rc;
     const unsigned long long M_ref = g_pinned[0], V = g_pinned[1], M = g_pinned[2], maxc = g_pinned[3];
     if (spec && (M > cap || sort_class(maxc) > sort_class(capc))) {
-        // misprediction: the kernels above left without writing; clear what the scatter / forward accumulate into
-        HIP_TRY(hipMemsetAsync((char*)cg.ptr + GLs.cursor, 0, GLs.counters - GLs.cursor, (hipStream_t)stream_));
+        // misprediction: the kernels above left without writing; clear what the scatter accumulates into
+        HIP_TRY(hipMemsetAsync(gbuf + GLs.cursor, 0, GLs.counters - GLs.cursor, stream));
         cap = 0;
     }
     if (!spec || cap == 0) {
         cap = M;
-        rc = finish_impl(views, B, N, out_color, out_depth, out_alpha, cg.ptr, ci.ptr, bin, M_ref, V, g_pinned + 8, M, maxc, stream_);
+        rc = finish_impl(views, B, N, out_color, out_depth, out_alpha, gbuf, ibuf, bin, shift, g_pinned + 8, M, maxc, stream);
     }
     if (stats) { stats->num_instances = (int64_t)M; stats->num_instances_ref = (int64_t)M_ref; stats->num_visible = (int64_t)V;
-                 stats->max_tile_count = (int64_t)maxc; stats->bin_capacity = (int64_t)cap; }
-    if (rc == 0) { g_hint.valid = true; g_hint.N = N; g_hint.H = vcs.H; g_hint.W = vcs.W; g_hint.B = B; g_hint.M = M; g_hint.maxc = maxc; g_hint.M_ref = M_ref; g_hint.V = V; }
+                 stats->max_tile_count = (int64_t)maxc; stats->bin_capacity = (int64_t)cap; stats->seg_shift = shift; }
+    if (rc == 0) {
+        g_hint.valid = true; g_hint.N = N; g_hint.H = vcs.H; g_hint.W = vcs.W; g_hint.B = B; g_hint.M = M; g_hint.maxc = maxc;
+        for (int v = 0; v < 2 * B; ++v) g_hint.per_view[v] = g_pinned[8 + v];
+    }
     return rc;
 }
 
@@ -573,15 +576,21 @@ int backward_impl(const GsrView* views, int B, int32_t N, int32_t K,
     const uint32_t* n_contrib = (const uint32_t*)(ibuf + align_up((size_t)H * W * 4));
     const float* totals = (const float*)(ibuf + 2 * align_up((size_t)H * W * 4));
     const uint32_t* tile_seg = (const uint32_t*)(gbuf + GL.tile_seg);
-    // the layout of `bin` follows the capacity it was sized for (>= M): from the caller's GsrStats, else read back
-    // from the device (blocking): counters[6], left there by the forward's scatter kernel
+    // the layout of `bin` follows the capacity and the segment length of the forward: from the caller's GsrStats, else
+    // read back from the device (blocking): counters[6] (left by the forward's scatter kernel) and counters[7]
     unsigned long long M = 0;
-    if (fwd_stats) M = (unsigned long long)(fwd_stats->num_instances > 0 ? fwd_stats->bin_capacity : 0);
-    else {
+    int shift = 6;
+    if (fwd_stats) {
+        M = (unsigned long long)(fwd_stats->num_instances > 0 ? fwd_stats->bin_capacity : 0);
+        shift = (int)fwd_stats->seg_shift;
+        if (shift < 6 || shift > 8) return fail(-1, "fwd_stats is not the GsrStats of a gsr_forward of this library version%s", "");
+    } else {
         unsigned long long h[8];
         HIP_TRY(hipMemcpyAsync(h, counters, sizeof(h), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         M = h[2] > 0 ? h[6] : 0;
+        shift = (int)(h[7] >> 32);
+        if (shift < 6 || shift > 8) return fail(-1, "geom does not hold the state of a forward%s", "");
     }
     const uint32_t* sorted_ids = (const uint32_t*)bin;    // BinLayout.ids == 0
 
@@ -592,28 +601,21 @@ int backward_impl(const GsrView* views, int B, int32_t N, int32_t K,
     HIP_TRY(hipMemsetAsync(g2d, 0, g2d_view * 4 * (size_t)B, stream));
     prof_end(stream, "memset_bwd");
 
+    prof_begin(stream);
     if (M > 0) {
-        const BinLayout BL = bin_layout((size_t)M, TA);
+        const BinLayout BL = bin_layout((size_t)M, TA, shift);
         const float* ckpt = (const float*)((const char*)bin + BL.ckpt);
-        // scratch of the matching forward, written here: the backward work list
-        uint32_t* plan_tile = (uint32_t*)((char*)const_cast<void*>(bin) + BL.plan_tile);
-        uint32_t* plan_off = (uint32_t*)(const_cast<char*>(gbuf) + GL.plan_off);
-        unsigned long long* plan_total = const_cast<unsigned long long*>(counters) + 4;
-        const uint32_t* tile_last = (const uint32_t*)(gbuf + GL.tile_last);
-        prof_begin(stream);
-        hipLaunchKernelGGL(gsr_bwd_plan, dim3(1), dim3(1024), 0, stream, tile_last, TA, seg_shift(), (uint32_t)BL.plan_cap,
-                           plan_off, plan_tile, plan_total);
-        hipLaunchKernelGGL(gsr_bwd_plan_fill, dim3((TA + 3) / 4), dim3(256), 0, stream, tile_last, TA, seg_shift(), (uint32_t)BL.plan_cap,
-                           plan_off, plan_tile);
-        LAUNCH_CHECK(view, stream, "bwd_plan");
-        prof_begin(stream);
+        // the work list ((tile, segment) up to each tile's deepest blended position) was left by the forward's chaining kernel
+        const uint32_t* plan_tile = (const uint32_t*)((const char*)bin + BL.plan_tile);
+        const uint32_t* plan_off = (const uint32_t*)(gbuf + GL.plan_off);
+        const unsigned long long* plan_total = counters + 4;
         const unsigned grid = (unsigned)BL.plan_cap;
         // workgroup table: [2^shift][10] 64-bit fixed-point sums
-        const size_t dyn = ((size_t)GSR_Q2_ROW * 8) << seg_shift();
+        const size_t dyn = ((size_t)GSR_Q2_ROW * 8) << shift;
         hipLaunchKernelGGL(gsr_render_bwd_q2, dim3(grid), dim3(256), dyn, stream, tile_off, recs, sorted_ids, W, H, vc.gx,
-                           final_T, n_contrib, totals, ckpt, tile_seg, dL_dcolor, dL_ddepth, dL_dalpha, g2d, seg_shift(),
+                           final_T, n_contrib, totals, ckpt, tile_seg, dL_dcolor, dL_ddepth, dL_dalpha, g2d, shift,
                            plan_tile, plan_off, plan_total, vs);
-    } else prof_begin(stream);
+    }
     LAUNCH_CHECK(view, stream, "render_bwd");
 
     const int grid_n = (int)fmin((double)((N + 255) / 256), 2048.0);
@@ -637,26 +639,6 @@ int backward_impl(const GsrView* views, int B, int32_t N, int32_t K,
     return 0;
 }
 }  // namespace
-
-extern "C" int gsr_forward_begin(const GsrView* view, int32_t N, int32_t K,
-                                 const float* means3D, const float* shs, const float* colors_precomp,
-                                 const float* opacities, const float* scales, const float* rotations,
-                                 const float* cov3D_precomp, int32_t* radii,
-                                 GsrAlloc geom, GsrAlloc img, uint64_t* host_counters, gsr_stream_t stream) {
-    return begin_impl(view, 1, N, K, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, geom, img, host_counters, 4, stream);
-}
-
-extern "C" int gsr_forward_finish(const GsrView* view, int32_t N, int32_t K,
-                                  float* out_color, float* out_depth, float* out_alpha,
-                                  void* geom_ptr, void* img_ptr, GsrAlloc bin,
-                                  const uint64_t* host_counters, GsrStats* stats, gsr_stream_t stream_) {
-    (void)K;
-    if (!host_counters) return fail(-1, "forward_begin state is required%s", "");
-    const unsigned long long M_ref = host_counters[0], V = host_counters[1], M = host_counters[2], maxc = host_counters[3];
-    if (stats) { stats->num_instances = (int64_t)M; stats->num_instances_ref = (int64_t)M_ref; stats->num_visible = (int64_t)V;
-                 stats->max_tile_count = (int64_t)maxc; stats->bin_capacity = (int64_t)M; }
-    return finish_impl(view, 1, N, out_color, out_depth, out_alpha, geom_ptr, img_ptr, bin, M_ref, V, nullptr, M, maxc, stream_);
-}
 
 extern "C" int gsr_forward(const GsrView* view, int32_t N, int32_t K,
                            const float* means3D, const float* shs, const float* colors_precomp,

@@ -14,26 +14,56 @@
 #include "gsr_device.h"
 
 // ---------------------------------------------------------------------------------------
-// K2: exclusive scan of the per-tile counts (single workgroup; T is a few thousand).
-// counters[0] = M_ref, [1] = V, [2] = M_emit, [3] = max per-tile count, [5] = bits of max(colour, depth),
+// K2: exclusive scan of the per-tile counts, K1's statistics, and the DEPTH-MAJOR work list of the segment
+// forward (single workgroup; T is a few thousand).
+// counters[0] = M_ref, [1] = V, [2] = M_emit, [3] = max per-tile count, [4] = backward work items (written by
+// gsr_render_fwd_combine), [5] = bits of max(colour, depth), [6] = list capacity (gsr_scatter), [7] = levels | seg_shift << 32,
 // [8 + 2v], [9 + 2v] = M_ref, V of view v.
+//
+// Work list. Tile t has nseg_t = ceil(n_t / 2^seg_shift) segments. `order` = the tiles sorted by
+// class = min(nseg, GSR_NLEV) DESCENDING (exact counting sort: one class per value), so the tiles that have a
+// segment c (< GSR_NLEV) are exactly order[0 .. S_c) with S_c = #tiles of class > c, and item k of the launch is
+// (level c, tile order[k - level_off[c]]) with level_off = exclusive scan of S: all first segments, then all second
+// segments, ... -- no list is written, gsr_render_fwd_seg finds its level with two ballots over level_off[0..1023].
+// level_off[c] = the item total for every c >= the number of levels.
 // ---------------------------------------------------------------------------------------
+#define GSR_NCLS (GSR_NLEV + 1)          // 1024 = one class per thread of the scan workgroup
+
+// exclusive scan over the 1024 threads of the workgroup, one value each (wsum: 16 words of LDS); *total = sum of all
+__device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t* wsum, uint32_t* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+    __syncthreads();                                   // wsum may still be read by the previous scan
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const uint32_t x = wsum[w]; all += x; base += w < wave ? x : 0u; }
+    if (total) *total = all;
+    return base + incl - v;
+}
+
 extern "C" __global__ void __launch_bounds__(1024)
 gsr_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_off, int T,
               unsigned long long* __restrict__ counters, uint32_t* __restrict__ tile_seg, int seg_shift,
               const unsigned long long* __restrict__ block_stats, int nblocks /* all views */, int nviews,
-              uint32_t* __restrict__ order /* heaviest-first launch order of the compositing forward, or NULL */) {
-    // tile_seg[t] = index of tile t's first checkpoint slot = exclusive scan of floor((n_t-1) >> seg_shift)
+              uint32_t* __restrict__ order /* tiles by segment count, descending */, uint32_t* __restrict__ level_off /* [1024] */) {
+    // tile_seg[t] = index of tile t's first segment record = exclusive scan of ceil(n_t / 2^seg_shift)
     __shared__ unsigned long long wsum[16];
     __shared__ uint32_t wsegs[16];
     __shared__ uint32_t wmax[16];
+    __shared__ uint32_t cls[GSR_NCLS];
+    const uint32_t round = (1u << seg_shift) - 1u;
     const int per = (T + 1023) / 1024;
     const int beg = min((int)threadIdx.x * per, T), end = min(beg + per, T);
     unsigned long long local = 0;
     uint32_t lmax = 0, lsegs = 0;
+    cls[threadIdx.x] = 0u;
     for (int i = beg; i < end; ++i) {
         const uint32_t c = tile_count[i];
-        local += c; lmax = max(lmax, c); lsegs += c ? (c - 1) >> seg_shift : 0u;
+        local += c; lmax = max(lmax, c); lsegs += (c + round) >> seg_shift;
     }
     // inclusive scan inside the wave
     unsigned long long incl = local;
@@ -57,7 +87,7 @@ gsr_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ ti
     for (int i = beg; i < end; ++i) {
         const uint32_t c = tile_count[i];
         tile_off[i] = (uint32_t)run; run += c;
-        tile_seg[i] = srun; srun += c ? (c - 1) >> seg_shift : 0u;
+        tile_seg[i] = srun; srun += (c + round) >> seg_shift;
     }
     {   // K1's per-workgroup statistics (M_ref, V): parallel sum over the workgroups
         __shared__ unsigned long long sref[16], svis[16], smax[16];
@@ -89,47 +119,40 @@ gsr_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ ti
         tile_off[T] = (uint32_t)(wave_base + incl);
         counters[2] = wave_base + incl;
         counters[3] = maxc;
+        const uint32_t nlev = min((maxc + round) >> seg_shift, (uint32_t)GSR_NLEV);
+        counters[7] = (unsigned long long)nlev | ((unsigned long long)seg_shift << 32);
     }
-    if (!order) return;
-    // Heaviest-first launch order (longest-processing-time-first: the dispatcher hands workgroups to CUs in
-    // index order, so tile weights are dealt round-robin). An approximate order is enough: counting sort of
-    // the tiles into 256 weight classes (an exact LDS bitonic sort of 2500 keys on one workgroup took 31 us).
-    __shared__ uint32_t cls_cnt[256];
-    __shared__ uint32_t cls_off[256];
-    const float scale = maxc > 0 ? 255.0f / (float)maxc : 0.f;
-    if (threadIdx.x < 256) cls_cnt[threadIdx.x] = 0;
-    __syncthreads();
-    // empty tiles (two thirds of a 512^2 view) all fall into class 255: one atomic per wave for them, not one per tile
+    // ---- classes: histogram of min(segments, GSR_NLEV). Empty tiles (two thirds of a 512^2 view) all fall into class 0:
+    // one atomic per wave for them, not one per tile
     for (int t0 = 0; t0 < T; t0 += 1024) {
         const int t = t0 + (int)threadIdx.x;
         const uint32_t n = t < T ? tile_count[t] : 0u;
         const unsigned long long em = __ballot(t < T && n == 0u);
-        if (t < T && n != 0u) atomicAdd(&cls_cnt[255u - min(255u, (uint32_t)((float)n * scale))], 1u);   // class 0 = heaviest
-        if (em != 0ull && lane == __builtin_ctzll(em)) atomicAdd(&cls_cnt[255], (uint32_t)__popcll(em));
+        if (t < T && n != 0u) atomicAdd(&cls[min((n + round) >> seg_shift, (uint32_t)GSR_NLEV)], 1u);
+        if (em != 0ull && lane == __builtin_ctzll(em)) atomicAdd(&cls[0], (uint32_t)__popcll(em));
     }
     __syncthreads();
-    if (threadIdx.x < 64) {                               // exclusive scan of 256 counters by one wave
-        uint32_t v[4], sum = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { v[q] = cls_cnt[threadIdx.x * 4 + q]; sum += v[q]; }
-        uint32_t inc = sum;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(inc, o, 64); if ((int)threadIdx.x >= o) inc += u; }
-        uint32_t run2 = inc - sum;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { cls_off[threadIdx.x * 4 + q] = run2; run2 += v[q]; }
-    }
+    uint32_t* scratch = wsegs;                            // 16 words, free from here on
+    // S[h] = #tiles of class > h: thread i <-> class h = 1023 - i, exclusive scan in i
+    const uint32_t mine = cls[(GSR_NCLS - 1) - threadIdx.x];
+    const uint32_t S_rev = block_scan_1024(mine, scratch, nullptr);
+    __syncthreads();                                      // every count is read: the array becomes S (and then the cursors)
+    cls[(GSR_NCLS - 1) - threadIdx.x] = S_rev;
     __syncthreads();
+    // level_off[c] = sum of S[c'] for c' < c: thread j <-> level c = j
+    level_off[threadIdx.x] = block_scan_1024(cls[threadIdx.x], scratch, nullptr);
+    __syncthreads();
+    // order[S[class]++] = tile: descending classes, the empty tiles last
     for (int t0 = 0; t0 < T; t0 += 1024) {
         const int t = t0 + (int)threadIdx.x;
         const uint32_t n = t < T ? tile_count[t] : 0u;
         const bool empty = t < T && n == 0u;
         const unsigned long long em = __ballot(empty);
-        if (t < T && n != 0u) order[atomicAdd(&cls_off[255u - min(255u, (uint32_t)((float)n * scale))], 1u)] = (uint32_t)t;
+        if (t < T && n != 0u) order[atomicAdd(&cls[min((n + round) >> seg_shift, (uint32_t)GSR_NLEV)], 1u)] = (uint32_t)t;
         if (em != 0ull) {
             const int leader = __builtin_ctzll(em);
             uint32_t b = 0;
-            if (lane == leader) b = atomicAdd(&cls_off[255], (uint32_t)__popcll(em));
+            if (lane == leader) b = atomicAdd(&cls[0], (uint32_t)__popcll(em));
             b = __builtin_amdgcn_readlane(b, leader);
             if (empty) order[b + (uint32_t)__popcll(em & ((1ull << lane) - 1ull))] = (uint32_t)t;
         }
@@ -226,51 +249,6 @@ __device__ __forceinline__ void bitonic_sort(KeyPtr keys, uint32_t n, int nthrea
             __syncthreads();
         }
     }
-}
-
-// Work list of the segmented backward: one entry per (tile, segment) whose segment starts before
-// the tile's deepest blended list position (tile_last, written by the forward). A 2-D grid
-// (tiles x longest list) would launch ~6x more workgroups than have work, and at 128-entry
-// segments the wave launch rate, not the math, bounded the kernel.
-// plan_off[t] = first entry of tile t; plan_tile[b] = tile of entry b; total[0] = entries.
-extern "C" __global__ void __launch_bounds__(1024)
-gsr_bwd_plan(const uint32_t* __restrict__ tile_last, int T, int seg_shift, uint32_t capacity,
-             uint32_t* __restrict__ plan_off, uint32_t* __restrict__ plan_tile,
-             unsigned long long* __restrict__ total) {
-    __shared__ uint32_t wsum[16];
-    const int per = (T + 1023) / 1024;
-    const int beg = min((int)threadIdx.x * per, T), end = min(beg + per, T);
-    const uint32_t round = (1u << seg_shift) - 1u;
-    uint32_t local = 0;
-    for (int i = beg; i < end; ++i) local += (tile_last[i] + round) >> seg_shift;
-    uint32_t incl = local;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    uint32_t base = 0;
-    for (int w = 0; w < wave; ++w) base += wsum[w];
-    uint32_t run = base + incl - local;
-    for (int i = beg; i < end; ++i) {
-        plan_off[i] = run;
-        run += (tile_last[i] + round) >> seg_shift;
-    }
-    if (threadIdx.x == 1023) total[0] = min(base + incl, capacity);
-}
-
-// The work list itself: plan_tile[plan_off[t] + k] = t for the k-th segment of tile t. One wave per tile, coalesced
-// runs, all CUs (filled by the single scan workgroup above, the ~100k scattered 4-byte stores of an 8-view batch went
-// through ONE CU's address pipeline: 36 us; a contiguous tile range per thread also serialised the heavy tiles).
-extern "C" __global__ void __launch_bounds__(256)
-gsr_bwd_plan_fill(const uint32_t* __restrict__ tile_last, int T, int seg_shift, uint32_t capacity,
-                  const uint32_t* __restrict__ plan_off, uint32_t* __restrict__ plan_tile) {
-    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (t >= T) return;
-    const uint32_t segs = (tile_last[t] + (1u << seg_shift) - 1u) >> seg_shift;
-    const uint32_t o = plan_off[t];
-    for (uint32_t k = lane; k < segs; k += 64)
-        if (o + k < capacity) plan_tile[o + k] = (uint32_t)t;
 }
 
 // ---------------------------------------------------------------------------------------

@@ -8,9 +8,9 @@
 #define GSR_LOG2E 1.4426950408889634f
 #define GSR_LN2 0.6931471805599453f
 
-// One 64-byte record per Gaussian (geom stage) and per (tile,Gaussian) instance (sorted
-// stage). 64 B = one s_load_dwordx16: the render kernels read records with SCALAR loads
-// because every lane of a wave consumes the same Gaussian.
+// One 64-byte record per (view, Gaussian), written by K1. The per-tile sorted lists hold Gaussian INDICES; the
+// compositing kernels gather the records with vector loads (one record per lane: three 16-byte loads for the
+// forward, the fourth dword group is for the backward and the binning).
 struct __attribute__((aligned(16))) SplatRec {
     // dwords 0..11: everything the forward compositing needs (three 16-byte loads)
     float x, y;        // projected mean, pixel coordinates
@@ -30,11 +30,23 @@ static_assert(sizeof(SplatRec) == 64, "SplatRec must be 64 bytes");
 
 #define GSR_FLAG_EMIT 8u
 
-// Backward segments: a tile's depth-sorted list is cut every 2^seg_shift positions; the forward
-// leaves a per-pixel checkpoint (T and the five running sums) at every cut so that each segment
-// of the backward can start front-to-back on its own workgroup.
-#define GSR_SEG_SHIFT_DEFAULT 6    // 64 list positions per segment = one fetch round per wave (env GSR_SEG_SHIFT: 6..8)
-#define GSR_CKPT_FLOATS (6 * 256)   // one checkpoint: [T, C0, C1, C2, D, A][256 pixels of the tile]
+// Depth segments: a tile's depth-sorted list is cut every 2^seg_shift positions (64, 128 or 256). Forward AND backward
+// run one workgroup per (tile, segment). One 8 KiB record per segment, [plane][256 pixels of the tile]:
+//   written by gsr_render_fwd_seg (the segment composited on its own, transmittance 1 coming in):
+//     0 T' at the segment's end | 1..3 colour sums | 4 depth sum | 5 alpha sum | 6 list position of the last blended
+//     entry (u32, 0 = none) | 7 hint: u16 floor(-256 log2(upper bound of the transmittance after this segment)) | u16 tag << 16
+//   rewritten in place by gsr_render_fwd_combine (planes 0..5): the ABSOLUTE state (T, C0, C1, C2, D, A) of the pixel
+//     after this segment = what segment + 1 of the backward starts from.
+#define GSR_REC_PLANES 8
+#define GSR_CKPT_FLOATS (GSR_REC_PLANES * 256)
+#define GSR_REC_LAST (6 * 256)
+#define GSR_REC_HINT (7 * 256)
+#define GSR_REC_SKIPPED (-1.0f)     // plane 0 of a segment gsr_render_fwd_seg did not composite (every pixel had stopped, by its hints)
+// Depth-major work list of the segment forward: level c = the c-th segment of every tile that has one; levels
+// 0 .. GSR_NLEV-2 hold one segment per item, an item of the last level walks the rest of its tile's list.
+#define GSR_NLEV 1023
+// hint value from which a pixel has certainly stopped: 2^(-3403/256) = 0.9964e-4 < 1e-4 (margin >> fp32 rounding of the products)
+#define GSR_QSAT 3403u
 
 // per-Gaussian streaming side array for the scatter kernel (coalesced 16 B / lane)
 struct __attribute__((aligned(16))) EmitRec {
@@ -80,33 +92,6 @@ struct ViewSplit {
 // ---------------------------------------------------------------------------------------
 // wave-level helpers (DPP; gfx9 encodings)
 // ---------------------------------------------------------------------------------------
-#define DPP_ROW_SHR(n) (0x110 + (n))
-#define DPP_ROW_BCAST15 0x142
-#define DPP_ROW_BCAST31 0x143
-
-template <int CTRL, int ROW_MASK = 0xf>
-__device__ __forceinline__ float dpp_add(float v) {
-    // v + (v moved by CTRL), lanes without a source add 0
-    int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true);
-    return v + __int_as_float(moved);
-}
-
-// sum over the 64 lanes; the total is valid in lane 63 only
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-    v = dpp_add<DPP_ROW_SHR(1)>(v);
-    v = dpp_add<DPP_ROW_SHR(2)>(v);
-    v = dpp_add<DPP_ROW_SHR(4)>(v);
-    v = dpp_add<DPP_ROW_SHR(8)>(v);
-    {   // row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3
-        int m = __builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_ROW_BCAST15, 0xa, 0xf, false);
-        v = v + __int_as_float(m);
-    }
-    {
-        int m = __builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_ROW_BCAST31, 0xc, 0xf, false);
-        v = v + __int_as_float(m);
-    }
-    return v;
-}
 
 // ---- exact support test ---------------------------------------------------------------
 // Largest value over the pixel rectangle [x0,x1] x [y0,y1] of the (concave, log2-scaled) exponent
@@ -173,24 +158,6 @@ __device__ __forceinline__ float min_visible_power(float opac) {
     return -__builtin_amdgcn_logf(255.f * opac) - 1.0e-3f;     // v_log_f32 = log2; NaN/inf for opac <= 0 never passes ">="
 }
 
-// ---- transposing wave reduction (gfx950 v_permlane32_swap / v_permlane16_swap) -------------
-// red32(a,b): lanes of one half hold sum over {l, l^32} of a, the other half the same for b.
-__device__ __forceinline__ float red32(float a, float b) {
-    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-// red16(a,b): same one level down (16-lane rows): alternate rows hold a-sums and b-sums.
-__device__ __forceinline__ float red16(float a, float b) {
-    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-// the same data movement applied to integer tags (which quantity a lane ends up holding)
-__device__ __forceinline__ uint32_t tag32(uint32_t a, uint32_t b) {
-    return __builtin_amdgcn_permlane32_swap(a, b, false, false)[0];
-}
-__device__ __forceinline__ uint32_t tag16(uint32_t a, uint32_t b) {
-    return __builtin_amdgcn_permlane16_swap(a, b, false, false)[0];
-}
 #define DPP_ROW_ROR(n) (0x120 + (n))
 // every lane of a 16-lane row receives the row's total
 __device__ __forceinline__ float row_sum16(float v) {

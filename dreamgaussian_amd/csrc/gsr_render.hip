@@ -9,11 +9,11 @@
 // gathered from the per-Gaussian array), tests every record EXACTLY against its pixel block
 // (ellipse alpha >= 1/255 vs rectangle, gsr_device.h), compacts the survivors into a private LDS
 // stage (ballot + mbcnt) and runs the per-pixel loop over the survivors only, reading them back
-// with wave-uniform (broadcast) ds_read_b128. No workgroup barrier in the loops; a wave leaves
-// as soon as its 64 pixels are saturated.
+// with wave-uniform (broadcast) ds_read_b128. No workgroup barrier in the loops.
 //
-// Backward: front to back and depth-segmented (one workgroup per (bin, 128-entry segment), started
-// from the checkpoints the forward leaves). The default kernel, gsr_render_bwd_q2, walks FOUR
+// Forward AND backward are depth-segmented: one workgroup per (bin, segment of 2^seg_shift list
+// entries). The forward composites every segment on its own (K5a) and chains them per pixel (K5b);
+// the backward starts each segment from the absolute checkpoint K5b leaves. gsr_render_bwd_q2 walks FOUR
 // quad lists per wave (each 16-lane DPP row owns a 4x4 pixel quad) and replaces the cross-lane
 // reduction of the ten per-Gaussian sums by a transposition through LDS: pass 1 (lane = pixel)
 // stores the two per-(Gaussian, pixel) scalars everything else derives from, pass 2
@@ -33,321 +33,415 @@ __device__ __forceinline__ float splat_power(float qa, float qb, float qc, float
 
 #define GSR_RB 64   // list entries fetched per wave per round
 
-// =========================================================================================
-// K5: forward.
-// =========================================================================================
-__global__ void __launch_bounds__(256)
-gsr_render_fwd(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict__ recs,
-               const uint32_t* __restrict__ ids,
-               int W, int H, int gx,
-               float* __restrict__ out_color, float* __restrict__ out_depth,
-               float* __restrict__ out_alpha, float* __restrict__ final_T,
-               uint32_t* __restrict__ n_contrib, float* __restrict__ totals /*[5][H*W]*/,
-               float* __restrict__ ckpt, const uint32_t* __restrict__ tile_seg,
-               const uint32_t* __restrict__ tile_order /* heaviest tile first, or NULL */,
-               int seg_shift, uint32_t* __restrict__ tile_last /* max list position blended in the tile */,
-               const unsigned long long* __restrict__ counters, uint32_t capacity, ViewSplit vs) {
-    if (counters[2] > (unsigned long long)capacity) return;   // lists do not fit the scratch: the host repeats the tail (gsr_scatter)
-    __shared__ float4 stage[4][3][GSR_RB + 2];             // 12.4 KiB: [wave][field group][slot (+2 pad)]
-    const int tg = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;     // tile among all views' tiles
-    const int view = tg / vs.tiles_per_view;
-    if (!((vs.view_mask >> view) & 1u)) return;           // this view composites with the other forward kernel
-    const int tile = tg - view * vs.tiles_per_view;
-    const float* __restrict__ bg = vs.bg[view];
-    {
-        const size_t HWv = (size_t)W * H;
-        recs += (size_t)view * vs.N;
-        out_color += view * 3 * HWv; out_depth += view * HWv; out_alpha += view * HWv;
-        final_T += view * vs.img_stride; n_contrib += view * vs.img_stride; totals += view * vs.img_stride;
-    }
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const int bx = (tile % gx) * GSR_TILE + (wave & 1) * 8;
-    const int by = (tile / gx) * GSR_TILE + (wave >> 1) * 8;
-    if (bx >= W || by >= H) return;                       // whole block outside the image
-    const int px = bx + (lane & 7), py = by + (lane >> 3);
-    const bool inside = (px < W) && (py < H);
-    const float pxf = (float)px, pyf = (float)py;
-    const uint32_t start = tile_off[tg], end = tile_off[tg + 1];
-    float4* __restrict__ sa = stage[wave][0];
-    float4* __restrict__ sb = stage[wave][1];
-    float4* __restrict__ sc = stage[wave][2];
+// agent-scope relaxed accesses (global_load / global_store ... sc1): the hint words other workgroups of the SAME launch
+// read; they carry no ordering and need none (every value ever stored at such an address is a valid hint or a tag mismatch)
+__device__ __forceinline__ uint32_t hint_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void hint_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long hint_load64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void hint_store64(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-    float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, A = 0.f;
-    uint32_t last = 0;
-    bool done = !inside;
-
-    // ea = x y qa qb | eb = qc opac r g | ec = b depth pos -
-#define GSR_FWD_ENTRY(ea, eb, ec, valid)                                                       \
+// One blended (pixel, Gaussian) pair of a segment composited on its own. T, C0, C1, C2, D, A, last, done are the lane's
+// running state; `gate` = the transmittance in front of the segment (1 in gsr_render_fwd_seg; the pixel's running product
+// in the exact walk of gsr_render_fwd_combine): the pixel stops at the first entry with gate * T' (1 - alpha) < 1e-4, which
+// is not blended. Both kernels run the SAME sequence of roundings on (T', C', ...) -- the combine's walk
+// reproduces the segment kernel's numbers bit for bit up to its own stopping point.
+//   ea = x y qa qb | eb = qc opac r g | ec = b depth - - ; kpos = 1-based list position
+#define GSR_COMPOSITE(ea, eb, ec, kpos, valid, gate, keepT)                                     \
     {                                                                                          \
         const float dx = ea.x - pxf, dy = ea.y - pyf;                                          \
         const float power = splat_power(ea.z, ea.w, eb.x, dx, dy);            /* log2 units */ \
         const float alpha = fminf(0.99f, eb.y * fast_exp2(power));                             \
         const bool ok = (valid) && !done && (power <= 0.f) && (alpha >= (1.0f / 255.0f));      \
-        const float test_T = T * (1.f - alpha);                                                \
-        const bool stop = ok && (test_T < 0.0001f);                                            \
+        const float test_T = __fmul_rn(T, 1.f - alpha);                                        \
+        const bool stop = ok && (__fmul_rn(gate, test_T) < 0.0001f);                           \
         const bool acc = ok && !stop;                                                          \
         const float w = acc ? alpha * T : 0.f;                                                 \
         C0 = fmaf(eb.z, w, C0); C1 = fmaf(eb.w, w, C1); C2 = fmaf(ec.x, w, C2);                \
         D = fmaf(ec.y, w, D); A += w;                                                          \
-        T = acc ? test_T : T;                                                                  \
-        last = acc ? __float_as_uint(ec.z) : last;                                             \
-        done = done || stop;                                                                   \
-    }
-
-    const uint32_t seg_slot0 = tile_seg[tg];
-    // padding slots are read (never used): keep them finite so that 0 * garbage stays 0
-    for (int q = lane; q < 3 * (GSR_RB + 2); q += 64) (&stage[wave][0][0])[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    wave_lds_handoff();
-    // Three-deep fetch pipeline: while round r is composited, the records of rounds r+1 and r+2 and the
-    // list entries of round r+3 are in flight (the gathers miss the XCD's L2 half of the time: one round of
-    // compositing, ~1 us, does not cover them; registers are free here -- the kernel never fills the wave slots).
-    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra, na = ra, nb = ra, nc = ra;
-    uint32_t id_next = 0;                                  // list entry of round r+2 (r+3 after the loads below)
-    if (start + lane < end) {
-        const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + ids[start + lane]);
-        ra = p[0]; rb = p[1]; rc = p[2];
-    }
-    if (start + GSR_RB + lane < end) {
-        const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + ids[start + GSR_RB + lane]);
-        na = p[0]; nb = p[1]; nc = p[2];
-    }
-    if (start + 2 * GSR_RB + lane < end) id_next = ids[start + 2 * GSR_RB + lane];
-    for (uint32_t base = start; base < end; base += GSR_RB) {
-        if (__ballot(!done) == 0ull) break;
-        float4 ma = make_float4(0.f, 0.f, 0.f, 0.f), mb = ma, mc = ma;
-        uint32_t id_next2 = 0;
-        {
-            const uint32_t i2 = base + 2 * GSR_RB + lane;
-            if (i2 < end) {
-                const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + id_next);
-                ma = p[0]; mb = p[1]; mc = p[2];
-            }
-            const uint32_t i3 = base + 3 * GSR_RB + lane;
-            if (i3 < end) id_next2 = ids[i3];
-        }
-        const uint32_t rel = base - start;
-        if (rel != 0u && (rel & ((1u << seg_shift) - 1u)) == 0u) {    // segment cut: checkpoint for the backward
-            float* c = ckpt + (size_t)(seg_slot0 + (rel >> seg_shift) - 1u) * GSR_CKPT_FLOATS + (wave * 64 + lane);
-            c[0] = T; c[256] = C0; c[512] = C1; c[768] = C2; c[1024] = D; c[1280] = A;
-        }
-        const uint32_t i = base + lane;
-        bool hit = false;
-        if (i < end)      // can alpha reach 1/255 anywhere in this wave's 8x8 block?
-            hit = rect_max_power(ra.x, ra.y, ra.z, ra.w, rb.x, (float)bx, (float)(bx + 7), (float)by, (float)(by + 7))
-                  >= min_visible_power(rb.y);
-        const unsigned long long mask = __ballot(hit);
-        if (mask != 0ull) {
-            const int n = __popcll(mask);
-            if (hit) {
-                const uint32_t pos = lanes_below(mask);
-                rc.z = __uint_as_float(i - start + 1);    // 1-based list position replaces the box
-                sa[pos] = ra; sb[pos] = rb; sc[pos] = rc;
-            }
-            wave_lds_handoff();
-            float4 e0a = sa[0], e0b = sb[0], e0c = sc[0];
-            // two entries per trip, both unconditional (the second is masked off on an odd tail) so
-            // that the body stays one basic block and the LDS reads are issued ahead of their use
-            for (int j = 0; j < n; j += 2) {              // slots n, n+1 are padding: read, masked
-                const float4 e1a = sa[j + 1], e1b = sb[j + 1], e1c = sc[j + 1];   // in flight during entry j
-                GSR_FWD_ENTRY(e0a, e0b, e0c, true)
-                e0a = sa[j + 2]; e0b = sb[j + 2]; e0c = sc[j + 2];               // in flight during entry j+1
-                GSR_FWD_ENTRY(e1a, e1b, e1c, j + 1 < n)
-            }
-            wave_lds_handoff();                           // reads above precede the next round's writes
-        }
-        ra = na; rb = nb; rc = nc; na = ma; nb = mb; nc = mc; id_next = id_next2;
-    }
-#undef GSR_FWD_ENTRY
-    {   // how deep the backward has to walk this tile's list
-        const uint32_t wl = wave_max_u32(last);
-        if (lane == 0 && wl != 0u) atomicMax(&tile_last[tg], wl);
-    }
-    if (inside) {
-        const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
-        final_T[pix] = T;
-        n_contrib[pix] = last;
-        out_color[pix] = fmaf(T, bg[0], C0);
-        out_color[HW + pix] = fmaf(T, bg[1], C1);
-        out_color[2 * HW + pix] = fmaf(T, bg[2], C2);
-        out_depth[pix] = D;
-        out_alpha[pix] = A;
-        totals[pix] = C0; totals[HW + pix] = C1; totals[2 * HW + pix] = C2;   // sums without background
-        totals[3 * HW + pix] = D; totals[4 * HW + pix] = A;
-    }
-}
-
-// -----------------------------------------------------------------------------------------
-// K5 with quad lists (GSR_FWD=q): the forward counterpart of gsr_render_bwd_q2's pass 1. Every 16-lane row of a
-// wave owns a 4x4 pixel quad with its own list of staged slots (exact ellipse-vs-quad tests, quad_max_powers);
-// the wave loops to the longest of the four lists, and a quad whose sixteen pixels have all stopped drops out.
-// Same arithmetic per (pixel, Gaussian) as gsr_render_fwd, every rounding pinned (splat_power, explicit fmaf):
-// bit-identical images (tools/fwd_variant_hash.py).
-// -----------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-gsr_render_fwd_q(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict__ recs,
-                 const uint32_t* __restrict__ ids,
-                 int W, int H, int gx,
-                 float* __restrict__ out_color, float* __restrict__ out_depth,
-                 float* __restrict__ out_alpha, float* __restrict__ final_T,
-                 uint32_t* __restrict__ n_contrib, float* __restrict__ totals /*[5][H*W]*/,
-                 float* __restrict__ ckpt, const uint32_t* __restrict__ tile_seg,
-                 const uint32_t* __restrict__ tile_order /* heaviest tile first, or NULL */,
-                 int seg_shift, uint32_t* __restrict__ tile_last /* max list position blended in the tile */,
-               const unsigned long long* __restrict__ counters, uint32_t capacity, ViewSplit vs) {
-    if (counters[2] > (unsigned long long)capacity) return;   // lists do not fit the scratch: the host repeats the tail (gsr_scatter)
-    __shared__ float4 stage[4][3][GSR_RB];                                   // slot = fetching lane
-    __shared__ __attribute__((aligned(8))) uint8_t qlist[4][4][80];          // [wave][quad][k] = staged slot of the quad's k-th entry
-    const int tg = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;     // tile among all views' tiles
-    const int view = tg / vs.tiles_per_view;
-    if (!((vs.view_mask >> view) & 1u)) return;           // this view composites with the other forward kernel
-    const int tile = tg - view * vs.tiles_per_view;
-    const float* __restrict__ bg = vs.bg[view];
-    {
-        const size_t HWv = (size_t)W * H;
-        recs += (size_t)view * vs.N;
-        out_color += view * 3 * HWv; out_depth += view * HWv; out_alpha += view * HWv;
-        final_T += view * vs.img_stride; n_contrib += view * vs.img_stride; totals += view * vs.img_stride;
-    }
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const int row = lane >> 4, l15 = lane & 15;
-    const int bx = (tile % gx) * GSR_TILE + (wave & 1) * 8;
-    const int by = (tile / gx) * GSR_TILE + (wave >> 1) * 8;
-    if (bx >= W || by >= H) return;                       // whole block outside the image
-    const int lx = (row & 1) * 4 + (l15 & 3), ly = (row >> 1) * 4 + (l15 >> 2);
-    const int px = bx + lx, py = by + ly;
-    const bool inside = (px < W) && (py < H);
-    const float pxf = (float)px, pyf = (float)py;
-    const int cidx = wave * 64 + ly * 8 + lx;             // checkpoint slot (row-major 8x8: the backward's layout)
-    const uint32_t start = tile_off[tg], end = tile_off[tg + 1];
-    float4* __restrict__ sa = stage[wave][0];
-    float4* __restrict__ sb = stage[wave][1];
-    float4* __restrict__ sc = stage[wave][2];
-    const uint8_t* __restrict__ ql = qlist[wave][row];
-    for (int q = lane; q < 4 * 80 / 4; q += 64) reinterpret_cast<uint32_t*>(&qlist[wave][0][0])[q] = 0u;   // stale reads stay inside the stage
-    for (int q = lane; q < 3 * GSR_RB; q += 64) (&stage[wave][0][0])[q] = make_float4(0.f, 0.f, 0.f, 0.f);  // ... and finite
-    wave_lds_handoff();
-
-    float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, A = 0.f;
-    uint32_t last = 0;
-    bool done = !inside;
-    const float bx0 = (float)bx, by0 = (float)by;
-
-    // ea = x y qa qb | eb = qc opac r g | ec = b depth - - ; kpos = 1-based list position (row-uniform)
-#define GSR_FWDQ_ENTRY(ea, eb, ec, kpos, valid)                                                \
-    {                                                                                          \
-        const float dx = ea.x - pxf, dy = ea.y - pyf;                                          \
-        const float power = splat_power(ea.z, ea.w, eb.x, dx, dy);            /* log2 units */ \
-        const float alpha = fminf(0.99f, eb.y * fast_exp2(power));                             \
-        const bool ok = (valid) && !done && (power <= 0.f) && (alpha >= (1.0f / 255.0f));      \
-        const float test_T = T * (1.f - alpha);                                                \
-        const bool stop = ok && (test_T < 0.0001f);                                            \
-        const bool acc = ok && !stop;                                                          \
-        const float w = acc ? alpha * T : 0.f;                                                 \
-        C0 = fmaf(eb.z, w, C0); C1 = fmaf(eb.w, w, C1); C2 = fmaf(ec.x, w, C2);                \
-        D = fmaf(ec.y, w, D); A += w;                                                          \
-        T = acc ? test_T : T;                                                                  \
+        T = (keepT ? acc : ok) ? test_T : T;                                                   \
         last = acc ? (kpos) : last;                                                            \
         done = done || stop;                                                                   \
     }
 
-    const uint32_t seg_slot0 = tile_seg[tg];
-    // three-deep fetch pipeline as gsr_render_fwd
-    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra, na = ra, nb = ra, nc = ra;
-    uint32_t id_next = 0;
-    if (start + lane < end) {
-        const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + ids[start + lane]);
-        ra = p[0]; rb = p[1]; rc = p[2];
+// =========================================================================================
+// K5a: forward, one workgroup per (tile, depth segment).
+//
+// A tile's depth-sorted list used to be one serial walk per 8x8 pixel block: at most 4 waves per tile, the heaviest
+// tile set the kernel's length and a 5k-Gaussian scene kept half the SIMDs empty. Here every segment of 2^seg_shift
+// entries is composited on its own workgroup with transmittance 1 coming in and leaves, per pixel, the segment's own
+// (T', C', D', A', last); gsr_render_fwd_combine chains the segments per pixel (T = product of the T', C = sum of
+// prefix * C') and re-walks, exactly, the ONE segment in which a pixel's running transmittance crosses the 1e-4 stop.
+//
+// Items run depth-major (gsr_tile_scan): all first segments, then all second segments, ... Most pixels of a dense
+// scene stop after a third of their list; a segment behind that point is not composited: plane 7 of a record carries a
+// per-pixel HINT, an upper bound of the transmittance after the segment (u16 fixed-point log2 | 16-bit launch tag), built
+// from whichever predecessors have already published theirs (agent-scope relaxed loads; a segment that sees nothing
+// assumes 1), and a per-(tile, wave) word names the segment from which all 64 pixels have stopped. Hints only ever
+// OVER-estimate a transmittance. A wave whose 64 pixels have all stopped writes GSR_REC_SKIPPED instead of compositing.
+// Nothing depends on a hint being seen or being right: a pixel that reaches a skipped record alive (stale words of an
+// earlier launch with the same 16-bit tag) has that segment walked by the combine kernel -- same result, bit for bit.
+//
+// QUAD = false: one list per 8x8 block (lane = pixel, row-major). QUAD = true: every 16-lane row owns a 4x4 quad with
+// its own list of staged slots (exact ellipse-vs-quad tests, quad_max_powers) -- fewer masked lanes when splats are small
+// against the block. Same arithmetic per (pixel, Gaussian), every rounding pinned: bit-identical records.
+// =========================================================================================
+template <bool QUAD>
+__global__ void __launch_bounds__(256)
+gsr_render_fwd_seg(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict__ recs,
+                   const uint32_t* __restrict__ ids, int W, int H, int gx,
+                   float* __restrict__ rec_base, const uint32_t* __restrict__ tile_seg,
+                   const uint32_t* __restrict__ order, const uint32_t* __restrict__ level_off,
+                   int seg_shift, unsigned long long* __restrict__ sat /* [tiles][4] */, uint32_t epoch,
+                   int hint_mode /* 0 = on; 1 = off (no hint is read: every segment is composited); 2 = TEST: every
+                                    segment behind a tile's first is skipped, the combine kernel walks them all */,
+                   const unsigned long long* __restrict__ counters, uint32_t capacity, uint32_t maxc_cap, ViewSplit vs) {
+    // lists that do not fit the scratch, or longer than the sort kernels that were launched cover: the host repeats the tail
+    if (counters[2] > (unsigned long long)capacity || counters[3] > (unsigned long long)maxc_cap) return;
+    __shared__ float4 stage[4][3][GSR_RB + 2];             // [wave][field group][slot (+2 pad)]
+    __shared__ __attribute__((aligned(8))) uint8_t qlist[QUAD ? 4 : 1][4][80];   // QUAD: [wave][quad][k] = staged slot of the quad's k-th entry
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    // ---- which (level, tile) is this item?
+    const uint32_t k = blockIdx.x;
+    if (k >= level_off[GSR_NLEV]) return;                 // = the item total
+    uint32_t c, rank;
+    {
+        const uint32_t a = level_off[lane * 16];
+        const int coarse = __popcll(__ballot(a <= k)) - 1;            // level_off[0] = 0 <= k
+        const uint32_t b = level_off[coarse * 16 + (lane & 15)];
+        const int fine = __popcll(__ballot(lane < 16 && b <= k)) - 1;
+        c = (uint32_t)(coarse * 16 + fine);
+        rank = k - (uint32_t)__builtin_amdgcn_readlane((int)b, fine);
     }
-    if (start + GSR_RB + lane < end) {
-        const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + ids[start + GSR_RB + lane]);
-        na = p[0]; nb = p[1]; nc = p[2];
-    }
-    if (start + 2 * GSR_RB + lane < end) id_next = ids[start + 2 * GSR_RB + lane];
-    for (uint32_t base = start; base < end; base += GSR_RB) {
-        const unsigned long long alive = __ballot(!done);
-        if (alive == 0ull) break;
-        float4 ma = make_float4(0.f, 0.f, 0.f, 0.f), mb = ma, mc = ma;
-        uint32_t id_next2 = 0;
-        {
-            const uint32_t i2 = base + 2 * GSR_RB + lane;
-            if (i2 < end) {
-                const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + id_next);
-                ma = p[0]; mb = p[1]; mc = p[2];
+    const int tg = (int)order[rank];                      // tile among all views' tiles
+    const int view = tg / vs.tiles_per_view;
+    if (!((vs.view_mask >> view) & 1u)) return;           // this view composites with the other instantiation
+    const int tile = tg - view * vs.tiles_per_view;
+    recs += (size_t)view * vs.N;
+    const int bx = (tile % gx) * GSR_TILE + (wave & 1) * 8;
+    const int by = (tile / gx) * GSR_TILE + (wave >> 1) * 8;
+    if (bx >= W || by >= H) return;                       // whole block outside the image (the combine skips it too)
+    const int row = lane >> 4, l15 = lane & 15;
+    const int lx = QUAD ? (row & 1) * 4 + (l15 & 3) : (lane & 7), ly = QUAD ? (row >> 1) * 4 + (l15 >> 2) : (lane >> 3);
+    const int px = bx + lx, py = by + ly;
+    const bool inside = (px < W) && (py < H);
+    const float pxf = (float)px, pyf = (float)py;
+    const int cidx = wave * 64 + ly * 8 + lx;             // record slot of this pixel (row-major 8x8 per wave)
+    const uint32_t start = tile_off[tg];
+    const uint32_t n = tile_off[tg + 1] - start;
+    const uint32_t nseg = (n + (1u << seg_shift) - 1u) >> seg_shift;
+    const uint32_t c_end = c == (uint32_t)(GSR_NLEV - 1) ? nseg : c + 1u;   // the last level walks the rest of the list
+    float* __restrict__ rec0 = rec_base + (size_t)tile_seg[tg] * GSR_CKPT_FLOATS + cidx;
+    unsigned long long* __restrict__ satw = sat + (size_t)tg * 4 + wave;
+    const uint32_t tag = epoch << 16;
+    float4* __restrict__ sa = stage[wave][0];
+    float4* __restrict__ sb = stage[wave][1];
+    float4* __restrict__ sc = stage[wave][2];
+    const float bx0 = (float)bx, by0 = (float)by;
+    // padding / stale slots are read (never used): keep them finite so that 0 * garbage stays 0
+    for (int q = lane; q < 3 * (GSR_RB + 2); q += 64) (&stage[wave][0][0])[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (QUAD) for (int q = lane; q < 4 * 80 / 4; q += 64) reinterpret_cast<uint32_t*>(&qlist[QUAD ? wave : 0][0][0])[q] = 0u;
+    wave_lds_handoff();
+
+    for (uint32_t s = c; s < c_end; ++s) {
+        float* __restrict__ rec = rec0 + (size_t)s * GSR_CKPT_FLOATS;
+        const uint32_t lo = s << seg_shift, hi = min(lo + (1u << seg_shift), n);
+        // the list entries of the first round travel while the hints are read
+        uint32_t id0 = 0;
+        if (lo + lane < hi) id0 = ids[start + lo + lane];
+        uint32_t qbest = 0;
+        if (s > 0 && hint_mode == 2) { rec[0] = GSR_REC_SKIPPED; continue; }
+        if (s > 0 && hint_mode == 0) {
+            const unsigned long long sw = hint_load64(satw);
+            const uint32_t* hp = reinterpret_cast<const uint32_t*>(rec) + GSR_REC_HINT;
+            const uint32_t h1 = hint_load(hp - GSR_CKPT_FLOATS);
+            const uint32_t h2 = s >= 2 ? hint_load(hp - 2 * GSR_CKPT_FLOATS) : 0u;
+            const uint32_t h3 = s >= 3 ? hint_load(hp - 3 * GSR_CKPT_FLOATS) : 0u;
+            qbest = (h1 & 0xffff0000u) == tag ? (h1 & 0xffffu) : 0u;
+            qbest = max(qbest, (h2 & 0xffff0000u) == tag ? (h2 & 0xffffu) : 0u);
+            qbest = max(qbest, (h3 & 0xffff0000u) == tag ? (h3 & 0xffffu) : 0u);
+            if (!inside) qbest = 0xffffu;
+            const bool sat_hit = (uint32_t)(sw >> 32) == epoch && (uint32_t)sw <= s;
+            if (sat_hit || __ballot(qbest < GSR_QSAT) == 0ull) {       // every pixel of the block has stopped in front of this segment
+                rec[0] = GSR_REC_SKIPPED;
+                hint_store(reinterpret_cast<uint32_t*>(rec) + GSR_REC_HINT, tag | max(qbest, GSR_QSAT));
+                if (!sat_hit && lane == 0) hint_store64(satw, ((unsigned long long)epoch << 32) | s);
+                continue;
             }
-            const uint32_t i3 = base + 3 * GSR_RB + lane;
-            if (i3 < end) id_next2 = ids[i3];
         }
-        const uint32_t rel = base - start;
-        if (rel != 0u && (rel & ((1u << seg_shift) - 1u)) == 0u) {    // segment cut: checkpoint for the backward
-            float* c = ckpt + (size_t)(seg_slot0 + (rel >> seg_shift) - 1u) * GSR_CKPT_FLOATS + cidx;
-            c[0] = T; c[256] = C0; c[512] = C1; c[768] = C2; c[1024] = D; c[1280] = A;
+        float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, A = 0.f;
+        uint32_t last = 0;
+        bool done = !inside;
+        float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na, nc = na;
+        if (lo + lane < hi) {
+            const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + id0);
+            na = p[0]; nb = p[1]; nc = p[2];
         }
-        const uint32_t i = base + lane;
-        bool h0 = false, h1 = false, h2 = false, h3 = false;
-        if (i < end) {
-            const float thr = min_visible_power(rb.y);
-            float qp[4];
-            quad_max_powers(ra.x, ra.y, ra.z, ra.w, rb.x, bx0, by0, qp);
-            // a quad whose pixels have all stopped takes no more entries
-            h0 = ((alive & 0x000000000000ffffull) != 0ull) && qp[0] >= thr;
-            h1 = ((alive & 0x00000000ffff0000ull) != 0ull) && qp[1] >= thr;
-            h2 = ((alive & 0x0000ffff00000000ull) != 0ull) && qp[2] >= thr;
-            h3 = ((alive & 0xffff000000000000ull) != 0ull) && qp[3] >= thr;
-        }
-        const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
-        if ((m0 | m1 | m2 | m3) != 0ull) {
-            if (h0 | h1 | h2 | h3) { sa[lane] = ra; sb[lane] = rb; sc[lane] = rc; }
-            if (h0) qlist[wave][0][lanes_below(m0)] = (uint8_t)lane;
-            if (h1) qlist[wave][1][lanes_below(m1)] = (uint8_t)lane;
-            if (h2) qlist[wave][2][lanes_below(m2)] = (uint8_t)lane;
-            if (h3) qlist[wave][3][lanes_below(m3)] = (uint8_t)lane;
-            const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
-            const int nmax = max(max(n0, n1), max(n2, n3));
-            const int nmine = row == 0 ? n0 : (row == 1 ? n1 : (row == 2 ? n2 : n3));
-            const uint32_t pos1 = rel + 1u;               // 1-based list position of staged slot 0
-            wave_lds_handoff();
-            for (int jb = 0; jb < nmax; jb += 8) {
-                const uint2 sl = *reinterpret_cast<const uint2*>(ql + jb);
-                uint32_t slot[8];
+        for (uint32_t pos0 = lo; pos0 < hi; pos0 += GSR_RB) {          // 0-based positions pos0 .. pos0+63
+            float4 ra = na, rb = nb, rc = nc;
+            const uint32_t i = pos0 + lane;
+            if (i + GSR_RB < hi) {                                     // next round's records: in flight during this round
+                const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + ids[start + i + GSR_RB]);
+                na = p[0]; nb = p[1]; nc = p[2];
+            }
+            const unsigned long long alive = __ballot(!done);
+            if (alive == 0ull) break;
+            if (!QUAD) {
+                bool hit = false;
+                if (i < hi)      // can alpha reach 1/255 anywhere in this wave's 8x8 block?
+                    hit = rect_max_power(ra.x, ra.y, ra.z, ra.w, rb.x, bx0, bx0 + 7.f, by0, by0 + 7.f) >= min_visible_power(rb.y);
+                const unsigned long long mask = __ballot(hit);
+                if (mask == 0ull) continue;
+                const int nhit = __popcll(mask);
+                if (hit) {
+                    const uint32_t pos = lanes_below(mask);
+                    rc.z = __uint_as_float(i + 1u);       // 1-based list position replaces the box
+                    sa[pos] = ra; sb[pos] = rb; sc[pos] = rc;
+                }
+                wave_lds_handoff();
+                float4 e0a = sa[0], e0b = sb[0], e0c = sc[0];
+                // two entries per trip, both unconditional (the second is masked off on an odd tail) so
+                // that the body stays one basic block and the LDS reads are issued ahead of their use
+                for (int j = 0; j < nhit; j += 2) {       // slots nhit, nhit+1 are padding: read, masked
+                    const float4 e1a = sa[j + 1], e1b = sb[j + 1], e1c = sc[j + 1];   // in flight during entry j
+                    GSR_COMPOSITE(e0a, e0b, e0c, __float_as_uint(e0c.z), true, 1.f, false)
+                    e0a = sa[j + 2]; e0b = sb[j + 2]; e0c = sc[j + 2];               // in flight during entry j+1
+                    GSR_COMPOSITE(e1a, e1b, e1c, __float_as_uint(e1c.z), j + 1 < nhit, 1.f, false)
+                }
+                wave_lds_handoff();                       // reads above precede the next round's writes
+            } else {
+                bool h0 = false, h1 = false, h2 = false, h3 = false;
+                if (i < hi) {
+                    const float thr = min_visible_power(rb.y);
+                    float qp[4];
+                    quad_max_powers(ra.x, ra.y, ra.z, ra.w, rb.x, bx0, by0, qp);
+                    // a quad whose pixels have all stopped takes no more entries
+                    h0 = ((alive & 0x000000000000ffffull) != 0ull) && qp[0] >= thr;
+                    h1 = ((alive & 0x00000000ffff0000ull) != 0ull) && qp[1] >= thr;
+                    h2 = ((alive & 0x0000ffff00000000ull) != 0ull) && qp[2] >= thr;
+                    h3 = ((alive & 0xffff000000000000ull) != 0ull) && qp[3] >= thr;
+                }
+                const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
+                if ((m0 | m1 | m2 | m3) == 0ull) continue;
+                uint8_t (*qlw)[80] = qlist[QUAD ? wave : 0];
+                if (h0 | h1 | h2 | h3) { sa[lane] = ra; sb[lane] = rb; sc[lane] = rc; }
+                if (h0) qlw[0][lanes_below(m0)] = (uint8_t)lane;
+                if (h1) qlw[1][lanes_below(m1)] = (uint8_t)lane;
+                if (h2) qlw[2][lanes_below(m2)] = (uint8_t)lane;
+                if (h3) qlw[3][lanes_below(m3)] = (uint8_t)lane;
+                const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
+                const int nmax = max(max(n0, n1), max(n2, n3));
+                const int nmine = row == 0 ? n0 : (row == 1 ? n1 : (row == 2 ? n2 : n3));
+                const uint32_t pos1 = pos0 + 1u;          // 1-based list position of staged slot 0
+                const uint8_t* __restrict__ ql = qlw[row];
+                wave_lds_handoff();
+                for (int jb = 0; jb < nmax; jb += 8) {
+                    const uint2 sl = *reinterpret_cast<const uint2*>(ql + jb);
+                    uint32_t slot[8];
 #pragma unroll
-                for (int b = 0; b < 8; ++b) slot[b] = ((b < 4 ? sl.x : sl.y) >> (8 * (b & 3))) & 0xffu;
-                // two entries per trip in two fixed register sets (a rotating set cost four 64-bit moves per entry); the
-                // second is masked off past the row's own list (nmine <= nmax; stale slots read staged records)
-                float4 e0a = sa[slot[0]], e0b = sb[slot[0]], e0c = sc[slot[0]];
+                    for (int b = 0; b < 8; ++b) slot[b] = ((b < 4 ? sl.x : sl.y) >> (8 * (b & 3))) & 0xffu;
+                    // two entries per trip in two fixed register sets; the second is masked off past the row's own
+                    // list (nmine <= nmax; stale slots read staged records)
+                    float4 e0a = sa[slot[0]], e0b = sb[slot[0]], e0c = sc[slot[0]];
 #pragma unroll
-                for (int b = 0; b < 8; b += 2) {
-                    if (jb + b < nmax) {                  // wave-uniform
-                        const float4 e1a = sa[slot[b + 1]], e1b = sb[slot[b + 1]], e1c = sc[slot[b + 1]];   // in flight during entry b
-                        GSR_FWDQ_ENTRY(e0a, e0b, e0c, pos1 + slot[b], jb + b < nmine)
-                        if (b + 2 < 8) { e0a = sa[slot[b + 2]]; e0b = sb[slot[b + 2]]; e0c = sc[slot[b + 2]]; }   // in flight during entry b+1
-                        GSR_FWDQ_ENTRY(e1a, e1b, e1c, pos1 + slot[b + 1], jb + b + 1 < nmine)
+                    for (int b = 0; b < 8; b += 2) {
+                        if (jb + b < nmax) {              // wave-uniform
+                            const float4 e1a = sa[slot[b + 1]], e1b = sb[slot[b + 1]], e1c = sc[slot[b + 1]];   // in flight during entry b
+                            GSR_COMPOSITE(e0a, e0b, e0c, pos1 + slot[b], jb + b < nmine, 1.f, false)
+                            if (b + 2 < 8) { e0a = sa[slot[b + 2]]; e0b = sb[slot[b + 2]]; e0c = sc[slot[b + 2]]; }   // in flight during entry b+1
+                            GSR_COMPOSITE(e1a, e1b, e1c, pos1 + slot[b + 1], jb + b + 1 < nmine, 1.f, false)
+                        }
                     }
                 }
+                wave_lds_handoff();                       // reads above precede the next round's writes
             }
-            wave_lds_handoff();                           // reads above precede the next round's writes
         }
-        ra = na; rb = nb; rc = nc; na = ma; nb = mb; nc = mc; id_next = id_next2;
+        // ---- the segment's record
+        rec[0] = T; rec[256] = C0; rec[512] = C1; rec[768] = C2; rec[1024] = D; rec[1280] = A;
+        reinterpret_cast<uint32_t*>(rec)[GSR_REC_LAST] = last;
+        // ---- its hint: the best bound of the transmittance in front (as seen now) times this segment's T', rounded UP
+        // (v_log_f32 is good to 1 ulp: the 0.02 steps of 1/256 cover it many times over)
+        if (hint_mode != 0) continue;
+        if (s > 0) {
+            const uint32_t h1 = hint_load(reinterpret_cast<const uint32_t*>(rec) + GSR_REC_HINT - GSR_CKPT_FLOATS);
+            qbest = max(qbest, (h1 & 0xffff0000u) == tag ? (h1 & 0xffffu) : 0u);
+        }
+        uint32_t q = 0xffffu;
+        if (inside && !done) {
+            const float dq = floorf(fmaf(-256.f, __builtin_amdgcn_logf(T), -0.02f));          // T in (0, 1]: dq >= -0.02
+            q = min(qbest + (uint32_t)fmaxf(dq, 0.f), 0xffffu);
+        }
+        hint_store(reinterpret_cast<uint32_t*>(rec) + GSR_REC_HINT, tag | q);
+        if (__ballot(q < GSR_QSAT) == 0ull && lane == 0) hint_store64(satw, ((unsigned long long)epoch << 32) | (s + 1u));
     }
-#undef GSR_FWDQ_ENTRY
-    {   // how deep the backward has to walk this tile's list
-        const uint32_t wl = wave_max_u32(last);
-        if (lane == 0 && wl != 0u) atomicMax(&tile_last[tg], wl);
+}
+template __global__ void gsr_render_fwd_seg<false>(const uint32_t*, const SplatRec*, const uint32_t*, int, int, int, float*, const uint32_t*,
+                                                   const uint32_t*, const uint32_t*, int, unsigned long long*, uint32_t, int,
+                                                   const unsigned long long*, uint32_t, uint32_t, ViewSplit);
+template __global__ void gsr_render_fwd_seg<true>(const uint32_t*, const SplatRec*, const uint32_t*, int, int, int, float*, const uint32_t*,
+                                                  const uint32_t*, const uint32_t*, int, unsigned long long*, uint32_t, int,
+                                                  const unsigned long long*, uint32_t, uint32_t, ViewSplit);
+
+// =========================================================================================
+// K5b: forward, chaining the segments. One workgroup per tile, wave = 8x8 block, lane = pixel (row-major).
+//
+// Per pixel, front to back over the tile's segment records: P = running transmittance (1 at the start).
+//   fl(P * T'_s) >= 1e-4 : no entry of segment s stops the pixel (T' only falls inside a segment and fl(P * .) is
+//                          monotone): C += P * C'_s, ..., P = fl(P * T'_s)                       [a handful of FMAs]
+//   fl(P * T'_s) <  1e-4 : the pixel stops INSIDE segment s: the wave walks that segment exactly (the same
+//                          arithmetic as gsr_render_fwd_seg with P as the gate of the stop test) for its stopping
+//                          lanes -- one segment per pixel, most lanes of a wave in the same one or two segments
+//   record skipped       : the same walk, for the whole segment (only reachable through a wrong hint; see K5a)
+// and writes back, in place, the pixel's ABSOLUTE state after every segment it passes: the checkpoint segment s + 1 of
+// the backward starts from. Then the image outputs, the tile's deepest blended position and -- what used to be two
+// more kernels in front of the backward -- the tile's entries of the backward's work list (one atomic per tile).
+// =========================================================================================
+__global__ void __launch_bounds__(256)
+gsr_render_fwd_combine(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict__ recs,
+                       const uint32_t* __restrict__ ids, int W, int H, int gx,
+                       float* __restrict__ out_color, float* __restrict__ out_depth,
+                       float* __restrict__ out_alpha, float* __restrict__ final_T,
+                       uint32_t* __restrict__ n_contrib, float* __restrict__ totals /*[5][H*W]*/,
+                       float* __restrict__ rec_base, const uint32_t* __restrict__ tile_seg,
+                       const uint32_t* __restrict__ order, int seg_shift,
+                       uint32_t* __restrict__ tile_last /* max list position blended in the tile */,
+                       uint32_t* __restrict__ plan_off, uint32_t* __restrict__ plan_tile,
+                       unsigned long long* __restrict__ plan_total, uint32_t plan_cap,
+                       const unsigned long long* __restrict__ counters, uint32_t capacity, uint32_t maxc_cap, ViewSplit vs) {
+    if (counters[2] > (unsigned long long)capacity || counters[3] > (unsigned long long)maxc_cap) return;
+    __shared__ float4 stage[4][3][GSR_RB + 2];
+    __shared__ uint32_t wl[4];
+    __shared__ uint32_t plan_base;
+    const int tg = (int)order[blockIdx.x];                // heaviest tiles first
+    const int view = tg / vs.tiles_per_view;
+    const int tile = tg - view * vs.tiles_per_view;
+    const float* __restrict__ bg = vs.bg[view];
+    {
+        const size_t HWv = (size_t)W * H;
+        recs += (size_t)view * vs.N;
+        out_color += view * 3 * HWv; out_depth += view * HWv; out_alpha += view * HWv;
+        final_T += view * vs.img_stride; n_contrib += view * vs.img_stride; totals += view * vs.img_stride;
+    }
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int bx = (tile % gx) * GSR_TILE + (wave & 1) * 8;
+    const int by = (tile / gx) * GSR_TILE + (wave >> 1) * 8;
+    const int px = bx + (lane & 7), py = by + (lane >> 3);
+    const bool inside = (px < W) && (py < H);             // false for every lane of a block outside the image
+    const float pxf = (float)px, pyf = (float)py;
+    const float bx0 = (float)bx, by0 = (float)by;
+    const uint32_t start = tile_off[tg];
+    const uint32_t n = tile_off[tg + 1] - start;
+    const uint32_t nseg = (n + (1u << seg_shift) - 1u) >> seg_shift;
+    float* __restrict__ rec0 = rec_base + (size_t)tile_seg[tg] * GSR_CKPT_FLOATS + (wave * 64 + lane);
+    float4* __restrict__ sa = stage[wave][0];
+    float4* __restrict__ sb = stage[wave][1];
+    float4* __restrict__ sc = stage[wave][2];
+    for (int q = lane; q < 3 * (GSR_RB + 2); q += 64) (&stage[wave][0][0])[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    wave_lds_handoff();
+
+    float P = 1.f, S0 = 0.f, S1 = 0.f, S2 = 0.f, SD = 0.f, SA = 0.f;     // the pixel's absolute state
+    uint32_t last_abs = 0;
+    bool alive = inside;
+    // record of the next segment, requested one segment ahead
+    float nT = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f, nD = 0.f, nA = 0.f;
+    uint32_t nL = 0;
+    if (nseg > 0 && inside) {
+        nT = rec0[0]; n0 = rec0[256]; n1 = rec0[512]; n2 = rec0[768]; nD = rec0[1024]; nA = rec0[1280];
+        nL = reinterpret_cast<const uint32_t*>(rec0)[GSR_REC_LAST];
+    }
+    for (uint32_t s = 0; s < nseg; ++s) {
+        if (__ballot(alive) == 0ull) break;
+        float* __restrict__ rec = rec0 + (size_t)s * GSR_CKPT_FLOATS;
+        float T = nT, C0 = n0, C1 = n1, C2 = n2, D = nD, A = nA;            // the segment's own (T', C', ...)
+        uint32_t last = nL;
+        if (s + 1 < nseg && inside) {
+            const float* __restrict__ r1 = rec + GSR_CKPT_FLOATS;
+            nT = r1[0]; n0 = r1[256]; n1 = r1[512]; n2 = r1[768]; nD = r1[1024]; nA = r1[1280];
+            nL = reinterpret_cast<const uint32_t*>(r1)[GSR_REC_LAST];
+        }
+        const bool walk = alive && (T < 0.f || __fmul_rn(P, T) < 0.0001f);
+        bool done = !walk;                                // lanes that do not walk keep the record's numbers
+        if (__ballot(walk) != 0ull) {
+            // ---- exact walk of segment s for the `walk` lanes, P as the gate of the stop test
+            if (walk) { T = 1.f; C0 = 0.f; C1 = 0.f; C2 = 0.f; D = 0.f; A = 0.f; last = 0u; }
+            const uint32_t lo = s << seg_shift, hi = min(lo + (1u << seg_shift), n);
+            for (uint32_t pos0 = lo; pos0 < hi; pos0 += GSR_RB) {
+                if (__ballot(!done) == 0ull) break;
+                const uint32_t i = pos0 + lane;
+                float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra;
+                bool hit = false;
+                if (i < hi) {
+                    const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + ids[start + i]);
+                    ra = p[0]; rb = p[1]; rc = p[2];
+                    hit = rect_max_power(ra.x, ra.y, ra.z, ra.w, rb.x, bx0, bx0 + 7.f, by0, by0 + 7.f) >= min_visible_power(rb.y);
+                }
+                const unsigned long long mask = __ballot(hit);
+                if (mask == 0ull) continue;
+                const int nhit = __popcll(mask);
+                if (hit) {
+                    const uint32_t pos = lanes_below(mask);
+                    rc.z = __uint_as_float(i + 1u);
+                    sa[pos] = ra; sb[pos] = rb; sc[pos] = rc;
+                }
+                wave_lds_handoff();
+                float4 e0a = sa[0], e0b = sb[0], e0c = sc[0];
+                for (int j = 0; j < nhit; j += 2) {
+                    const float4 e1a = sa[j + 1], e1b = sb[j + 1], e1c = sc[j + 1];
+                    GSR_COMPOSITE(e0a, e0b, e0c, __float_as_uint(e0c.z), true, P, true)
+                    e0a = sa[j + 2]; e0b = sb[j + 2]; e0c = sc[j + 2];
+                    GSR_COMPOSITE(e1a, e1b, e1c, __float_as_uint(e1c.z), j + 1 < nhit, P, true)
+                }
+                wave_lds_handoff();
+            }
+        }
+        const bool stopped = walk && done;                // (done was false for walking lanes and is set by a stop only)
+        if (alive) {
+            S0 = fmaf(P, C0, S0); S1 = fmaf(P, C1, S1); S2 = fmaf(P, C2, S2);
+            SD = fmaf(P, D, SD); SA = fmaf(P, A, SA);
+            P = __fmul_rn(P, T);
+            last_abs = last != 0u ? last : last_abs;
+            alive = !stopped;
+        }
+        if (inside) {   // the backward's checkpoint after segment s (lanes that have stopped: never read for a blended entry)
+            rec[0] = P; rec[256] = S0; rec[512] = S1; rec[768] = S2; rec[1024] = SD; rec[1280] = SA;
+        }
     }
     if (inside) {
         const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
-        final_T[pix] = T;
-        n_contrib[pix] = last;
-        out_color[pix] = fmaf(T, bg[0], C0);
-        out_color[HW + pix] = fmaf(T, bg[1], C1);
-        out_color[2 * HW + pix] = fmaf(T, bg[2], C2);
-        out_depth[pix] = D;
-        out_alpha[pix] = A;
-        totals[pix] = C0; totals[HW + pix] = C1; totals[2 * HW + pix] = C2;   // sums without background
-        totals[3 * HW + pix] = D; totals[4 * HW + pix] = A;
+        final_T[pix] = P;
+        n_contrib[pix] = last_abs;
+        out_color[pix] = fmaf(P, bg[0], S0);
+        out_color[HW + pix] = fmaf(P, bg[1], S1);
+        out_color[2 * HW + pix] = fmaf(P, bg[2], S2);
+        out_depth[pix] = SD;
+        out_alpha[pix] = SA;
+        totals[pix] = S0; totals[HW + pix] = S1; totals[2 * HW + pix] = S2;   // sums without background
+        totals[3 * HW + pix] = SD; totals[4 * HW + pix] = SA;
+    }
+    // ---- how deep the backward has to walk this tile's list, and its (tile, segment) work items
+    {
+        const uint32_t wmax = wave_max_u32(inside ? last_abs : 0u);
+        if (lane == 0) wl[wave] = wmax;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t tl = max(max(wl[0], wl[1]), max(wl[2], wl[3]));
+        const uint32_t segs = (tl + (1u << seg_shift) - 1u) >> seg_shift;
+        tile_last[tg] = tl;
+        const uint32_t base = segs ? (uint32_t)atomicAdd(plan_total, (unsigned long long)segs) : 0u;
+        plan_off[tg] = base;
+        plan_base = base;
+        wl[0] = segs;
+    }
+    __syncthreads();
+    {
+        const uint32_t segs = wl[0], base = plan_base;
+        for (uint32_t q = threadIdx.x; q < segs; q += 256)
+            if (base + q < plan_cap) plan_tile[base + q] = (uint32_t)tg;
     }
 }
+#undef GSR_COMPOSITE
 
 // =========================================================================================
 // Backward, FRONT TO BACK and depth-segmented.

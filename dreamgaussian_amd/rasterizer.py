@@ -133,7 +133,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             sc_.release()
         _lib.check(rc, "gsr_forward")
         _last_stats.update(M=stats.num_instances, M_ref=stats.num_instances_ref,
-                           V=stats.num_visible, max_tile=stats.max_tile_count, N=N, H=H, W=W, K=K)
+                           V=stats.num_visible, max_tile=stats.max_tile_count, N=N, H=H, W=W, K=K,
+                           seg_shift=stats.seg_shift)
         ctx.raster_settings = rs
         ctx.view = (view, keep)            # the backward reuses the struct (and keeps its device constants alive)
         ctx.dims = (N, K)
@@ -145,7 +146,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.save_for_backward(m3 if m3 is not None else empty, shc if shc is not None else empty,
                               col if col is not None else empty, op if op is not None else empty, sc if sc is not None else empty,
                               rot if rot is not None else empty, cov if cov is not None else empty,
-                              radii, geom.tensor, binb.tensor, img.tensor)
+                              radii, geom.tensor, binb.tensor, img.tensor,
+                              *keep)       # the camera constants travel as raw pointers: saved, so that an in-place edit before the backward raises
         ctx.shapes = (means3D.shape, means2D.shape, None if sh is None else sh.shape,
                       None if colors_precomp is None else colors_precomp.shape, opacities.shape,
                       None if scales is None else scales.shape,
@@ -157,7 +159,7 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
         lib = _lib.load()
-        (m3, shc, col, op, sc, rot, cov, radii, geom, binb, img) = ctx.saved_tensors
+        (m3, shc, col, op, sc, rot, cov, radii, geom, binb, img) = ctx.saved_tensors[:11]
         has_sh, has_col, has_sr, has_cov = ctx.present
         N, K = ctx.dims
         rs = ctx.raster_settings

@@ -13,8 +13,6 @@
  *   gsr_forward       <- GaussianRasterizer(raster_settings)(means3D, means2D, shs, ...)
  *                        gs_renderer.py:760,800-809  (ext: _C.rasterize_gaussians)
  *   gsr_forward_views / gsr_backward_views <- the serial per-view render loop main.py:219-255 (B cameras, one launch chain)
- *   gsr_forward_begin / _finish <- the same loop, one stream per view (superseded by gsr_forward_views; kept for callers
- *                        that must overlap views of DIFFERENT sizes)
  *   gsr_backward      <- loss.backward() through that call, main.py:273
  *                        (ext: _C.rasterize_gaussians_backward)
  *   gsr_mark_visible  <- GaussianRasterizer.markVisible (ext: _C.mark_visible; never called
@@ -85,7 +83,14 @@ typedef struct GsrStats {
     int64_t max_tile_count;     /* longest per-tile list */
     int64_t bin_capacity;       /* instances the `bin` scratch was laid out for (>= num_instances): gsr_forward sizes it
                                  * from the previous call (+25 %) so that nothing waits for the host; the backward needs it */
+    int64_t seg_shift;          /* log2 of the depth-segment length (6..8) the forward cut the tile lists with; the backward
+                                 * walks the same segments */
 } GsrStats;
+
+/* Bumped whenever a struct of this header changes size or meaning (GsrStats grew in 3). A caller built against another
+ * value must not call the library: dreamgaussian_amd/_lib.py checks gsr_abi_version() at load. */
+#define GSR_ABI_VERSION 3
+int gsr_abi_version(void);
 
 /* Forward.
  *   N                number of Gaussians; K = shs.shape[1] (max coefficients per Gaussian)
@@ -96,9 +101,10 @@ typedef struct GsrStats {
  *   stats            [host] optional
  * The host returns once the instance counters of THIS call have arrived (GsrStats is exact), but nothing on the GPU waits for
  * the host: the list scratch is sized from the previous call of the thread on the same (N, H, W) (+25 %), binning / sort /
- * compositing are enqueued before the wait, and a prediction that turns out too small is detected on the device and the
- * tail repeated (first call of a shape, GSR_SPECULATE=0: counters first, then the tail, like the reference ext's blocking
- * read of num_rendered).
+ * compositing are enqueued before the wait, and a prediction that turns out too small (instances, or the longest list against
+ * the sort kernels that were launched) is detected on the device by every kernel that touches the lists and the tail repeated
+ * (first call of a shape, GSR_SPECULATE=0: counters first, then the tail, like the reference ext's blocking read of num_rendered).
+ * The result does not depend on the prediction: the depth-segment length (GsrStats.seg_shift) follows N and the image size only.
  * Returns 0, or a negative code with gsr_last_error() set. N==0 renders the background. */
 int gsr_forward(const GsrView* view, int32_t N, int32_t K,
                 const float* means3D, const float* shs, const float* colors_precomp,
@@ -107,25 +113,6 @@ int gsr_forward(const GsrView* view, int32_t N, int32_t K,
                 float* out_color, float* out_depth, float* out_alpha, int32_t* radii,
                 GsrAlloc geom, GsrAlloc bin, GsrAlloc img,
                 GsrStats* stats, gsr_stream_t stream);
-
-/* The forward in two phases, for callers that keep several views in flight (one stream per view):
- *   gsr_forward_begin   per-Gaussian stage + tile scan, then an async copy of four counters
- *                       (M_ref, V, M, longest list) into host_counters (pinned, 4 x uint64, caller-owned);
- *                       geom / img scratch are obtained through the callbacks as in gsr_forward
- *   gsr_forward_finish  after the caller has waited for `stream` (or an event recorded behind
- *                       begin): binning, sort, compositing; geom_ptr / img_ptr are the buffers the
- *                       callbacks returned in begin
- * gsr_forward == begin + wait for the counter copy + finish. Issuing every view's begin before the first
- * finish pays the host round trip once per batch of views instead of once per view. */
-int gsr_forward_begin(const GsrView* view, int32_t N, int32_t K,
-                      const float* means3D, const float* shs, const float* colors_precomp,
-                      const float* opacities, const float* scales, const float* rotations,
-                      const float* cov3D_precomp, int32_t* radii,
-                      GsrAlloc geom, GsrAlloc img, uint64_t* host_counters, gsr_stream_t stream);
-int gsr_forward_finish(const GsrView* view, int32_t N, int32_t K,
-                       float* out_color, float* out_depth, float* out_alpha,
-                       void* geom_ptr, void* img_ptr, GsrAlloc bin,
-                       const uint64_t* host_counters, GsrStats* stats, gsr_stream_t stream);
 
 /* Backward. Same inputs as the forward plus the incoming gradients
  *   dL_dcolor [3,H,W]  dL_ddepth [H,W]  dL_dalpha [H,W]

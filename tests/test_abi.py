@@ -33,7 +33,13 @@ def test_struct_layout_matches_header():
     from dreamgaussian_amd import _lib
     assert ctypes.sizeof(_lib.GsrView) == 8 * 4 + 4 * 8 + 2 * 4 + 2 * 8
     assert ctypes.sizeof(_lib.GsrAlloc) == 16
-    assert ctypes.sizeof(_lib.GsrStats) == 40
+    assert ctypes.sizeof(_lib.GsrStats) == 48
+
+
+def test_abi_version_matches_header():
+    from dreamgaussian_amd import _lib
+    src = open(os.path.join(ROOT, "include", "gsr.h")).read()
+    assert int(re.search(r"#define GSR_ABI_VERSION (\d+)", src).group(1)) == _lib.GSR_ABI_VERSION == _lib.load().gsr_abi_version()
 
 
 def test_c_argument_errors_without_gpu():

@@ -1,6 +1,5 @@
-"""rasterize_views (B cameras through one launch chain, gsr_forward_views / gsr_backward_views; mode="streams": one
-stream per view through the two-phase C ABI) must equal B single-view calls: forward bit for bit, gradients of the
-shared Gaussians = sum over views."""
+"""rasterize_views (B cameras through one launch chain, gsr_forward_views / gsr_backward_views) must equal B
+single-view calls: forward bit for bit, gradients of the shared Gaussians = sum over views."""
 import pytest
 import torch
 
@@ -11,13 +10,19 @@ import dreamgaussian_amd as D
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("mode", ["chain", "streams"])
-@pytest.mark.parametrize("deg,N,size,nviews", [(0, 3000, 128, 5), (3, 1500, 96, 5), (1, 800, 80, 19)])
-def test_batched_views_equal_serial(gpu, deg, N, size, nviews, mode):
-    sc = O.make_scene(N, deg, 0, "trained")
+# the last case is BASELINE.json configs[3] at full size: 250k Gaussians, SH degree 0, 512x512, 8 orbit cameras (8 x 1024 tiles,
+# lists of several thousand entries: every sort class below the HBM fallback, both forward kernels chosen per view)
+@pytest.mark.parametrize("deg,N,size,nviews,kind", [(0, 3000, 128, 5, "trained"), (3, 1500, 96, 5, "trained"), (1, 800, 80, 19, "trained"),
+                                                     (0, 250_000, 512, 8, "blob")],
+                         ids=["sh0_3000_128_5v", "sh3_1500_96_5v", "sh1_800_80_19v", "cfg3_250k_512_8v"])
+def test_batched_views_equal_serial(gpu, deg, N, size, nviews, kind):
+    sc = O.make_scene(N, deg, 0, kind)
     azs = [0.0, 70.0, 160.0, -95.0, 33.0] + [20.0 * i + 5 for i in range(nviews - 5)]   # 19 views: two chunks of the chain
-    S = [settings_to(O.make_settings(O.orbit_pose(-10.0 + 7 * i, az, 2.0 + 0.1 * i), size, size, sh_degree=deg), gpu)
-         for i, az in enumerate(azs)]
+    if N >= 100_000:                                       # configs[3]: the orbit of main.py:219-255, radius 2
+        S = [settings_to(O.make_settings(O.orbit_pose(0.0, 45.0 * i, 2.0), size, size, sh_degree=deg), gpu) for i in range(nviews)]
+    else:
+        S = [settings_to(O.make_settings(O.orbit_pose(-10.0 + 7 * i, az, 2.0 + 0.1 * i), size, size, sh_degree=deg), gpu)
+             for i, az in enumerate(azs)]
     B = len(S)
     w = [[x.to(gpu) for x in weights_for(size, size, seed=10 + i)] for i in range(B)]
 
@@ -41,7 +46,7 @@ def test_batched_views_equal_serial(gpu, deg, N, size, nviews, mode):
     t2 = leaves()
     m2b = torch.zeros(B, N, 3, device=gpu, requires_grad=True)
     color, radii, depth, alpha = D.rasterize_views(t2["means3D"], m2b, t2["opacities"], S, shs=t2["shs"],
-                                                   scales=t2["scales"], rotations=t2["rotations"], mode=mode)
+                                                   scales=t2["scales"], rotations=t2["rotations"])
     assert color.shape == (B, 3, size, size) and radii.shape == (B, N) and depth.shape == (B, 1, size, size)
     bad = []
     for i in range(B):

@@ -52,6 +52,17 @@ FWD_ATOL = 2e-5          # color / alpha, absolute (values are O(1)); depth rela
 GRAD_RTOL = 1e-4         # per attribute, relative to that attribute's max |grad| (float64 oracle as arbiter)
 
 
+# Row-relative bound: the max-normalised tolerance above lets a Gaussian whose gradient is small
+# against the attribute's maximum be badly wrong. For every row (Gaussian) with |ref|_inf >= ROW_REL_FLOOR * max |ref| the
+# ratio |err|_inf / |ref|_inf is taken; its 99.9th percentile over those rows must stay below ROW_REL_P999 and its
+# median below ROW_REL_MEDIAN. (Rows under the floor are covered by the max-normalised bound only: their relative error is
+# dominated by the cancellation of thousands of per-pixel terms.)
+ROW_REL_FLOOR = 1e-3
+ROW_REL_P999 = 5e-3         # fp32-vs-fp64 of the ORACLE ITSELF reaches 1.2e-3 here (tests/test_oracle.py): fp32 rounding, not a kernel property
+ROW_REL_MEDIAN = 2e-5
+REPORT = {}              # what the last assert_* calls observed (printed by the full-size tests)
+
+
 FRAGILE_ABS = 8e-3       # a pixel with an ambiguous discrete decision may differ by one minimal contribution (2/255)
 FRAGILE_GRAD_REL = 5e-2  # ... and the Gaussian of that pair by its single-pair gradient share
 
@@ -67,6 +78,7 @@ def assert_forward_close(ho, oo, aux=None, atol=FWD_ATOL):
     # sqrt) may flip a value sitting on an integer boundary, by one, on a handful of Gaussians
     if dr.numel():
         nbad = int((dr != 0).sum())
+        REPORT["radii_mismatch"] = nbad
         assert int(dr.max()) <= 1 and nbad <= max(1, dr.numel() // 5000), \
             f"radii mismatch on {nbad} Gaussians (max |diff| {int(dr.max())})"
     frag = None if aux is None else torch.as_tensor(aux["fragile_pixels"]).bool()
@@ -106,6 +118,19 @@ def assert_grads_close(hg, og, aux=None, rtol=GRAD_RTOL, floors=None):
                 f"d{k}: max abs err {strict.max().item():.3e} vs {rtol:.0e} * scale {scale:.3e}"
         if err.numel():
             assert err.max().item() <= FRAGILE_GRAD_REL * scale + 1e-9, f"d{k}: fragile row err {err.max().item():.3e}"
+        # row-relative statistic over the rows that carry a gradient worth the name
+        if ref.shape[0] and k not in floors:
+            rn = ref.abs().reshape(ref.shape[0], -1).max(1).values
+            sel = rn >= ROW_REL_FLOOR * scale
+            if fg is not None:
+                sel = sel & ~fg
+            if int(sel.sum()) >= 10:
+                rel = (err[sel] / rn[sel]).sort().values
+                p999 = rel[min(rel.numel() - 1, int(0.999 * rel.numel()))].item()
+                med = rel[rel.numel() // 2].item()
+                REPORT[f"rowrel_{k}"] = dict(rows=int(sel.sum()), median=med, p999=p999, max=rel[-1].item())
+                assert p999 <= ROW_REL_P999 and med <= ROW_REL_MEDIAN, \
+                    f"d{k}: row-relative error median {med:.2e} / p99.9 {p999:.2e} over {int(sel.sum())} rows"
 
 
 # ---- bounded fragile set -----------------------------------------------------
