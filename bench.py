@@ -66,10 +66,11 @@ def alg_bytes(N, K, V, M, P):
 
 def kernel_family(name: str) -> str:
     """Kernels that share one line of alg_bytes: the sort's size classes; the forward compositing's two kernels
-    (gsr_render_fwd_seg composites the depth segments, gsr_render_fwd_combine chains them per pixel)."""
+    (gsr_render_fwd_seg composites the depth segments, gsr_render_fwd_combine chains them per pixel, gsr_render_fwd_fix
+    walks the one segment in which a pixel stops)."""
     if name.startswith("tile_sort"):
         return "tile_sort"
-    return "render_fwd" if name == "render_combine" else name
+    return "render_fwd" if name in ("render_combine", "render_fix") else name
 
 
 def build_inputs(wl, kind, dev, azimuth):

@@ -23,7 +23,8 @@ namespace {
 
 thread_local char g_err[512] = "";
 thread_local unsigned long long* g_pinned = nullptr;   // (kCounterWords + 1) x u64 host-pinned scratch: the counters, then the arrival flag
-constexpr int kCounterWords = 8 + 2 * GSR_MAX_VIEWS;  // device counters: 8 totals, then (M_ref, V) per view
+constexpr int kCounterWords = 8 + 2 * GSR_MAX_VIEWS;  // device counters the host reads: 8 totals, then (M_ref, V) per view
+constexpr int kWalkCounter = kCounterWords;            // device only: walk items handed from the chaining kernel to the fix-up kernel
 struct FwdHint { bool valid = false; int N = 0, H = 0, W = 0, B = 0; unsigned long long M = 0, maxc = 0; unsigned long long per_view[2 * GSR_MAX_VIEWS] = {}; };
 thread_local FwdHint g_hint;                            // this thread's previous gsr_forward: predicts the next one's list sizes
 thread_local hipEvent_t g_copied = nullptr;            // this thread's "counters copied" event
@@ -104,7 +105,7 @@ int once_per_device(F fn) {
 }
 
 struct GeomLayout {
-    size_t recs, emit, flags8, block_stats, tile_count, cursor, counters, tile_off, tile_seg, order, level_off, sat, tile_last, plan_off, total;
+    size_t recs, emit, flags8, block_stats, tile_count, cursor, counters, tile_off, tile_seg, order, level_off, sat, plan_off, total;
     int nTiles;        // per view
     int allTiles;      // views * nTiles: the per-tile arrays hold every view's tiles, view-major
 };
@@ -124,18 +125,17 @@ GeomLayout geom_layout(int N, int H, int W, int B = 1) {
     // tile_count | cursor | counters are contiguous: one memset in front of K1
     L.tile_count = o; o += align_up(BT * 4);
     L.cursor = o; o += align_up(BT * 4);
-    L.counters = o; o += align_up((8 + 2 * GSR_MAX_VIEWS) * 8);   // totals, then (M_ref, V) per view
+    L.counters = o; o += align_up((8 + 2 * GSR_MAX_VIEWS + 2) * 8);   // totals, (M_ref, V) per view, walk items
     L.tile_off = o; o += align_up((BT + 1) * 4);
     L.tile_seg = o; o += align_up((BT + 1) * 4);
     L.order = o; o += align_up(BT * 4);
     L.level_off = o; o += align_up((GSR_NLEV + 1) * 4);
     L.sat = o; o += align_up(BT * 4 * 8);                         // hint word per (tile, wave) of the segment forward
-    L.tile_last = o; o += align_up(BT * 4);
     L.plan_off = o; o += align_up(BT * 4);
     L.total = o;
     return L;
 }
-struct BinLayout { size_t entries, ids, ckpt, plan_tile, plan_cap, items, total; };
+struct BinLayout { size_t entries, ids, ckpt, plan_tile, plan_cap, items, item_recs, walk_items, total; };
 BinLayout bin_layout(size_t M, int nTiles, int shift) {
     BinLayout L;
     size_t o = 0;
@@ -149,6 +149,8 @@ BinLayout bin_layout(size_t M, int nTiles, int shift) {
     // backward work list: sum over tiles of ceil(last_t / 2^shift) <= the same bound
     L.plan_cap = L.items + 1;
     L.plan_tile = o; o += align_up(L.plan_cap * 4);
+    L.item_recs = o; o += align_up(L.items * 16);        // the forward's work items (written by gsr_scatter)
+    L.walk_items = o; o += align_up(L.items * 4 * 8);    // (tile, block, segment) items of the fix-up kernel: <= one per block and segment
     L.total = o < 256 ? 256 : o;
     return L;
 }
@@ -397,8 +399,10 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
             HIP_TRY(hipFuncSetAttribute((const void*)gsr_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         static const int scatter_grid = [] { const char* e = getenv("GSR_SCATTER_GRID"); const int g = e ? atoi(e) : 512; return g < 1 ? 1 : (g > 4096 ? 4096 : g); }();
         const int grid_sc = (int)fmin((double)((N + 255) / 256), (double)scatter_grid);
+        const uint32_t* level_off = (const uint32_t*)(gbuf + GL.level_off);
+        uint4* items = (uint4*)(bbuf + BL.item_recs);
         prof_begin(stream); hipLaunchKernelGGL(gsr_scatter, dim3(grid_sc, B), dim3(256), lds, stream, N, emit, tile_off, cursor, entries,
-                           vc.gx, T, hist_in_lds, (uint32_t)M, counters);
+                           vc.gx, T, hist_in_lds, (uint32_t)M, counters, level_off, order, tile_seg, shift, items, (uint32_t)BL.items);
         LAUNCH_CHECK(view, stream, "scatter");
         // per-tile sort, size classes by list length
         constexpr size_t lds_s = 2048 * 8 + (512 + 1 + 512 + 40) * 4;
@@ -437,27 +441,40 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
         const uint32_t epoch = g_epoch.fetch_add(1u) + 1u;
         const int hint_mode = fwd_hint_env();
         unsigned long long* sat = (unsigned long long*)(gbuf + GL.sat);
-        const uint32_t* level_off = (const uint32_t*)(gbuf + GL.level_off);
+        // one workgroup per item (GSR_FWD_GRID = n: n workgroups striding through the list, an A/B switch -- measured 2x slower,
+        // see the kernel)
+        const char* ge = getenv("GSR_FWD_GRID");
+        const size_t gmax = ge && atoi(ge) > 0 ? (size_t)atoi(ge) : ~(size_t)0;
+        const unsigned grid_a = (unsigned)(BL.items < gmax ? BL.items : gmax);
         prof_begin(stream);
         if (mask_q) {
             vs.view_mask = mask_q;
-            hipLaunchKernelGGL(gsr_render_fwd_seg<true>, dim3((unsigned)BL.items), dim3(256), 0, stream, tile_off, recs, sorted_ids, W, H, vc.gx,
-                               ckpt, tile_seg, order, level_off, shift, sat, epoch, hint_mode, counters, (uint32_t)M, maxc_cap, vs);
+            hipLaunchKernelGGL(gsr_render_fwd_seg<true>, dim3(grid_a), dim3(256), 0, stream, items, level_off, tile_off, recs, sorted_ids, W, H, vc.gx,
+                               ckpt, shift, sat, epoch, hint_mode, counters, (uint32_t)M, maxc_cap, vs);
         }
         if (mask_q != mask_all) {
             vs.view_mask = mask_all & ~mask_q;
-            hipLaunchKernelGGL(gsr_render_fwd_seg<false>, dim3((unsigned)BL.items), dim3(256), 0, stream, tile_off, recs, sorted_ids, W, H, vc.gx,
-                               ckpt, tile_seg, order, level_off, shift, sat, epoch, hint_mode, counters, (uint32_t)M, maxc_cap, vs);
+            hipLaunchKernelGGL(gsr_render_fwd_seg<false>, dim3(grid_a), dim3(256), 0, stream, items, level_off, tile_off, recs, sorted_ids, W, H, vc.gx,
+                               ckpt, shift, sat, epoch, hint_mode, counters, (uint32_t)M, maxc_cap, vs);
         }
         LAUNCH_CHECK(view, stream, "render_fwd");
     }
-    // ---- K5b: chain the segments per pixel, image outputs, the backward's work list
+    // ---- K5b: chain the segments per pixel, outputs of the pixels that never stop, the backward's work list, walk items for K5c
     prof_begin(stream);
+    uint2* walk_items = (uint2*)(bbuf + BL.walk_items);
     hipLaunchKernelGGL(gsr_render_fwd_combine, dim3(TA), dim3(256), 0, stream, tile_off, recs, sorted_ids, W, H, vc.gx,
                        out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, order, shift,
-                       (uint32_t*)(gbuf + GL.tile_last), (uint32_t*)(gbuf + GL.plan_off), (uint32_t*)(bbuf + BL.plan_tile),
-                       counters + 4, (uint32_t)BL.plan_cap, counters, (uint32_t)M, maxc_cap, vs);
+                       (uint32_t*)(gbuf + GL.plan_off), (uint32_t*)(bbuf + BL.plan_tile),
+                       counters + 4, (uint32_t)BL.plan_cap, walk_items, counters + kWalkCounter, counters, (uint32_t)M, maxc_cap, vs);
     LAUNCH_CHECK(view, stream, "render_combine");
+    if (M > 0) {   // ---- K5c: the pixels that stop inside a segment, one wave per (block, segment) item
+        const unsigned grid_f = (unsigned)(TA < 2048 ? (TA < 64 ? 64 : TA) : 2048);
+        prof_begin(stream);
+        hipLaunchKernelGGL(gsr_render_fwd_fix, dim3(grid_f), dim3(256), 0, stream, (const uint2*)walk_items, (const unsigned long long*)(counters + kWalkCounter),
+                           tile_off, recs, sorted_ids, W, H, vc.gx, out_color, out_depth, out_alpha, final_T, n_contrib, totals,
+                           (const float*)ckpt, tile_seg, shift, counters, (uint32_t)M, maxc_cap, vs);
+        LAUNCH_CHECK(view, stream, "render_fix");
+    }
     return 0;
 }
 

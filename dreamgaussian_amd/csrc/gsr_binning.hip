@@ -166,13 +166,33 @@ gsr_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ ti
 extern "C" __global__ void __launch_bounds__(256)
 gsr_scatter(int N, const EmitRec* __restrict__ emit, const uint32_t* __restrict__ tile_off,
             uint32_t* __restrict__ cursor, unsigned long long* __restrict__ entries,
-            int gx, int nTiles, int hist_in_lds, uint32_t capacity, unsigned long long* __restrict__ counters) {
+            int gx, int nTiles, int hist_in_lds, uint32_t capacity, unsigned long long* __restrict__ counters,
+            const uint32_t* __restrict__ level_off, const uint32_t* __restrict__ order, const uint32_t* __restrict__ tile_seg,
+            int seg_shift, uint4* __restrict__ items, uint32_t items_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem_raw);
     // The scratch may have been sized BEFORE the host knew M (gsr_forward: previous call + 25 %). M is on the
     // device: every consumer of the lists leaves at once when they do not fit, and the host repeats the tail.
     if (counters[2] > (unsigned long long)capacity) return;
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) counters[6] = capacity;    // for a backward called without GsrStats
+    {   // Riding along (this kernel waits on scattered stores most of its time): the segment forward's work items, one 16-byte
+        // record each -- {tile, list start, segment record, segment << 8 | entries - 1} -- in the depth-major order
+        // gsr_tile_scan defined (item k = level c, tile order[k - level_off[c]]), so that a workgroup of gsr_render_fwd_seg
+        // learns everything about its item from ONE scalar load instead of a chain of five dependent ones.
+        __shared__ uint32_t lev[GSR_NLEV + 1];
+        for (int i = threadIdx.x; i <= GSR_NLEV; i += 256) lev[i] = level_off[i];
+        __syncthreads();
+        const uint32_t total = min(lev[GSR_NLEV], items_cap);
+        const uint32_t nthreads = gridDim.x * gridDim.y * 256u, gid = (blockIdx.y * gridDim.x + blockIdx.x) * 256u + threadIdx.x;
+        for (uint32_t k = gid; k < total; k += nthreads) {
+            uint32_t lo = 0, hi = GSR_NLEV;               // lev[lo] <= k < lev[hi]
+            while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (lev[mid] <= k) lo = mid; else hi = mid; }
+            const uint32_t t = order[k - lev[lo]];
+            const uint32_t s0 = tile_off[t], n = tile_off[t + 1] - s0, first = lo << seg_shift;
+            const uint32_t len = min(1u << seg_shift, n - first);
+            items[k] = make_uint4(t, s0, tile_seg[t] + lo, (lo << 8) | (len - 1u));
+        }
+    }
     // blockIdx.y = view: its records and its tiles (tile_off holds positions in the one list array of all views)
     emit += (size_t)blockIdx.y * (size_t)N;
     tile_off += (size_t)blockIdx.y * nTiles;

@@ -87,11 +87,10 @@ __device__ __forceinline__ void hint_store64(unsigned long long* p, unsigned lon
 // =========================================================================================
 template <bool QUAD>
 __global__ void __launch_bounds__(256)
-gsr_render_fwd_seg(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict__ recs,
+gsr_render_fwd_seg(const uint4* __restrict__ items, const uint32_t* __restrict__ level_off,
+                   const uint32_t* __restrict__ tile_off, const SplatRec* __restrict__ recs_all,
                    const uint32_t* __restrict__ ids, int W, int H, int gx,
-                   float* __restrict__ rec_base, const uint32_t* __restrict__ tile_seg,
-                   const uint32_t* __restrict__ order, const uint32_t* __restrict__ level_off,
-                   int seg_shift, unsigned long long* __restrict__ sat /* [tiles][4] */, uint32_t epoch,
+                   float* __restrict__ rec_base, int seg_shift, unsigned long long* __restrict__ sat /* [tiles][4] */, uint32_t epoch,
                    int hint_mode /* 0 = on; 1 = off (no hint is read: every segment is composited); 2 = TEST: every
                                     segment behind a tile's first is skipped, the combine kernel walks them all */,
                    const unsigned long long* __restrict__ counters, uint32_t capacity, uint32_t maxc_cap, ViewSplit vs) {
@@ -101,58 +100,60 @@ gsr_render_fwd_seg(const uint32_t* __restrict__ tile_off, const SplatRec* __rest
     __shared__ __attribute__((aligned(8))) uint8_t qlist[QUAD ? 4 : 1][4][80];   // QUAD: [wave][quad][k] = staged slot of the quad's k-th entry
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    // ---- which (level, tile) is this item?
-    const uint32_t k = blockIdx.x;
-    if (k >= level_off[GSR_NLEV]) return;                 // = the item total
-    uint32_t c, rank;
-    {
-        const uint32_t a = level_off[lane * 16];
-        const int coarse = __popcll(__ballot(a <= k)) - 1;            // level_off[0] = 0 <= k
-        const uint32_t b = level_off[coarse * 16 + (lane & 15)];
-        const int fine = __popcll(__ballot(lane < 16 && b <= k)) - 1;
-        c = (uint32_t)(coarse * 16 + fine);
-        rank = k - (uint32_t)__builtin_amdgcn_readlane((int)b, fine);
-    }
-    const int tg = (int)order[rank];                      // tile among all views' tiles
-    const int view = tg / vs.tiles_per_view;
-    if (!((vs.view_mask >> view) & 1u)) return;           // this view composites with the other instantiation
-    const int tile = tg - view * vs.tiles_per_view;
-    recs += (size_t)view * vs.N;
-    const int bx = (tile % gx) * GSR_TILE + (wave & 1) * 8;
-    const int by = (tile / gx) * GSR_TILE + (wave >> 1) * 8;
-    if (bx >= W || by >= H) return;                       // whole block outside the image (the combine skips it too)
     const int row = lane >> 4, l15 = lane & 15;
     const int lx = QUAD ? (row & 1) * 4 + (l15 & 3) : (lane & 7), ly = QUAD ? (row >> 1) * 4 + (l15 >> 2) : (lane >> 3);
-    const int px = bx + lx, py = by + ly;
-    const bool inside = (px < W) && (py < H);
-    const float pxf = (float)px, pyf = (float)py;
-    const int cidx = wave * 64 + ly * 8 + lx;             // record slot of this pixel (row-major 8x8 per wave)
-    const uint32_t start = tile_off[tg];
-    const uint32_t n = tile_off[tg + 1] - start;
-    const uint32_t nseg = (n + (1u << seg_shift) - 1u) >> seg_shift;
-    const uint32_t c_end = c == (uint32_t)(GSR_NLEV - 1) ? nseg : c + 1u;   // the last level walks the rest of the list
-    float* __restrict__ rec0 = rec_base + (size_t)tile_seg[tg] * GSR_CKPT_FLOATS + cidx;
-    unsigned long long* __restrict__ satw = sat + (size_t)tg * 4 + wave;
-    const uint32_t tag = epoch << 16;
+    const int cidx = wave * 64 + ly * 8 + lx;             // record slot of this lane's pixel (row-major 8x8 per wave)
     float4* __restrict__ sa = stage[wave][0];
     float4* __restrict__ sb = stage[wave][1];
     float4* __restrict__ sc = stage[wave][2];
+    bool lds_ready = false;
+    // One item per workgroup by default (the dispatcher then hands the items out in list order as slots free up, which is what
+    // keeps the hints flowing; a fixed stride per workgroup -- GSR_FWD_GRID -- lets the fast ones run ahead of the hints: 2x slower).
+    const uint32_t total = level_off[GSR_NLEV];
+  for (uint32_t k = blockIdx.x; k < total; k += gridDim.x) {
+    const uint4 item = items[k];                          // {tile, list start, segment record, segment << 8 | entries - 1}
+    const int tg = (int)item.x;                           // tile among all views' tiles
+    const uint32_t start = item.y, c = item.w >> 8;
+    const int view = tg / vs.tiles_per_view;
+    if (!((vs.view_mask >> view) & 1u)) continue;         // this view composites with the other instantiation
+    float* __restrict__ rec0 = rec_base + ((size_t)item.z - c) * GSR_CKPT_FLOATS + cidx;
+    // Two thirds of the items of a dense scene lie behind the depth at which their whole tile has stopped: those leave here,
+    // after one load (the tile's four per-wave hint words, one per lane group) and the store of the skip marker.
+    unsigned long long sw_own = 0ull;
+    if (c > 0u && hint_mode == 0) {
+        const unsigned long long sw = hint_load64(sat + (size_t)tg * 4 + (lane & 3));
+        const bool hit = (uint32_t)(sw >> 32) == epoch && (uint32_t)sw <= c;
+        if (__ballot(hit) == ~0ull && c != (uint32_t)(GSR_NLEV - 1)) { rec0[(size_t)c * GSR_CKPT_FLOATS] = GSR_REC_SKIPPED; continue; }
+        sw_own = __shfl(sw, wave, 64);
+    }
+    const int tile = tg - view * vs.tiles_per_view;
+    const SplatRec* __restrict__ recs = recs_all + (size_t)view * vs.N;
+    const int bx = (tile % gx) * GSR_TILE + (wave & 1) * 8;
+    const int by = (tile / gx) * GSR_TILE + (wave >> 1) * 8;
+    if (bx >= W || by >= H) continue;                     // whole block outside the image (the combine skips it too)
+    const int px = bx + lx, py = by + ly;
+    const bool inside = (px < W) && (py < H);
+    const float pxf = (float)px, pyf = (float)py;
+    // the last level walks the rest of its tile's list (tiles with more than GSR_NLEV segments)
+    uint32_t n = (c << seg_shift) + (item.w & 255u) + 1u, c_end = c + 1u;
+    if (c == (uint32_t)(GSR_NLEV - 1)) { n = tile_off[tg + 1] - start; c_end = (n + (1u << seg_shift) - 1u) >> seg_shift; }
+    unsigned long long* __restrict__ satw = sat + (size_t)tg * 4 + wave;
+    const uint32_t tag = epoch << 16;
     const float bx0 = (float)bx, by0 = (float)by;
-    // padding / stale slots are read (never used): keep them finite so that 0 * garbage stays 0
-    for (int q = lane; q < 3 * (GSR_RB + 2); q += 64) (&stage[wave][0][0])[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (QUAD) for (int q = lane; q < 4 * 80 / 4; q += 64) reinterpret_cast<uint32_t*>(&qlist[QUAD ? wave : 0][0][0])[q] = 0u;
-    wave_lds_handoff();
 
     for (uint32_t s = c; s < c_end; ++s) {
         float* __restrict__ rec = rec0 + (size_t)s * GSR_CKPT_FLOATS;
         const uint32_t lo = s << seg_shift, hi = min(lo + (1u << seg_shift), n);
-        // the list entries of the first round travel while the hints are read
-        uint32_t id0 = 0;
-        if (lo + lane < hi) id0 = ids[start + lo + lane];
         uint32_t qbest = 0;
         if (s > 0 && hint_mode == 2) { rec[0] = GSR_REC_SKIPPED; continue; }
         if (s > 0 && hint_mode == 0) {
-            const unsigned long long sw = hint_load64(satw);
+            const unsigned long long sw = s == c ? sw_own : hint_load64(satw);
+            if ((uint32_t)(sw >> 32) == epoch && (uint32_t)sw <= s) { rec[0] = GSR_REC_SKIPPED; continue; }   // this block stopped earlier
+        }
+        // the list entries of the first round travel while the hints are read
+        uint32_t id0 = 0;
+        if (lo + lane < hi) id0 = ids[start + lo + lane];
+        if (s > 0 && hint_mode == 0) {
             const uint32_t* hp = reinterpret_cast<const uint32_t*>(rec) + GSR_REC_HINT;
             const uint32_t h1 = hint_load(hp - GSR_CKPT_FLOATS);
             const uint32_t h2 = s >= 2 ? hint_load(hp - 2 * GSR_CKPT_FLOATS) : 0u;
@@ -161,11 +162,10 @@ gsr_render_fwd_seg(const uint32_t* __restrict__ tile_off, const SplatRec* __rest
             qbest = max(qbest, (h2 & 0xffff0000u) == tag ? (h2 & 0xffffu) : 0u);
             qbest = max(qbest, (h3 & 0xffff0000u) == tag ? (h3 & 0xffffu) : 0u);
             if (!inside) qbest = 0xffffu;
-            const bool sat_hit = (uint32_t)(sw >> 32) == epoch && (uint32_t)sw <= s;
-            if (sat_hit || __ballot(qbest < GSR_QSAT) == 0ull) {       // every pixel of the block has stopped in front of this segment
+            if (__ballot(qbest < GSR_QSAT) == 0ull) {     // every pixel of the block has stopped in front of this segment
                 rec[0] = GSR_REC_SKIPPED;
-                hint_store(reinterpret_cast<uint32_t*>(rec) + GSR_REC_HINT, tag | max(qbest, GSR_QSAT));
-                if (!sat_hit && lane == 0) hint_store64(satw, ((unsigned long long)epoch << 32) | s);
+                hint_store(reinterpret_cast<uint32_t*>(rec) + GSR_REC_HINT, tag | qbest);
+                if (lane == 0) hint_store64(satw, ((unsigned long long)epoch << 32) | s);
                 continue;
             }
         }
@@ -176,6 +176,12 @@ gsr_render_fwd_seg(const uint32_t* __restrict__ tile_off, const SplatRec* __rest
         if (lo + lane < hi) {
             const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + id0);
             na = p[0]; nb = p[1]; nc = p[2];
+        }
+        if (!lds_ready) {   // padding / stale slots are read (never used): keep them finite so that 0 * garbage stays 0
+            for (int q = lane; q < 3 * (GSR_RB + 2); q += 64) (&stage[wave][0][0])[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (QUAD) for (int q = lane; q < 4 * 80 / 4; q += 64) reinterpret_cast<uint32_t*>(&qlist[QUAD ? wave : 0][0][0])[q] = 0u;
+            wave_lds_handoff();
+            lds_ready = true;
         }
         for (uint32_t pos0 = lo; pos0 < hi; pos0 += GSR_RB) {          // 0-based positions pos0 .. pos0+63
             float4 ra = na, rb = nb, rc = nc;
@@ -274,13 +280,48 @@ gsr_render_fwd_seg(const uint32_t* __restrict__ tile_off, const SplatRec* __rest
         hint_store(reinterpret_cast<uint32_t*>(rec) + GSR_REC_HINT, tag | q);
         if (__ballot(q < GSR_QSAT) == 0ull && lane == 0) hint_store64(satw, ((unsigned long long)epoch << 32) | (s + 1u));
     }
+  }
 }
-template __global__ void gsr_render_fwd_seg<false>(const uint32_t*, const SplatRec*, const uint32_t*, int, int, int, float*, const uint32_t*,
-                                                   const uint32_t*, const uint32_t*, int, unsigned long long*, uint32_t, int,
-                                                   const unsigned long long*, uint32_t, uint32_t, ViewSplit);
-template __global__ void gsr_render_fwd_seg<true>(const uint32_t*, const SplatRec*, const uint32_t*, int, int, int, float*, const uint32_t*,
-                                                  const uint32_t*, const uint32_t*, int, unsigned long long*, uint32_t, int,
-                                                  const unsigned long long*, uint32_t, uint32_t, ViewSplit);
+template __global__ void gsr_render_fwd_seg<false>(const uint4*, const uint32_t*, const uint32_t*, const SplatRec*, const uint32_t*, int, int, int,
+                                                   float*, int, unsigned long long*, uint32_t, int, const unsigned long long*, uint32_t, uint32_t, ViewSplit);
+template __global__ void gsr_render_fwd_seg<true>(const uint4*, const uint32_t*, const uint32_t*, const SplatRec*, const uint32_t*, int, int, int,
+                                                  float*, int, unsigned long long*, uint32_t, int, const unsigned long long*, uint32_t, uint32_t, ViewSplit);
+
+// The exact walk of list positions [lo, hi) of a tile for the lanes with done == false (lane = pixel, row-major 8x8 block at
+// (bx0, by0)), `gate` = their transmittance in front of the segment. Updates T, C0, C1, C2, D, A, last, done: the segment's own
+// numbers up to the stopping entry (done is set by a stop only). Same fetch / exact cull / stage / composite as K5a, block lists.
+#define GSR_WALK_SEGMENT(lo, hi, gate)                                                                     \
+    for (uint32_t pos0 = (lo); pos0 < (hi); pos0 += GSR_RB) {                                              \
+        if (__ballot(!done) == 0ull) break;                                                                \
+        const uint32_t i = pos0 + lane;                                                                    \
+        float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra;                                     \
+        bool hit = false;                                                                                  \
+        if (i < (hi)) {                                                                                    \
+            const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + ids[start + i]);         \
+            ra = p[0]; rb = p[1]; rc = p[2];                                                               \
+            hit = rect_max_power(ra.x, ra.y, ra.z, ra.w, rb.x, bx0, bx0 + 7.f, by0, by0 + 7.f) >= min_visible_power(rb.y); \
+        }                                                                                                  \
+        const unsigned long long mask = __ballot(hit);                                                     \
+        if (mask == 0ull) continue;                                                                        \
+        const int nhit = __popcll(mask);                                                                   \
+        if (hit) {                                                                                         \
+            const uint32_t pos = lanes_below(mask);                                                        \
+            rc.z = __uint_as_float(i + 1u);                                                                \
+            sa[pos] = ra; sb[pos] = rb; sc[pos] = rc;                                                      \
+        }                                                                                                  \
+        wave_lds_handoff();                                                                                \
+        float4 e0a = sa[0], e0b = sb[0], e0c = sc[0];                                                      \
+        for (int j = 0; j < nhit; j += 2) {                                                                \
+            const float4 e1a = sa[j + 1], e1b = sb[j + 1], e1c = sc[j + 1];                                \
+            GSR_COMPOSITE(e0a, e0b, e0c, __float_as_uint(e0c.z), true, gate, true)                         \
+            e0a = sa[j + 2]; e0b = sb[j + 2]; e0c = sc[j + 2];                                             \
+            GSR_COMPOSITE(e1a, e1b, e1c, __float_as_uint(e1c.z), j + 1 < nhit, gate, true)                 \
+        }                                                                                                  \
+        wave_lds_handoff();                                                                                \
+    }
+
+#define GSR_DEFERRED 0x80000000u    // n_contrib of a pixel between K5b and K5c: stops inside segment (value & 0x7fffffff)
+#define GSR_WALK_SLOTS 32           // walk items a wave of K5b can hand to K5c (more: it walks them itself)
 
 // =========================================================================================
 // K5b: forward, chaining the segments. One workgroup per tile, wave = 8x8 block, lane = pixel (row-major).
@@ -288,13 +329,14 @@ template __global__ void gsr_render_fwd_seg<true>(const uint32_t*, const SplatRe
 // Per pixel, front to back over the tile's segment records: P = running transmittance (1 at the start).
 //   fl(P * T'_s) >= 1e-4 : no entry of segment s stops the pixel (T' only falls inside a segment and fl(P * .) is
 //                          monotone): C += P * C'_s, ..., P = fl(P * T'_s)                       [a handful of FMAs]
-//   fl(P * T'_s) <  1e-4 : the pixel stops INSIDE segment s: the wave walks that segment exactly (the same
-//                          arithmetic as gsr_render_fwd_seg with P as the gate of the stop test) for its stopping
-//                          lanes -- one segment per pixel, most lanes of a wave in the same one or two segments
-//   record skipped       : the same walk, for the whole segment (only reachable through a wrong hint; see K5a)
+//   fl(P * T'_s) <  1e-4 : the pixel stops INSIDE segment s. Which entry stops it takes a walk of that segment with P as
+//                          the gate of the stop test: deferred to K5c (one item per (block, segment) with such pixels,
+//                          handed over through a list; the pixel is tagged GSR_DEFERRED | s in n_contrib) -- walked here,
+//                          one after the other by a wave with < 2 neighbours per SIMD, the walks were 2/3 of this kernel
+//   record skipped       : walked here, for the whole segment (only reachable through a wrong hint; see K5a)
 // and writes back, in place, the pixel's ABSOLUTE state after every segment it passes: the checkpoint segment s + 1 of
-// the backward starts from. Then the image outputs, the tile's deepest blended position and -- what used to be two
-// more kernels in front of the backward -- the tile's entries of the backward's work list (one atomic per tile).
+// the backward -- and the walk of K5c -- starts from. Then the image outputs of the pixels that never stop, and -- what used
+// to be two more kernels in front of the backward -- the tile's entries of the backward's work list (one atomic per tile).
 // =========================================================================================
 __global__ void __launch_bounds__(256)
 gsr_render_fwd_combine(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict__ recs,
@@ -304,14 +346,16 @@ gsr_render_fwd_combine(const uint32_t* __restrict__ tile_off, const SplatRec* __
                        uint32_t* __restrict__ n_contrib, float* __restrict__ totals /*[5][H*W]*/,
                        float* __restrict__ rec_base, const uint32_t* __restrict__ tile_seg,
                        const uint32_t* __restrict__ order, int seg_shift,
-                       uint32_t* __restrict__ tile_last /* max list position blended in the tile */,
                        uint32_t* __restrict__ plan_off, uint32_t* __restrict__ plan_tile,
                        unsigned long long* __restrict__ plan_total, uint32_t plan_cap,
+                       uint2* __restrict__ walk_items, unsigned long long* __restrict__ walk_total,
                        const unsigned long long* __restrict__ counters, uint32_t capacity, uint32_t maxc_cap, ViewSplit vs) {
     if (counters[2] > (unsigned long long)capacity || counters[3] > (unsigned long long)maxc_cap) return;
     __shared__ float4 stage[4][3][GSR_RB + 2];
     __shared__ uint32_t wl[4];
     __shared__ uint32_t plan_base;
+    __shared__ uint16_t wseg[4][GSR_WALK_SLOTS];          // segments this wave hands to K5c
+    __shared__ uint32_t wcnt[4], walk_base;
     const int tg = (int)order[blockIdx.x];                // heaviest tiles first
     const int view = tg / vs.tiles_per_view;
     const int tile = tg - view * vs.tiles_per_view;
@@ -337,63 +381,60 @@ gsr_render_fwd_combine(const uint32_t* __restrict__ tile_off, const SplatRec* __
     float4* __restrict__ sa = stage[wave][0];
     float4* __restrict__ sb = stage[wave][1];
     float4* __restrict__ sc = stage[wave][2];
-    for (int q = lane; q < 3 * (GSR_RB + 2); q += 64) (&stage[wave][0][0])[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    wave_lds_handoff();
+    bool lds_ready = false;
 
     float P = 1.f, S0 = 0.f, S1 = 0.f, S2 = 0.f, SD = 0.f, SA = 0.f;     // the pixel's absolute state
-    uint32_t last_abs = 0;
+    uint32_t last_abs = 0;                                // deepest blended position (deferred pixels: the end of their segment)
+    uint32_t deferred = 0;                                // GSR_DEFERRED | stop segment
+    uint32_t carry_last = 0;                              // ... and the pixel's deepest blended position in front of that segment
+    uint32_t nwalk = 0;                                   // (wave-uniform) items handed to K5c
     bool alive = inside;
-    // record of the next segment, requested one segment ahead
-    float nT = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f, nD = 0.f, nA = 0.f;
-    uint32_t nL = 0;
-    if (nseg > 0 && inside) {
-        nT = rec0[0]; n0 = rec0[256]; n1 = rec0[512]; n2 = rec0[768]; nD = rec0[1024]; nA = rec0[1280];
-        nL = reinterpret_cast<const uint32_t*>(rec0)[GSR_REC_LAST];
+    // The records of the next GSR_CQ segments are in flight while one is chained: a queue in registers, one record
+    // requested per segment passed (the chain is a string of dependent ~1 us loads otherwise: 30-80 segments per tile)
+#define GSR_CQ 4
+    float qT[GSR_CQ], q0[GSR_CQ], q1[GSR_CQ], q2[GSR_CQ], qD[GSR_CQ], qA[GSR_CQ];
+    uint32_t qL[GSR_CQ];
+#pragma unroll
+    for (int j = 0; j < GSR_CQ; ++j) {
+        qT[j] = 0.f; q0[j] = 0.f; q1[j] = 0.f; q2[j] = 0.f; qD[j] = 0.f; qA[j] = 0.f; qL[j] = 0u;
+        if ((uint32_t)j < nseg && inside) {
+            const float* __restrict__ r = rec0 + (size_t)j * GSR_CKPT_FLOATS;
+            qT[j] = r[0]; q0[j] = r[256]; q1[j] = r[512]; q2[j] = r[768]; qD[j] = r[1024]; qA[j] = r[1280];
+            qL[j] = reinterpret_cast<const uint32_t*>(r)[GSR_REC_LAST];
+        }
     }
     for (uint32_t s = 0; s < nseg; ++s) {
         if (__ballot(alive) == 0ull) break;
         float* __restrict__ rec = rec0 + (size_t)s * GSR_CKPT_FLOATS;
-        float T = nT, C0 = n0, C1 = n1, C2 = n2, D = nD, A = nA;            // the segment's own (T', C', ...)
-        uint32_t last = nL;
-        if (s + 1 < nseg && inside) {
-            const float* __restrict__ r1 = rec + GSR_CKPT_FLOATS;
-            nT = r1[0]; n0 = r1[256]; n1 = r1[512]; n2 = r1[768]; nD = r1[1024]; nA = r1[1280];
-            nL = reinterpret_cast<const uint32_t*>(r1)[GSR_REC_LAST];
+        float T = qT[0], C0 = q0[0], C1 = q1[0], C2 = q2[0], D = qD[0], A = qA[0];            // the segment's own (T', C', ...)
+        uint32_t last = qL[0];
+#pragma unroll
+        for (int j = 0; j + 1 < GSR_CQ; ++j) { qT[j] = qT[j + 1]; q0[j] = q0[j + 1]; q1[j] = q1[j + 1]; q2[j] = q2[j + 1]; qD[j] = qD[j + 1]; qA[j] = qA[j + 1]; qL[j] = qL[j + 1]; }
+        if (s + GSR_CQ < nseg && inside) {
+            const float* __restrict__ r = rec + (size_t)GSR_CQ * GSR_CKPT_FLOATS;
+            qT[GSR_CQ - 1] = r[0]; q0[GSR_CQ - 1] = r[256]; q1[GSR_CQ - 1] = r[512]; q2[GSR_CQ - 1] = r[768];
+            qD[GSR_CQ - 1] = r[1024]; qA[GSR_CQ - 1] = r[1280];
+            qL[GSR_CQ - 1] = reinterpret_cast<const uint32_t*>(r)[GSR_REC_LAST];
         }
-        const bool walk = alive && (T < 0.f || __fmul_rn(P, T) < 0.0001f);
+        const uint32_t lo = s << seg_shift, hi = min(lo + (1u << seg_shift), n);
+        const bool skipped = alive && T < 0.f;            // the record holds nothing: walk it here
+        bool defer = alive && !skipped && __fmul_rn(P, T) < 0.0001f;       // the pixel stops inside this segment
+        if (__ballot(defer) != 0ull && nwalk >= (uint32_t)GSR_WALK_SLOTS) defer = false;   // no slot left: walked here like a skipped record
+        const bool walk = alive && (skipped || (!defer && __fmul_rn(P, T) < 0.0001f));
+        if (__ballot(defer) != 0ull) {
+            if (lane == 0) wseg[wave][nwalk] = (uint16_t)s;
+            ++nwalk;
+            if (defer) { deferred = GSR_DEFERRED | s; carry_last = last_abs; last_abs = hi; alive = false; }
+        }
         bool done = !walk;                                // lanes that do not walk keep the record's numbers
         if (__ballot(walk) != 0ull) {
-            // ---- exact walk of segment s for the `walk` lanes, P as the gate of the stop test
-            if (walk) { T = 1.f; C0 = 0.f; C1 = 0.f; C2 = 0.f; D = 0.f; A = 0.f; last = 0u; }
-            const uint32_t lo = s << seg_shift, hi = min(lo + (1u << seg_shift), n);
-            for (uint32_t pos0 = lo; pos0 < hi; pos0 += GSR_RB) {
-                if (__ballot(!done) == 0ull) break;
-                const uint32_t i = pos0 + lane;
-                float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra;
-                bool hit = false;
-                if (i < hi) {
-                    const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + ids[start + i]);
-                    ra = p[0]; rb = p[1]; rc = p[2];
-                    hit = rect_max_power(ra.x, ra.y, ra.z, ra.w, rb.x, bx0, bx0 + 7.f, by0, by0 + 7.f) >= min_visible_power(rb.y);
-                }
-                const unsigned long long mask = __ballot(hit);
-                if (mask == 0ull) continue;
-                const int nhit = __popcll(mask);
-                if (hit) {
-                    const uint32_t pos = lanes_below(mask);
-                    rc.z = __uint_as_float(i + 1u);
-                    sa[pos] = ra; sb[pos] = rb; sc[pos] = rc;
-                }
+            if (!lds_ready) {
+                for (int q = lane; q < 3 * (GSR_RB + 2); q += 64) (&stage[wave][0][0])[q] = make_float4(0.f, 0.f, 0.f, 0.f);
                 wave_lds_handoff();
-                float4 e0a = sa[0], e0b = sb[0], e0c = sc[0];
-                for (int j = 0; j < nhit; j += 2) {
-                    const float4 e1a = sa[j + 1], e1b = sb[j + 1], e1c = sc[j + 1];
-                    GSR_COMPOSITE(e0a, e0b, e0c, __float_as_uint(e0c.z), true, P, true)
-                    e0a = sa[j + 2]; e0b = sb[j + 2]; e0c = sc[j + 2];
-                    GSR_COMPOSITE(e1a, e1b, e1c, __float_as_uint(e1c.z), j + 1 < nhit, P, true)
-                }
-                wave_lds_handoff();
+                lds_ready = true;
             }
+            if (walk) { T = 1.f; C0 = 0.f; C1 = 0.f; C2 = 0.f; D = 0.f; A = 0.f; last = 0u; }
+            GSR_WALK_SEGMENT(lo, hi, P)
         }
         const bool stopped = walk && done;                // (done was false for walking lanes and is set by a stop only)
         if (alive) {
@@ -409,38 +450,121 @@ gsr_render_fwd_combine(const uint32_t* __restrict__ tile_off, const SplatRec* __
     }
     if (inside) {
         const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
-        final_T[pix] = P;
-        n_contrib[pix] = last_abs;
-        out_color[pix] = fmaf(P, bg[0], S0);
-        out_color[HW + pix] = fmaf(P, bg[1], S1);
-        out_color[2 * HW + pix] = fmaf(P, bg[2], S2);
-        out_depth[pix] = SD;
-        out_alpha[pix] = SA;
-        totals[pix] = S0; totals[HW + pix] = S1; totals[2 * HW + pix] = S2;   // sums without background
-        totals[3 * HW + pix] = SD; totals[4 * HW + pix] = SA;
+        if (deferred != 0u) { n_contrib[pix] = deferred; final_T[pix] = __uint_as_float(carry_last); }   // K5c finishes this pixel
+        else {
+            final_T[pix] = P;
+            n_contrib[pix] = last_abs;
+            out_color[pix] = fmaf(P, bg[0], S0);
+            out_color[HW + pix] = fmaf(P, bg[1], S1);
+            out_color[2 * HW + pix] = fmaf(P, bg[2], S2);
+            out_depth[pix] = SD;
+            out_alpha[pix] = SA;
+            totals[pix] = S0; totals[HW + pix] = S1; totals[2 * HW + pix] = S2;   // sums without background
+            totals[3 * HW + pix] = SD; totals[4 * HW + pix] = SA;
+        }
     }
-    // ---- how deep the backward has to walk this tile's list, and its (tile, segment) work items
+    // ---- how deep the backward has to walk this tile's list (a deferred pixel counts to the end of its segment: the same
+    // number of segments), its (tile, segment) work items, and the walk items of K5c
     {
         const uint32_t wmax = wave_max_u32(inside ? last_abs : 0u);
-        if (lane == 0) wl[wave] = wmax;
+        if (lane == 0) { wl[wave] = wmax; wcnt[wave] = nwalk; }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t tl = max(max(wl[0], wl[1]), max(wl[2], wl[3]));
         const uint32_t segs = (tl + (1u << seg_shift) - 1u) >> seg_shift;
-        tile_last[tg] = tl;
         const uint32_t base = segs ? (uint32_t)atomicAdd(plan_total, (unsigned long long)segs) : 0u;
         plan_off[tg] = base;
         plan_base = base;
         wl[0] = segs;
+        const uint32_t nw = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        walk_base = nw ? (uint32_t)atomicAdd(walk_total, (unsigned long long)nw) : 0u;
     }
     __syncthreads();
     {
         const uint32_t segs = wl[0], base = plan_base;
         for (uint32_t q = threadIdx.x; q < segs; q += 256)
             if (base + q < plan_cap) plan_tile[base + q] = (uint32_t)tg;
+        uint32_t wb = walk_base;
+        for (int w = 0; w < wave; ++w) wb += wcnt[w];
+        if ((uint32_t)lane < nwalk) walk_items[wb + lane] = make_uint2((uint32_t)tg * 4u + (uint32_t)wave, (uint32_t)wseg[wave][lane]);
     }
 }
+
+// =========================================================================================
+// K5c: forward, the pixels that stop inside a segment. One wave per item (tile, 8x8 block, segment) of K5b's list: the
+// lanes tagged GSR_DEFERRED | segment start from the checkpoint in front of the segment (K5b's in-place record), walk the
+// segment with that transmittance as the gate of the stop test, and write the pixel's outputs. Every pixel is in exactly one
+// item; the walks of a tile run on as many waves as it has items instead of one after the other.
+// =========================================================================================
+__global__ void __launch_bounds__(256)
+gsr_render_fwd_fix(const uint2* __restrict__ walk_items, const unsigned long long* __restrict__ walk_total,
+                   const uint32_t* __restrict__ tile_off, const SplatRec* __restrict__ recs_all,
+                   const uint32_t* __restrict__ ids, int W, int H, int gx,
+                   float* __restrict__ out_color, float* __restrict__ out_depth,
+                   float* __restrict__ out_alpha, float* __restrict__ final_T,
+                   uint32_t* __restrict__ n_contrib, float* __restrict__ totals /*[5][H*W]*/,
+                   const float* __restrict__ rec_base, const uint32_t* __restrict__ tile_seg, int seg_shift,
+                   const unsigned long long* __restrict__ counters, uint32_t capacity, uint32_t maxc_cap, ViewSplit vs) {
+    if (counters[2] > (unsigned long long)capacity || counters[3] > (unsigned long long)maxc_cap) return;
+    __shared__ float4 stage[4][3][GSR_RB + 2];
+    const uint32_t nitems = (uint32_t)walk_total[0];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (blockIdx.x * 4u + (uint32_t)wave >= nitems) return;
+    float4* __restrict__ sa = stage[wave][0];
+    float4* __restrict__ sb = stage[wave][1];
+    float4* __restrict__ sc = stage[wave][2];
+    for (int q = lane; q < 3 * (GSR_RB + 2); q += 64) (&stage[wave][0][0])[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    wave_lds_handoff();
+    for (uint32_t it = blockIdx.x * 4u + (uint32_t)wave; it < nitems; it += gridDim.x * 4u) {
+        const uint2 item = walk_items[it];
+        const int tg = (int)(item.x >> 2), blk = (int)(item.x & 3u);
+        const uint32_t s = item.y;
+        const int view = tg / vs.tiles_per_view;
+        const int tile = tg - view * vs.tiles_per_view;
+        const float* __restrict__ bg = vs.bg[view];
+        const SplatRec* __restrict__ recs = recs_all + (size_t)view * vs.N;
+        const int bx = (tile % gx) * GSR_TILE + (blk & 1) * 8;
+        const int by = (tile / gx) * GSR_TILE + (blk >> 1) * 8;
+        const int px = bx + (lane & 7), py = by + (lane >> 3);
+        const bool inside = (px < W) && (py < H);
+        const float pxf = (float)px, pyf = (float)py;
+        const float bx0 = (float)bx, by0 = (float)by;
+        const size_t pix = (size_t)py * W + px, HW = (size_t)H * W, plane = (size_t)view * vs.img_stride;
+        const bool mine = inside && n_contrib[plane + pix] == (GSR_DEFERRED | s);
+        const uint32_t start = tile_off[tg];
+        const uint32_t n = tile_off[tg + 1] - start;
+        const uint32_t lo = s << seg_shift, hi = min(lo + (1u << seg_shift), n);
+        float P = 1.f, S0 = 0.f, S1 = 0.f, S2 = 0.f, SD = 0.f, SA = 0.f;
+        if (mine && s > 0u) {
+            const float* __restrict__ r = rec_base + ((size_t)tile_seg[tg] + s - 1u) * GSR_CKPT_FLOATS + (blk * 64 + lane);
+            P = r[0]; S0 = r[256]; S1 = r[512]; S2 = r[768]; SD = r[1024]; SA = r[1280];
+        }
+        float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, A = 0.f;
+        uint32_t last = 0;
+        bool done = !mine;
+        GSR_WALK_SEGMENT(lo, hi, P)
+        if (mine) {
+            S0 = fmaf(P, C0, S0); S1 = fmaf(P, C1, S1); S2 = fmaf(P, C2, S2);
+            SD = fmaf(P, D, SD); SA = fmaf(P, A, SA);
+            P = __fmul_rn(P, T);
+            if (last == 0u) last = __float_as_uint(final_T[plane + pix]);   // nothing blended in this segment: K5b left the position in front
+            final_T[plane + pix] = P;
+            n_contrib[plane + pix] = last;
+            float* __restrict__ oc = out_color + (size_t)view * 3 * HW;
+            oc[pix] = fmaf(P, bg[0], S0);
+            oc[HW + pix] = fmaf(P, bg[1], S1);
+            oc[2 * HW + pix] = fmaf(P, bg[2], S2);
+            out_depth[(size_t)view * HW + pix] = SD;
+            out_alpha[(size_t)view * HW + pix] = SA;
+            float* __restrict__ tt = totals + plane;
+            tt[pix] = S0; tt[HW + pix] = S1; tt[2 * HW + pix] = S2;
+            tt[3 * HW + pix] = SD; tt[4 * HW + pix] = SA;
+        }
+    }
+}
+#undef GSR_WALK_SEGMENT
 #undef GSR_COMPOSITE
 
 // =========================================================================================

@@ -4,7 +4,7 @@
   python tools/pmc_summary.py gpurun_out [--json profiles/pmc_traffic.json --key 1M-800-sh3/blob]
 
 Looks for */*counter_collection.csv under the given directory (one sub-directory per pass, as
-tools/gpu_r2.sh writes them). HBM traffic per launch follows MI355X_MICROARCH.md's HBM
+tools/gpu_r3.sh writes them). HBM traffic per launch follows MI355X_MICROARCH.md's HBM
 section: FETCH_SIZE / WRITE_SIZE are in KiB-equivalents of 1024 B... (rocprofv3 reports
 FETCH_SIZE and WRITE_SIZE in kilobytes); on gfx950 FETCH_SIZE counts 64 B per 128-B request for
 wide coalesced reads, so the read side is reported both raw and doubled (the correction the
@@ -21,7 +21,7 @@ from collections import defaultdict
 def short(name):
     n = name.split("(")[0]
     n = n.replace("void ", "")
-    for fam in ("gsr_tile_sort", "gsr_render_fwd", "gsr_render_bwd"):
+    for fam in ("gsr_tile_sort", "gsr_render_fwd_combine", "gsr_render_fwd_seg", "gsr_render_bwd"):
         if fam in n and "v0" not in n:
             return fam
     return n.strip()

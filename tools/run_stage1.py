@@ -172,7 +172,7 @@ def run(ref, iters, input_path, profiled, optin=False):
                                           (("128", 0, int(0.3 * iters) - 1), ("256", int(0.3 * iters), int(0.6 * iters) - 1),
                                            ("512", int(0.6 * iters), iters)) if b > a})
     if profiled:
-        fwd = sum(ms for k, (ms, n) in kern.items() if k in ("memset_fwd", "preprocess_fwd", "tile_scan", "scatter", "render_fwd", "render_combine") or k.startswith("tile_sort"))
+        fwd = sum(ms for k, (ms, n) in kern.items() if k in ("memset_fwd", "preprocess_fwd", "tile_scan", "scatter", "render_fwd", "render_combine", "render_fix") or k.startswith("tile_sort"))
         bwd = sum(ms for k, (ms, n) in kern.items() if k in ("memset_bwd", "bwd_plan", "render_bwd", "preprocess_bwd"))
         other = sum(ms for k, (ms, n) in kern.items()) - fwd - bwd
         res["rasterizer_kernel_ms_per_iter"] = dict(forward=round(fwd / iters, 4), backward=round(bwd / iters, 4),
