@@ -221,14 +221,31 @@ constexpr int kHistLdsMaxTiles = 16384;   // 64 KiB of LDS histogram
 //   GSR_SEG_SHIFT=6..8    log2 of the segment length in list positions (default: from N and the tile count, below)
 //   GSR_SPECULATE=0       gsr_forward waits for the instance count before binning (default: speculative, see forward_impl)
 //   GSR_WAIT=event        that wait through hipEventSynchronize instead of the pinned arrival flag
-// Segment length of one call. It fixes where the per-pixel sums are cut (the rounding of the results), so it must not
-// depend on anything a second call with the same inputs could see differently, nor on how many views share the call:
-// N and the per-view tile count only. Short lists (the DreamGaussian-sized scenes) want the finest cut -- their
-// forward is a latency chain; long lists amortise the per-workgroup set-up over more entries.
+//   GSR_FWD_MODE=seg|seq  depth-segmented forward / serial walk (default: by the per-view tile count, below)
+// How the forward composites. Depth-segmented (K5a + K5b + K5c) where a view has few tiles: there the serial walk of a
+// tile's list leaves the chip empty (a 512^2 view has ~350 non-empty tiles = 1.4 waves per SIMD, a 256^2 view 0.6) and
+// the forward is a latency chain. The serial walk (K5b alone) where a view fills the chip: every vector instruction of the
+// compositing is then needed exactly once, and the segmented path's extra ones (segments composited behind the stop before
+// the hint arrived, the stop segment walked a second time, per-item set-up: +40 % at 1M Gaussians / 800^2) cost more than
+// its fuller SIMDs win. Measured, forward compositing in us, segmented / serial: 5k-256^2 36 / 63, 250k-512^2 116 / 130,
+// 100k-800^2 125 / 89, 1M-800^2 196 / 169, 1M-800^2 anisotropic 152 / 108.
+// The choice fixes where the per-pixel sums are cut (the rounding of the results), so -- like the segment length below --
+// it must not depend on anything a second call with the same inputs could see differently, nor on how many views share the
+// call (a view of a batch renders bit-identically to its single-view call): the per-view tile count only.
+bool fwd_sequential_for(int N, int tiles_per_view) {
+    (void)N;
+    if (const char* e = getenv("GSR_FWD_MODE")) { if (strcmp(e, "seq") == 0) return true; if (strcmp(e, "seg") == 0) return false; }
+    return tiles_per_view > 1024;
+}
+// Segment length of one call: the backward's unit of work in both modes (it prefers 64 entries: 0.219 / 0.233 / 0.300 ms
+// at 1M for 64 / 128 / 256), the forward's in the segmented mode, where long lists amortise the per-item set-up over 128
+// entries (250k-512^2: K5a 97 -> 75 us) and short ones want the finest cut (5k-256^2: 16 / 21 / 32 us). From N and the
+// per-view tile count only, for the reason above.
 int seg_shift_for(int N, int tiles_per_view) {
     if (const char* e = getenv("GSR_SEG_SHIFT")) { const int s = atoi(e); if (s >= 6 && s <= 8) return s; }
+    if (fwd_sequential_for(N, tiles_per_view)) return 6;
     const double x = 4.0 * (double)N / (double)(tiles_per_view > 0 ? tiles_per_view : 1);   // ~ list length of an average tile
-    return x <= 512.0 ? 6 : (x <= 2048.0 ? 7 : 8);
+    return x <= 512.0 ? 6 : 7;
 }
 // forward compositing kernel: 0 = per view (finish_impl), 1 = 8x8 block lists, 2 = quad lists
 int fwd_kernel_env() {
@@ -393,6 +410,7 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
     uint32_t* sorted_ids = (uint32_t*)(bbuf + BL.ids);
     float* ckpt = (float*)(bbuf + BL.ckpt);
 
+    const bool sequential = fwd_sequential_for(N, T);
     if (M > 0) {
         const size_t lds = hist_in_lds ? (size_t)T * 4 : 0;
         if (lds > 48 * 1024)
@@ -427,6 +445,7 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
             prof_begin(stream); hipLaunchKernelGGL(gsr_tile_sort_global_ids, dim3(TA), dim3(1024), 0, stream, tile_off, entries, sorted_ids, 16384u, counters, (uint32_t)M);
             LAUNCH_CHECK(view, stream, "tile_sort_global");
         }
+      if (!sequential) {
         // ---- K5a: every (tile, segment) composited on its own
         // Quad lists pay when splats are small against an 8x8 block (few of its 64 lanes blend a given Gaussian): the scene
         // statistic M_ref / V (reference tiles per visible Gaussian) decides, view by view -- a view renders with the kernel its
@@ -458,6 +477,7 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
                                ckpt, shift, sat, epoch, hint_mode, counters, (uint32_t)M, maxc_cap, vs);
         }
         LAUNCH_CHECK(view, stream, "render_fwd");
+      }
     }
     // ---- K5b: chain the segments per pixel, outputs of the pixels that never stop, the backward's work list, walk items for K5c
     prof_begin(stream);
@@ -465,9 +485,9 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
     hipLaunchKernelGGL(gsr_render_fwd_combine, dim3(TA), dim3(256), 0, stream, tile_off, recs, sorted_ids, W, H, vc.gx,
                        out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, order, shift,
                        (uint32_t*)(gbuf + GL.plan_off), (uint32_t*)(bbuf + BL.plan_tile),
-                       counters + 4, (uint32_t)BL.plan_cap, walk_items, counters + kWalkCounter, counters, (uint32_t)M, maxc_cap, vs);
+                       counters + 4, (uint32_t)BL.plan_cap, walk_items, counters + kWalkCounter, sequential ? 1 : 0, counters, (uint32_t)M, maxc_cap, vs);
     LAUNCH_CHECK(view, stream, "render_combine");
-    if (M > 0) {   // ---- K5c: the pixels that stop inside a segment, one wave per (block, segment) item
+    if (M > 0 && !sequential) {   // ---- K5c: the pixels that stop inside a segment, one wave per (block, segment) item
         const unsigned grid_f = (unsigned)(TA < 2048 ? (TA < 64 ? 64 : TA) : 2048);
         prof_begin(stream);
         hipLaunchKernelGGL(gsr_render_fwd_fix, dim3(grid_f), dim3(256), 0, stream, (const uint2*)walk_items, (const unsigned long long*)(counters + kWalkCounter),

@@ -349,6 +349,7 @@ gsr_render_fwd_combine(const uint32_t* __restrict__ tile_off, const SplatRec* __
                        uint32_t* __restrict__ plan_off, uint32_t* __restrict__ plan_tile,
                        unsigned long long* __restrict__ plan_total, uint32_t plan_cap,
                        uint2* __restrict__ walk_items, unsigned long long* __restrict__ walk_total,
+                       int sequential /* no segment records exist: this kernel composites the tile's list front to back itself */,
                        const unsigned long long* __restrict__ counters, uint32_t capacity, uint32_t maxc_cap, ViewSplit vs) {
     if (counters[2] > (unsigned long long)capacity || counters[3] > (unsigned long long)maxc_cap) return;
     __shared__ float4 stage[4][3][GSR_RB + 2];
@@ -389,6 +390,69 @@ gsr_render_fwd_combine(const uint32_t* __restrict__ tile_off, const SplatRec* __
     uint32_t carry_last = 0;                              // ... and the pixel's deepest blended position in front of that segment
     uint32_t nwalk = 0;                                   // (wave-uniform) items handed to K5c
     bool alive = inside;
+    if (sequential) {
+        // ---- long lists (seg_mode_for): the serial walk. A wave fetches 64 list entries per round, three rounds ahead (the
+        // gathers miss the XCD's L2 half of the time), tests each record exactly against its 8x8 block, stages the survivors
+        // and composites them; the per-pixel stop is exact where it happens, and the wave leaves when its 64 pixels have
+        // stopped. At every segment cut it leaves the checkpoint the backward's segment starts from.
+        for (int q = lane; q < 3 * (GSR_RB + 2); q += 64) (&stage[wave][0][0])[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        wave_lds_handoff();
+        float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, A = 0.f;
+        uint32_t last = 0;
+        bool done = !inside;
+        float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra, na = ra, nb = ra, nc = ra;
+        uint32_t id_next = 0;                              // list entry of round r+2 (r+3 after the loads below)
+        if (lane < n) {
+            const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + ids[start + lane]);
+            ra = p[0]; rb = p[1]; rc = p[2];
+        }
+        if (GSR_RB + lane < n) {
+            const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + ids[start + GSR_RB + lane]);
+            na = p[0]; nb = p[1]; nc = p[2];
+        }
+        if (2 * GSR_RB + lane < n) id_next = ids[start + 2 * GSR_RB + lane];
+        for (uint32_t rel = 0; rel < n; rel += GSR_RB) {
+            if (__ballot(!done) == 0ull) break;
+            float4 ma = make_float4(0.f, 0.f, 0.f, 0.f), mb = ma, mc = ma;
+            uint32_t id_next2 = 0;
+            {
+                if (rel + 2 * GSR_RB + lane < n) {
+                    const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + id_next);
+                    ma = p[0]; mb = p[1]; mc = p[2];
+                }
+                if (rel + 3 * GSR_RB + lane < n) id_next2 = ids[start + rel + 3 * GSR_RB + lane];
+            }
+            if (rel != 0u && (rel & ((1u << seg_shift) - 1u)) == 0u && inside) {    // segment cut: checkpoint for the backward
+                float* c = rec0 + (size_t)((rel >> seg_shift) - 1u) * GSR_CKPT_FLOATS;
+                c[0] = T; c[256] = C0; c[512] = C1; c[768] = C2; c[1024] = D; c[1280] = A;
+            }
+            const uint32_t i = rel + lane;
+            bool hit = false;
+            if (i < n)      // can alpha reach 1/255 anywhere in this wave's 8x8 block?
+                hit = rect_max_power(ra.x, ra.y, ra.z, ra.w, rb.x, bx0, bx0 + 7.f, by0, by0 + 7.f) >= min_visible_power(rb.y);
+            const unsigned long long mask = __ballot(hit);
+            if (mask != 0ull) {
+                const int nhit = __popcll(mask);
+                if (hit) {
+                    const uint32_t pos = lanes_below(mask);
+                    rc.z = __uint_as_float(i + 1u);       // 1-based list position replaces the box
+                    sa[pos] = ra; sb[pos] = rb; sc[pos] = rc;
+                }
+                wave_lds_handoff();
+                float4 e0a = sa[0], e0b = sb[0], e0c = sc[0];
+                for (int j = 0; j < nhit; j += 2) {
+                    const float4 e1a = sa[j + 1], e1b = sb[j + 1], e1c = sc[j + 1];
+                    GSR_COMPOSITE(e0a, e0b, e0c, __float_as_uint(e0c.z), true, 1.f, true)
+                    e0a = sa[j + 2]; e0b = sb[j + 2]; e0c = sc[j + 2];
+                    GSR_COMPOSITE(e1a, e1b, e1c, __float_as_uint(e1c.z), j + 1 < nhit, 1.f, true)
+                }
+                wave_lds_handoff();
+            }
+            ra = na; rb = nb; rc = nc; na = ma; nb = mb; nc = mc; id_next = id_next2;
+        }
+        P = T; S0 = C0; S1 = C1; S2 = C2; SD = D; SA = A; last_abs = last;
+        alive = false;
+    }
     // The records of the next GSR_CQ segments are in flight while one is chained: a queue in registers, one record
     // requested per segment passed (the chain is a string of dependent ~1 us loads otherwise: 30-80 segments per tile)
 #define GSR_CQ 4
@@ -397,7 +461,7 @@ gsr_render_fwd_combine(const uint32_t* __restrict__ tile_off, const SplatRec* __
 #pragma unroll
     for (int j = 0; j < GSR_CQ; ++j) {
         qT[j] = 0.f; q0[j] = 0.f; q1[j] = 0.f; q2[j] = 0.f; qD[j] = 0.f; qA[j] = 0.f; qL[j] = 0u;
-        if ((uint32_t)j < nseg && inside) {
+        if ((uint32_t)j < nseg && inside && !sequential) {
             const float* __restrict__ r = rec0 + (size_t)j * GSR_CKPT_FLOATS;
             qT[j] = r[0]; q0[j] = r[256]; q1[j] = r[512]; q2[j] = r[768]; qD[j] = r[1024]; qA[j] = r[1280];
             qL[j] = reinterpret_cast<const uint32_t*>(r)[GSR_REC_LAST];

@@ -378,6 +378,7 @@ def test_forward_variants_are_bit_identical(gpu, monkeypatch, case):
     S = O.make_settings(O.orbit_pose(-8.0, 25.0, 2.0), size, size, sh_degree=deg)
     w = weights_for(size, size)
     monkeypatch.delenv("GSR_FWD", raising=False); monkeypatch.delenv("GSR_FWD_HINTS", raising=False)
+    monkeypatch.setenv("GSR_FWD_MODE", "seg")
     base, gbase, st = run_hip(sc, S, gpu, w)
     assert st["max_tile"] > 3 * (1 << st["seg_shift"]), st            # several segments per tile, or the test is empty
     for env in ({"GSR_FWD": "q"}, {"GSR_FWD": "block"}, {"GSR_FWD_HINTS": "off"}, {"GSR_FWD_HINTS": "skipall"},
@@ -394,12 +395,14 @@ def test_forward_variants_are_bit_identical(gpu, monkeypatch, case):
             assert (hg[k_] - gbase[k_]).abs().max().item() <= 2e-5 * scale, (env, k_)
 
 
+@pytest.mark.parametrize("mode", ["seg", "seq"])
 @pytest.mark.parametrize("shift", [6, 7, 8])
-def test_segment_lengths_match_oracle(gpu, monkeypatch, shift):
+def test_segment_lengths_match_oracle(gpu, monkeypatch, shift, mode):
     """Every segment length the host may pick (GsrStats.seg_shift; 64 / 128 / 256 list entries per workgroup of the
     forward and of the backward) against the fp64 oracle, on lists long enough for a dozen segments per tile and
     short enough opacities for pixels to stop in the middle of them."""
     monkeypatch.setenv("GSR_SEG_SHIFT", str(shift))
+    monkeypatch.setenv("GSR_FWD_MODE", mode)              # depth-segmented forward / serial walk (the host picks by N and tile count)
     sc = O.make_scene(40_000, 1, 7, "trained")
     S = O.make_settings(O.orbit_pose(12.0, -60.0, 2.0), 200, 168, sh_degree=1)
     w = weights_for(168, 200)
