@@ -237,6 +237,9 @@ def main():
                     help="render = rasterizer fwd+bwd (+ RCCL gather of the images when N>1): the headline metric; "
                          "sds = the multi-view SDS exchange on BASELINE configs[3] (see the module docstring)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="with --gpus 1: initialise a ONE-rank nccl group and run every collective of the step through RCCL "
+                         "(views.force_collectives) instead of short-circuiting them")
     ap.add_argument("--trace-steps", action="store_true", help="print every timed step's wall time to stderr")
     ap.add_argument("--views", type=int, default=1,
                     help="cameras per step on each GPU (B > 1: dreamgaussian_amd.rasterize_views keeps them in flight "
@@ -265,6 +268,13 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+    elif a.force_collectives:
+        import socket
+        s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port_ = s_.getsockname()[1]; s_.close()
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(port_))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        from dreamgaussian_amd import views as _v
+        _v.force_collectives(True)
 
     import dreamgaussian_amd as D
     from dreamgaussian_amd import _lib, views
@@ -275,12 +285,12 @@ def main():
             out = {"metric": "Mrays/s (multi-view SDS step, fwd+bwd+exchange)", "value": res["value"], "unit": "Mrays/s",
                    "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": res["ms_per_step"],
                    "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                   "config": {"workload": res["workload"], "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU",
+                   "config": {"workload": res["workload"], "parallelism": f"view-parallel x{world}" if world > 1 else ("single GPU, collectives through a 1-rank RCCL group" if a.force_collectives else "single GPU"),
                               "timed": res["timed"], "allreduce_bytes": res["allreduce_bytes"],
                               "image_bytes_per_view": res["image_bytes_per_view"], "M": res["M"], "M_emitted": res["M_emitted"]},
                    "roofline": None, "cpu_baseline": None}
             print(json.dumps(out), flush=True)
-        if world > 1:
+        if world > 1 or a.force_collectives:
             dist.destroy_process_group()
         return
     wl = WORKLOADS[a.workload]

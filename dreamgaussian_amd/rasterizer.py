@@ -172,21 +172,23 @@ class _RasterizeGaussians(torch.autograd.Function):
         # one allocation for all gradients, each carved out at a 256-byte boundary
         k_rest = ctx.k_rest                              # split SH: dL/dfeatures_dc and dL/dfeatures_rest are separate tensors
         k_sh = K - k_rest
-        widths = [3, 3, 1, 3 * k_sh if has_sh else 0, 3 if has_col else 0, 3 if has_sr else 0, 4 if has_sr else 0,
-                  6 if has_cov else 0, 3 * k_rest]
+        # layout: the parameter gradients first, the per-view means2D gradient last -- views.allreduce_grads reduces the span of
+        # the parameter gradients in place and must not touch the screen-space one
+        widths = [3, 1, 3 * k_sh if has_sh else 0, 3 if has_col else 0, 3 if has_sr else 0, 4 if has_sr else 0,
+                  6 if has_cov else 0, 3 * k_rest, 3]
         offs, total = [], 0
         for w_ in widths:
             offs.append(total)
             total += (N * w_ + 63) & ~63
         flat = (torch.empty if N > 0 else torch.zeros)(max(total, 1), dtype=torch.float32, device=dev)
         part = lambda i, *shape: flat[offs[i]:offs[i] + N * widths[i]].view(*shape)
-        d_m3, d_m2, d_op = part(0, N, 3), part(1, N, 3), part(2, N, 1)
-        d_sh = part(3, N, k_sh, 3) if has_sh else None
-        d_rest = part(8, N, k_rest, 3) if k_rest else None
-        d_col = part(4, N, 3) if has_col else None
-        d_sc = part(5, N, 3) if has_sr else None
-        d_rot = part(6, N, 4) if has_sr else None
-        d_cov = part(7, N, 6) if has_cov else None
+        d_m3, d_op, d_m2 = part(0, N, 3), part(1, N, 1), part(8, N, 3)
+        d_sh = part(2, N, k_sh, 3) if has_sh else None
+        d_rest = part(7, N, k_rest, 3) if k_rest else None
+        d_col = part(3, N, 3) if has_col else None
+        d_sc = part(4, N, 3) if has_sr else None
+        d_rot = part(5, N, 4) if has_sr else None
+        d_cov = part(6, N, 6) if has_cov else None
         if N > 0:
             tmp = _lib.Scratch(dev)
             with torch.cuda.device(dev):

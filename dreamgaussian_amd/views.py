@@ -18,10 +18,26 @@ import torch
 import torch.distributed as dist
 
 
+_force = False
+
+
+def force_collectives(on: bool = True):
+    """Run every collective even in a group of ONE rank (default: a single rank short-circuits them). With a 1-rank
+    "nccl" group this pushes gather / scatter / all-reduce of device tensors through RCCL on a single-GPU box: the
+    same calls, arguments and buffer handling as on 8 GPUs (tests/test_views_gpu.py, bench.py --force-collectives)."""
+    global _force
+    _force = bool(on)
+
+
 def _world(group=None):
     if not (dist.is_available() and dist.is_initialized()):
         return 0, 1
     return dist.get_rank(group), dist.get_world_size(group)
+
+
+def _single(world: int) -> bool:
+    """True when the collectives may be skipped: one rank and nobody asked for them."""
+    return world == 1 and not (_force and dist.is_available() and dist.is_initialized())
 
 
 def shard_views(views: Sequence, group=None) -> List:
@@ -46,7 +62,7 @@ def gather_views_async(color: torch.Tensor, depth: torch.Tensor, alpha: torch.Te
     detached: gradients flow back through `scatter_view_grads`."""
     rank, world = _world(group)
     local = torch.cat([color.detach(), depth.detach(), alpha.detach()], dim=0).contiguous()
-    if world == 1:
+    if _single(world):
         buf[0].copy_(local)
         return None
     glist = [buf[i] for i in range(world)] if rank == dst else None
@@ -70,7 +86,7 @@ def gather_images(local: torch.Tensor, dst: Optional[int] = 0, group=None,
     multiple of the world size the ranks hold unequal counts (rank r: views r, r+world, ...) and the
     shorter ranks are padded for the collective. Default: b * world (equal counts)."""
     rank, world = _world(group)
-    if world == 1:
+    if _single(world):
         return local
     b = int(local.shape[0])
     if num_views is None:
@@ -99,7 +115,7 @@ def scatter_view_grads(grad_all: Optional[torch.Tensor], like: torch.Tensor, src
     """Inverse of gather_images for the backward: `grad_all` [num_views,C,H,W] in view order on
     `src` -> this rank's [b,C,H,W] slice (`like` gives its shape)."""
     rank, world = _world(group)
-    if world == 1:
+    if _single(world):
         return grad_all
     b = int(like.shape[0])
     if num_views is None:
@@ -118,29 +134,50 @@ def scatter_view_grads(grad_all: Optional[torch.Tensor], like: torch.Tensor, src
 
 
 def allreduce_grads(params: Iterable[torch.Tensor], group=None, bucket_bytes: int = 64 << 20):
-    """Sum `.grad` of the replicated Gaussian parameters over the ranks, in flat buckets of
-    ~bucket_bytes (few, large collectives: xGMI rings are per-link bound, launch latency
-    dominates small ones)."""
+    """Sum `.grad` of the replicated Gaussian parameters over the ranks.
+
+    The rasterizer's backward carves every gradient out of ONE allocation (rasterizer.py: the parameter gradients first,
+    the per-view means2D gradient last) and autograd keeps those views as `.grad`: gradients that tile one storage are
+    reduced IN PLACE with a single all-reduce over their span -- no `cat`, no copy back (62 MB at 1M Gaussians / SH 3:
+    two passes over HBM and a launch per tensor saved). Anything else (gradients that went through torch ops, e.g. the
+    activations of gs_renderer.py:196-216) goes through flat buckets of ~bucket_bytes: few, large collectives -- xGMI
+    rings are per-link bound, launch latency dominates small ones."""
     rank, world = _world(group)
-    if world == 1:
+    if _single(world):
         return
     grads = [p.grad for p in params if p.grad is not None]
+    by_storage = {}
+    for g in grads:
+        by_storage.setdefault((g.untyped_storage().data_ptr(), g.dtype, g.device), []).append(g)
+    rest = []
+    for (_, dtype, dev), gs in by_storage.items():
+        if len(gs) > 1 and all(g.is_contiguous() for g in gs):
+            lo = min(g.storage_offset() for g in gs)
+            hi = max(g.storage_offset() + g.numel() for g in gs)
+            if sum(g.numel() for g in gs) >= 0.95 * (hi - lo):      # only alignment gaps in between (never read)
+                span = torch.empty(0, dtype=dtype, device=dev).set_(gs[0].untyped_storage(), lo, (hi - lo,))
+                dist.all_reduce(span, op=dist.ReduceOp.SUM, group=group)
+                continue
+        rest.extend(gs)
     bucket, size = [], 0
 
     def flush():
         nonlocal bucket, size
         if not bucket:
             return
-        flat = torch.cat([g.reshape(-1) for g in bucket])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-        off = 0
-        for g in bucket:
-            n = g.numel()
-            g.copy_(flat[off:off + n].view_as(g))
-            off += n
+        if len(bucket) == 1 and bucket[0].is_contiguous():
+            dist.all_reduce(bucket[0], op=dist.ReduceOp.SUM, group=group)
+        else:
+            flat = torch.cat([g.reshape(-1) for g in bucket])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+            off = 0
+            for g in bucket:
+                n = g.numel()
+                g.copy_(flat[off:off + n].view_as(g))
+                off += n
         bucket, size = [], 0
 
-    for g in grads:
+    for g in rest:
         bucket.append(g)
         size += g.numel() * g.element_size()
         if size >= bucket_bytes:

@@ -201,7 +201,7 @@ def test_baseline_config_against_fp64_oracle(gpu, case):
     util.REPORT.clear()
     try:
         assert_forward_close(ho, oo, aux)
-        assert_grads_close(hg, og, aux, floors=floors)
+        assert_grads_close(hg, og, aux, floors=floors, row_rel_p999=util.ROW_REL_P999_FULL)
     finally:
         print(f"[{name}] observed: {util.REPORT}")
     assert_fragile_bounded(rep, size * size, N)
@@ -409,5 +409,22 @@ def test_segment_lengths_match_oracle(gpu, monkeypatch, shift, mode):
     ho, hg, st = run_hip(sc, S, gpu, w)
     assert st["seg_shift"] == shift and st["max_tile"] > 1500
     oo, og, aux = run_oracle(sc, S, w, torch.float64)
+    assert_forward_close(ho, oo, aux)
+    assert_grads_close(hg, og, aux, floors=grad_floors(sc, og))
+
+
+@pytest.mark.parametrize("size,el,az", [(256, 0.0, 0.0), (512, -15.0, 130.0)], ids=["256", "512"])
+def test_stage1_trained_gaussians_match_oracle(gpu, golden_dir, size, el, az):
+    """Gaussians the reference's own trainer produced: a seeded 2000-Gaussian subsample of the model after 500 iterations of
+    DreamGaussian stage 1 through libgsr.so (tools/run_stage1.py --export-fixture: densified, pruned, opacity-reset history,
+    gs_renderer.py:597-623) -- neither of the two synthetic distributions. Against the fp64 oracle, strict tolerances."""
+    path = os.path.join(golden_dir, "stage1_trained.npz")
+    z = np.load(path)
+    sc = {k: torch.from_numpy(z[k]) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+    S = O.make_settings(O.orbit_pose(el, az, 2.0), size, size, sh_degree=0)
+    w = weights_for(size, size)
+    ho, hg, st = run_hip(sc, S, gpu, w)
+    oo, og, aux = run_oracle(sc, S, w, torch.float64)
+    assert abs(st["M_ref"] - aux["M"]) <= 1e-4 * aux["M"] + 8 and st["V"] == aux["V"]
     assert_forward_close(ho, oo, aux)
     assert_grads_close(hg, og, aux, floors=grad_floors(sc, og))

@@ -13,6 +13,25 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _np(x):
+    """Tensors leave the workers as numpy arrays (pickled by value): a torch tensor travels as a shared-memory file descriptor
+    that the parent must fetch while the worker is still alive -- a race with the worker's exit."""
+    if torch.is_tensor(x):
+        return x.detach().numpy().copy()
+    if isinstance(x, dict):
+        return {k: _np(v) for k, v in x.items()}
+    return x
+
+
+def _pt(x):
+    import numpy as np
+    if isinstance(x, np.ndarray):
+        return torch.from_numpy(x)
+    if isinstance(x, dict):
+        return {k: _pt(v) for k, v in x.items()}
+    return x
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
@@ -52,12 +71,21 @@ def _worker(rank, world, port, q):
         torch.autograd.backward([local], [g_local])
         params = list(sc.values())
         views.allreduce_grads(params, bucket_bytes=1 << 10)                    # several buckets
+        # gradients carved out of ONE allocation (what the rasterizer's backward hands to autograd): reduced in place, in one
+        # collective over their span -- same storage afterwards, the trailing (per-view) tensor of the allocation untouched
+        flat = torch.full((256,), float(rank + 1))
+        pa, pb, pv = (torch.nn.Parameter(torch.zeros(s)) for s in ((10, 3), (10, 1), (10, 3)))
+        pa.grad, pb.grad, pv.grad = flat[0:30].view(10, 3), flat[64:74].view(10, 1), flat[128:158].view(10, 3)
+        views.allreduce_grads([pa, pb])
+        total = float(sum(range(1, world + 1)))
+        assert pa.grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr()
+        assert bool((pa.grad == total).all()) and bool((pb.grad == total).all()) and bool((pv.grad == rank + 1).all())
         if rank == 0:
-            q.put(dict(batch=batch, everywhere=everywhere, buf=buf.clone(),
-                       grads={k: v.grad.clone() for k, v in sc.items()}))
+            q.put(_np(dict(batch=batch, everywhere=everywhere, buf=buf.clone(),
+                           grads={k: v.grad.clone() for k, v in sc.items()})))
         else:
             assert batch is None
-            q.put(dict(everywhere=everywhere, grads={k: v.grad.clone() for k, v in sc.items()}))
+            q.put(_np(dict(everywhere=everywhere, grads={k: v.grad.clone() for k, v in sc.items()})))
     finally:
         dist.barrier()
         dist.destroy_process_group()
@@ -73,7 +101,7 @@ def test_two_rank_view_parallel_equals_serial():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in range(world)]
+    res = [_pt(q.get(timeout=120)) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -118,7 +146,7 @@ def _worker_ragged(rank, world, port, q, azs):
             if v.grad is None:
                 v.grad = torch.zeros_like(v)
         views.allreduce_grads(list(sc.values()), bucket_bytes=1 << 9)
-        q.put(dict(rank=rank, batch=batch, grads={k: v.grad.clone() for k, v in sc.items()}))
+        q.put(_np(dict(rank=rank, batch=batch, grads={k: v.grad.clone() for k, v in sc.items()})))
     finally:
         dist.barrier()
         dist.destroy_process_group()
@@ -136,7 +164,7 @@ def test_four_rank_unequal_view_counts_equal_serial(nviews):
     procs = [ctx.Process(target=_worker_ragged, args=(r, world, port, q, azs)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda r: r["rank"])
+    res = sorted([_pt(q.get(timeout=180)) for _ in range(world)], key=lambda r: r["rank"])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -158,3 +186,32 @@ def test_single_process_fallthrough():
     assert views.gather_images(x) is x
     assert views.scatter_view_grads(x, x) is x
     views.allreduce_grads([torch.nn.Parameter(torch.zeros(3))])
+
+
+def _worker_forced(port, q):
+    """One rank, collectives forced: the path tests/test_views_gpu.py drives through RCCL on the 1-GPU box, here on gloo."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        from dreamgaussian_amd import views
+        views.force_collectives(True)
+        x = torch.rand(3, 5, 4, 6)
+        got = views.gather_images(x, dst=0)
+        back = views.scatter_view_grads(2 * x, x, src=0)
+        p = torch.nn.Parameter(torch.zeros(7)); p.grad = torch.arange(7.0)
+        views.allreduce_grads([p])
+        q.put(dict(fresh=got is not x, same=torch.equal(got, x), back=torch.equal(back, 2 * x), grad=torch.equal(p.grad, torch.arange(7.0))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_forced_collectives_on_one_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_forced, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=60)
+    p.join(timeout=30)
+    assert p.exitcode == 0 and res == dict(fresh=True, same=True, back=True, grad=True)

@@ -58,12 +58,18 @@ GRAD_RTOL = 1e-4         # per attribute, relative to that attribute's max |grad
 # median below ROW_REL_MEDIAN. (Rows under the floor are covered by the max-normalised bound only: their relative error is
 # dominated by the cancellation of thousands of per-pixel terms.)
 ROW_REL_FLOOR = 1e-3
-ROW_REL_P999 = 5e-3         # fp32-vs-fp64 of the ORACLE ITSELF reaches 1.2e-3 here (tests/test_oracle.py): fp32 rounding, not a kernel property
+ROW_REL_P999 = 5e-3         # small scenes (a few thousand rows: the 99.9th percentile is the second-worst row); fp32-vs-fp64 of the
+                            # ORACLE ITSELF reaches 1.2e-3 there (tests/test_oracle.py): fp32 rounding, not a kernel property
+ROW_REL_P999_FULL = 1e-3    # BASELINE configs[1]-[3] at full size (>= 20k rows): observed on the MI355X <= 5.2e-4
 ROW_REL_MEDIAN = 2e-5
 REPORT = {}              # what the last assert_* calls observed (printed by the full-size tests)
 
 
-FRAGILE_ABS = 8e-3       # a pixel with an ambiguous discrete decision may differ by one minimal contribution (2/255)
+# A pixel with an ambiguous discrete decision may differ by ONE flipped decision. alpha >= 1/255: the pair contributes
+# alpha T <= (1/255) / (1 - 1/255) ~ 4e-3. T (1 - alpha) >= 1e-4 (the stop): the pair at the stop contributes alpha T with
+# T (1 - alpha) ~ 1e-4, i.e. up to 1e-4 * 0.99 / 0.01 = 9.9e-3 for a near-opaque Gaussian (alpha is clamped at 0.99) -- the
+# trained stage-1 model has those (tools/run_stage1.py's oracle check: 2.4e-2 of depth = 9.9e-3 * z 2.4).
+FRAGILE_ABS = 1.1e-2
 FRAGILE_GRAD_REL = 5e-2  # ... and the Gaussian of that pair by its single-pair gradient share
 
 
@@ -102,7 +108,7 @@ def grad_floors(sc, og):
     return floors
 
 
-def assert_grads_close(hg, og, aux=None, rtol=GRAD_RTOL, floors=None):
+def assert_grads_close(hg, og, aux=None, rtol=GRAD_RTOL, floors=None, row_rel_p999=ROW_REL_P999):
     """Each attribute's gradient within rtol * max|ref| (row-wise strict), except the rows of
     Gaussians the oracle flags as part of an ambiguous discrete decision (see above)."""
     floors = floors or {}
@@ -129,7 +135,7 @@ def assert_grads_close(hg, og, aux=None, rtol=GRAD_RTOL, floors=None):
                 p999 = rel[min(rel.numel() - 1, int(0.999 * rel.numel()))].item()
                 med = rel[rel.numel() // 2].item()
                 REPORT[f"rowrel_{k}"] = dict(rows=int(sel.sum()), median=med, p999=p999, max=rel[-1].item())
-                assert p999 <= ROW_REL_P999 and med <= ROW_REL_MEDIAN, \
+                assert p999 <= row_rel_p999 and med <= ROW_REL_MEDIAN, \
                     f"d{k}: row-relative error median {med:.2e} / p99.9 {p999:.2e} over {int(sel.sum())} rows"
 
 

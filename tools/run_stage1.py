@@ -128,7 +128,39 @@ def install_optin(gs_renderer):
     return lambda: [setattr(GM, n, f) for n, f in zip(("training_setup", "add_densification_stats", "prune_points"), saved)]
 
 
-def run(ref, iters, input_path, profiled, optin=False):
+def trained_gaussians(gui):
+    """The activated parameters Renderer.render hands to the rasterizer (gs_renderer.py:196-216, 762-775), on the CPU."""
+    g = gui.renderer.gaussians
+    with torch.no_grad():
+        return dict(means3D=g.get_xyz.detach().float().cpu(), shs=g.get_features.detach().float().cpu().contiguous(),
+                    opacities=g.get_opacity.detach().float().cpu(), scales=g.get_scaling.detach().float().cpu(),
+                    rotations=g.get_rotation.detach().float().cpu())
+
+
+def check_against_oracle(sc, sizes=((256, 0.0, 0.0), (512, -15.0, 130.0)), label="stage-1 model"):
+    """The HIP rasterizer against the fp64 oracle on Gaussians the reference's trainer produced (densified, pruned,
+    opacity-reset history: gs_renderer.py:597-623), with the parity tests' own tolerances (tests/util.py). Raises on a miss."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import util
+    from oracle import gs_oracle as O
+    rep = {}
+    deg = int(round(math.sqrt(sc["shs"].shape[1]))) - 1
+    for size, el, az in sizes:
+        S = O.make_settings(O.orbit_pose(el, az, 2.0), size, size, sh_degree=deg)
+        w = util.weights_for(size, size)
+        ho, hg, st = util.run_hip(sc, S, torch.device("cuda:0"), w)
+        oo, og, aux = util.run_oracle(sc, S, w, torch.float64)
+        util.REPORT.clear()
+        util.assert_forward_close(ho, oo, aux)
+        util.assert_grads_close(hg, og, aux, floors=util.grad_floors(sc, og))
+        rep[f"{size}x{size}"] = dict(N=int(sc["means3D"].shape[0]), M=int(aux["M"]), V=int(aux["V"]), max_tile=int(st["max_tile"]),
+                                     max_abs_color_err=float((ho[0].double() - oo[0].double()).abs().max()),
+                                     fragile_pixels=int(torch.as_tensor(aux["fragile_pixels"]).sum()), observed=dict(util.REPORT))
+    print(f"[oracle check] {label}: HIP == fp64 oracle within the parity tolerances: {json.dumps(rep)[:600]}")
+    return rep
+
+
+def run(ref, iters, input_path, profiled, optin=False, keep=None):
     from dreamgaussian_amd import _lib
     for m in ("main", "gs_renderer", "sh_utils", "cam_utils", "grid_put"):
         sys.modules.pop(m, None)
@@ -165,6 +197,8 @@ def run(ref, iters, input_path, profiled, optin=False):
         kern = _lib.profile_read()
     gui.save_model(mode="model")                     # main.py:897 (PLY through the plyfile shim)
     n_final = int(gui.renderer.gaussians.get_xyz.shape[0])
+    if keep is not None:
+        keep.update(trained_gaussians(gui))
     res = dict(iters=iters, wall_s=round(wall, 3), init_s=round(t_init, 3), ms_per_iter=round(wall / iters * 1e3, 3),
                psnr_before=round(psnr0, 2), psnr_after=round(psnr_fixed_view(gui), 2), n_initial=counts[0] if counts else None,
                n_final=n_final, n_max=max(counts) if counts else None, n_every_100=counts[99::100],
@@ -189,6 +223,9 @@ def main():
     ap.add_argument("--iters", type=int, default=500)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "stage1.json"))
     ap.add_argument("--no-profiled-run", action="store_true")
+    ap.add_argument("--export-fixture", default=None, help="write a seeded 2000-Gaussian subsample of the trained model to this .npz "
+                                                          "(tests/golden/stage1_trained.npz: the parity tests' trained-Gaussians case)")
+    ap.add_argument("--no-oracle-check", action="store_true")
     ap.add_argument("--optin", action="store_true", help="one more run with FusedAdam, the fused densification statistics and the "
                                                          "one-gather prune patched onto the reference's GaussianModel")
     a = ap.parse_args()
@@ -201,7 +238,17 @@ def main():
     sys.path.insert(0, ref)
     input_path = os.path.join(ref, "data", "catstatue_rgba.png")
     cold = run(ref, a.iters, input_path, profiled=False)      # first run of the process: includes one-time costs (code objects, allocator growth)
-    plain = run(ref, a.iters, input_path, profiled=False)     # the number to quote: same seed, warm process
+    model = {}
+    plain = run(ref, a.iters, input_path, profiled=False, keep=model)     # the number to quote: same seed, warm process
+    oracle_rep = None
+    if not a.no_oracle_check:                                 # the run asserts what it rendered with: the trained model, HIP vs oracle
+        oracle_rep = check_against_oracle(model)
+    if a.export_fixture:
+        n = int(model["means3D"].shape[0])
+        idx = torch.randperm(n, generator=torch.Generator().manual_seed(0))[:2000].sort().values
+        np.savez_compressed(a.export_fixture, **{k: v[idx].numpy().astype(np.float32) for k, v in model.items()},
+                            n_model=n, iters=a.iters)
+        print(f"[fixture] {min(n, 2000)} of {n} trained Gaussians -> {a.export_fixture}")
     prof = None if a.no_profiled_run else run(ref, a.iters, input_path, profiled=True)
     from dreamgaussian_amd import _lib
     out = {"config": "BASELINE.json configs[4]: main.py --config configs/image.yaml input=data/catstatue_rgba.png, "
@@ -210,7 +257,8 @@ def main():
            "deviations": "stub modules for cv2 (Pillow), dearpygui, rembg, trimesh, pymeshlab, kiui, mesh, mesh_utils, omegaconf; "
                          "plyfile -> dreamgaussian_amd.ply; save_model('geo+tex') skipped (mcubes/xatlas/nvdiffrast absent)",
            "device": torch.cuda.get_device_name(0), "torch": torch.__version__,
-           "cold_run_wall_s": cold["wall_s"], "run": plain, "profiled_run": prof}
+           "cold_run_wall_s": cold["wall_s"], "run": plain, "profiled_run": prof,
+           "oracle_check_of_the_trained_model": oracle_rep}
     if a.optin:
         out["optin_run"] = run(ref, a.iters, input_path, profiled=False, optin=True)
         out["optin_run"]["what"] = ("same trainer, same seed; GaussianModel.training_setup -> dreamgaussian_amd.FusedAdam, "
