@@ -235,7 +235,7 @@ constexpr int kHistLdsMaxTiles = 16384;   // 64 KiB of LDS histogram
 bool fwd_sequential_for(int N, int tiles_per_view) {
     (void)N;
     if (const char* e = getenv("GSR_FWD_MODE")) { if (strcmp(e, "seq") == 0) return true; if (strcmp(e, "seg") == 0) return false; }
-    return tiles_per_view > 1024;
+    return tiles_per_view >= 1024;
 }
 // Segment length of one call: the backward's unit of work in both modes (it prefers 64 entries: 0.219 / 0.233 / 0.300 ms
 // at 1M for 64 / 128 / 256), the forward's in the segmented mode, where long lists amortise the per-item set-up over 128
@@ -445,21 +445,44 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
             prof_begin(stream); hipLaunchKernelGGL(gsr_tile_sort_global_ids, dim3(TA), dim3(1024), 0, stream, tile_off, entries, sorted_ids, 16384u, counters, (uint32_t)M);
             LAUNCH_CHECK(view, stream, "tile_sort_global");
         }
-      if (!sequential) {
-        // ---- K5a: every (tile, segment) composited on its own
-        // Quad lists pay when splats are small against an 8x8 block (few of its 64 lanes blend a given Gaussian): the scene
-        // statistic M_ref / V (reference tiles per visible Gaussian) decides, view by view -- a view renders with the kernel its
-        // single-view call would use (the two give the same bits anyway: tests/test_parity_gpu.py).
-        uint32_t mask_q = 0;
-        const int fk = fwd_kernel_env();
-        for (int v = 0; v < B; ++v) {
-            const unsigned long long mr = per_view[2 * v], vv = per_view[2 * v + 1];
-            if (fk == 2 || (fk == 0 && vv > 0 && mr <= 6ull * vv)) mask_q |= 1u << v;
+    }
+    // Quad lists pay when splats are small against an 8x8 block (few of its 64 lanes blend a given Gaussian): the scene
+    // statistic M_ref / V (reference tiles per visible Gaussian) decides, view by view -- a view renders with the kernel its
+    // single-view call would use (the two give the same bits anyway: tests/test_parity_gpu.py).
+    uint32_t mask_q = 0;
+    const int fk = fwd_kernel_env();
+    for (int v = 0; v < B; ++v) {
+        const unsigned long long mr = per_view[2 * v], vv = per_view[2 * v + 1];
+        if (fk == 2 || (fk == 0 && vv > 0 && mr <= 6ull * vv)) mask_q |= 1u << v;
+    }
+    const uint32_t mask_all = B >= 32 ? ~0u : ((1u << B) - 1u);
+    uint32_t* plan_off = (uint32_t*)(gbuf + GL.plan_off);
+    uint32_t* plan_tile = (uint32_t*)(bbuf + BL.plan_tile);
+    if (sequential) {
+        // ---- K5s: the serial walk, one workgroup per tile
+        prof_begin(stream);
+        if (mask_q) {
+            vs.view_mask = mask_q;
+            hipLaunchKernelGGL(gsr_render_fwd_serial<true>, dim3(TA), dim3(256), 0, stream, tile_off, recs, sorted_ids, W, H, vc.gx,
+                               out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, order, shift,
+                               plan_off, plan_tile, counters + 4, (uint32_t)BL.plan_cap, counters, (uint32_t)M, maxc_cap, vs);
         }
-        const uint32_t mask_all = B >= 32 ? ~0u : ((1u << B) - 1u);
+        if (mask_q != mask_all) {
+            vs.view_mask = mask_all & ~mask_q;
+            hipLaunchKernelGGL(gsr_render_fwd_serial<false>, dim3(TA), dim3(256), 0, stream, tile_off, recs, sorted_ids, W, H, vc.gx,
+                               out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, order, shift,
+                               plan_off, plan_tile, counters + 4, (uint32_t)BL.plan_cap, counters, (uint32_t)M, maxc_cap, vs);
+        }
+        LAUNCH_CHECK(view, stream, "render_fwd");
+        return 0;
+    }
+    if (M > 0) {
+        // ---- K5a: every (tile, segment) composited on its own
         const uint32_t epoch = g_epoch.fetch_add(1u) + 1u;
         const int hint_mode = fwd_hint_env();
         unsigned long long* sat = (unsigned long long*)(gbuf + GL.sat);
+        const uint32_t* level_off = (const uint32_t*)(gbuf + GL.level_off);
+        uint4* items = (uint4*)(bbuf + BL.item_recs);
         // one workgroup per item (GSR_FWD_GRID = n: n workgroups striding through the list, an A/B switch -- measured 2x slower,
         // see the kernel)
         const char* ge = getenv("GSR_FWD_GRID");
@@ -477,17 +500,15 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
                                ckpt, shift, sat, epoch, hint_mode, counters, (uint32_t)M, maxc_cap, vs);
         }
         LAUNCH_CHECK(view, stream, "render_fwd");
-      }
     }
     // ---- K5b: chain the segments per pixel, outputs of the pixels that never stop, the backward's work list, walk items for K5c
     prof_begin(stream);
     uint2* walk_items = (uint2*)(bbuf + BL.walk_items);
     hipLaunchKernelGGL(gsr_render_fwd_combine, dim3(TA), dim3(256), 0, stream, tile_off, recs, sorted_ids, W, H, vc.gx,
                        out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, order, shift,
-                       (uint32_t*)(gbuf + GL.plan_off), (uint32_t*)(bbuf + BL.plan_tile),
-                       counters + 4, (uint32_t)BL.plan_cap, walk_items, counters + kWalkCounter, sequential ? 1 : 0, counters, (uint32_t)M, maxc_cap, vs);
+                       plan_off, plan_tile, counters + 4, (uint32_t)BL.plan_cap, walk_items, counters + kWalkCounter, counters, (uint32_t)M, maxc_cap, vs);
     LAUNCH_CHECK(view, stream, "render_combine");
-    if (M > 0 && !sequential) {   // ---- K5c: the pixels that stop inside a segment, one wave per (block, segment) item
+    if (M > 0) {   // ---- K5c: the pixels that stop inside a segment, one wave per (block, segment) item
         const unsigned grid_f = (unsigned)(TA < 2048 ? (TA < 64 ? 64 : TA) : 2048);
         prof_begin(stream);
         hipLaunchKernelGGL(gsr_render_fwd_fix, dim3(grid_f), dim3(256), 0, stream, (const uint2*)walk_items, (const unsigned long long*)(counters + kWalkCounter),

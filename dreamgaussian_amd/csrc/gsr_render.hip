@@ -287,6 +287,204 @@ template __global__ void gsr_render_fwd_seg<false>(const uint4*, const uint32_t*
 template __global__ void gsr_render_fwd_seg<true>(const uint4*, const uint32_t*, const uint32_t*, const SplatRec*, const uint32_t*, int, int, int,
                                                   float*, int, unsigned long long*, uint32_t, int, const unsigned long long*, uint32_t, uint32_t, ViewSplit);
 
+// =========================================================================================
+// K5s: forward, the serial walk -- for views that fill the chip on their own (fwd_sequential_for in gsr_api.hip).
+// One workgroup per tile (heaviest first), four independent waves = four 8x8 blocks. A wave fetches 64 list entries per
+// round, three rounds ahead (the gathers miss the XCD's L2 half of the time), tests each record exactly against its
+// block (QUAD: against each of its four 4x4 quads, one list of staged slots per 16-lane row), stages the survivors and
+// composites them; the per-pixel stop is exact where it happens and a wave leaves when its 64 pixels have stopped: every
+// vector instruction of the compositing is needed exactly once. At every segment cut the wave leaves the absolute
+// checkpoint the backward's segment starts from (the record K5b writes in the segmented mode); the tile's entries of the
+// backward's work list are reserved at the end as in K5b.
+// =========================================================================================
+template <bool QUAD>
+__global__ void __launch_bounds__(256)
+gsr_render_fwd_serial(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict__ recs,
+                      const uint32_t* __restrict__ ids, int W, int H, int gx,
+                      float* __restrict__ out_color, float* __restrict__ out_depth,
+                      float* __restrict__ out_alpha, float* __restrict__ final_T,
+                      uint32_t* __restrict__ n_contrib, float* __restrict__ totals /*[5][H*W]*/,
+                      float* __restrict__ rec_base, const uint32_t* __restrict__ tile_seg,
+                      const uint32_t* __restrict__ order, int seg_shift,
+                      uint32_t* __restrict__ plan_off, uint32_t* __restrict__ plan_tile,
+                      unsigned long long* __restrict__ plan_total, uint32_t plan_cap,
+                      const unsigned long long* __restrict__ counters, uint32_t capacity, uint32_t maxc_cap, ViewSplit vs) {
+    if (counters[2] > (unsigned long long)capacity || counters[3] > (unsigned long long)maxc_cap) return;
+    __shared__ float4 stage[4][3][GSR_RB + 2];
+    __shared__ __attribute__((aligned(8))) uint8_t qlist[QUAD ? 4 : 1][4][80];
+    __shared__ uint32_t wl[4];
+    __shared__ uint32_t plan_base;
+    const int tg = (int)order[blockIdx.x];                // heaviest tiles first
+    const int view = tg / vs.tiles_per_view;
+    if (!((vs.view_mask >> view) & 1u)) return;           // (workgroup-uniform) this view composites with the other instantiation
+    const int tile = tg - view * vs.tiles_per_view;
+    const float* __restrict__ bg = vs.bg[view];
+    {
+        const size_t HWv = (size_t)W * H;
+        recs += (size_t)view * vs.N;
+        out_color += view * 3 * HWv; out_depth += view * HWv; out_alpha += view * HWv;
+        final_T += view * vs.img_stride; n_contrib += view * vs.img_stride; totals += view * vs.img_stride;
+    }
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int row = lane >> 4, l15 = lane & 15;
+    const int bx = (tile % gx) * GSR_TILE + (wave & 1) * 8;
+    const int by = (tile / gx) * GSR_TILE + (wave >> 1) * 8;
+    const int lx = QUAD ? (row & 1) * 4 + (l15 & 3) : (lane & 7), ly = QUAD ? (row >> 1) * 4 + (l15 >> 2) : (lane >> 3);
+    const int px = bx + lx, py = by + ly;
+    const bool inside = (px < W) && (py < H);             // false for every lane of a block outside the image
+    const float pxf = (float)px, pyf = (float)py;
+    const float bx0 = (float)bx, by0 = (float)by;
+    const uint32_t start = tile_off[tg];
+    const uint32_t n = (bx < W && by < H) ? tile_off[tg + 1] - start : 0u;   // a block outside the image walks nothing
+    float* __restrict__ rec0 = rec_base + (size_t)tile_seg[tg] * GSR_CKPT_FLOATS + (wave * 64 + ly * 8 + lx);
+    float4* __restrict__ sa = stage[wave][0];
+    float4* __restrict__ sb = stage[wave][1];
+    float4* __restrict__ sc = stage[wave][2];
+    for (int q = lane; q < 3 * (GSR_RB + 2); q += 64) (&stage[wave][0][0])[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (QUAD) for (int q = lane; q < 4 * 80 / 4; q += 64) reinterpret_cast<uint32_t*>(&qlist[QUAD ? wave : 0][0][0])[q] = 0u;
+    wave_lds_handoff();
+
+    float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, A = 0.f;
+    uint32_t last = 0;
+    bool done = !inside;
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra, na = ra, nb = ra, nc = ra;
+    uint32_t id_next = 0;                                  // list entry of round r+2 (r+3 after the loads below)
+    if ((uint32_t)lane < n) {
+        const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + ids[start + lane]);
+        ra = p[0]; rb = p[1]; rc = p[2];
+    }
+    if (GSR_RB + (uint32_t)lane < n) {
+        const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + ids[start + GSR_RB + lane]);
+        na = p[0]; nb = p[1]; nc = p[2];
+    }
+    if (2 * GSR_RB + (uint32_t)lane < n) id_next = ids[start + 2 * GSR_RB + lane];
+    for (uint32_t rel = 0; rel < n; rel += GSR_RB) {
+        const unsigned long long alive = __ballot(!done);
+        if (alive == 0ull) break;
+        float4 ma = make_float4(0.f, 0.f, 0.f, 0.f), mb = ma, mc = ma;
+        uint32_t id_next2 = 0;
+        {
+            if (rel + 2 * GSR_RB + lane < n) {
+                const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + id_next);
+                ma = p[0]; mb = p[1]; mc = p[2];
+            }
+            if (rel + 3 * GSR_RB + lane < n) id_next2 = ids[start + rel + 3 * GSR_RB + lane];
+        }
+        if (rel != 0u && (rel & ((1u << seg_shift) - 1u)) == 0u && inside) {    // segment cut: checkpoint for the backward
+            float* c = rec0 + (size_t)((rel >> seg_shift) - 1u) * GSR_CKPT_FLOATS;
+            c[0] = T; c[256] = C0; c[512] = C1; c[768] = C2; c[1024] = D; c[1280] = A;
+        }
+        const uint32_t i = rel + lane;
+        if (!QUAD) {
+            bool hit = false;
+            if (i < n)      // can alpha reach 1/255 anywhere in this wave's 8x8 block?
+                hit = rect_max_power(ra.x, ra.y, ra.z, ra.w, rb.x, bx0, bx0 + 7.f, by0, by0 + 7.f) >= min_visible_power(rb.y);
+            const unsigned long long mask = __ballot(hit);
+            if (mask != 0ull) {
+                const int nhit = __popcll(mask);
+                if (hit) {
+                    const uint32_t pos = lanes_below(mask);
+                    rc.z = __uint_as_float(i + 1u);       // 1-based list position replaces the box
+                    sa[pos] = ra; sb[pos] = rb; sc[pos] = rc;
+                }
+                wave_lds_handoff();
+                float4 e0a = sa[0], e0b = sb[0], e0c = sc[0];
+                for (int j = 0; j < nhit; j += 2) {       // slots nhit, nhit+1 are padding: read, masked
+                    const float4 e1a = sa[j + 1], e1b = sb[j + 1], e1c = sc[j + 1];   // in flight during entry j
+                    GSR_COMPOSITE(e0a, e0b, e0c, __float_as_uint(e0c.z), true, 1.f, true)
+                    e0a = sa[j + 2]; e0b = sb[j + 2]; e0c = sc[j + 2];               // in flight during entry j+1
+                    GSR_COMPOSITE(e1a, e1b, e1c, __float_as_uint(e1c.z), j + 1 < nhit, 1.f, true)
+                }
+                wave_lds_handoff();                       // reads above precede the next round's writes
+            }
+        } else {
+            bool h0 = false, h1 = false, h2 = false, h3 = false;
+            if (i < n) {
+                const float thr = min_visible_power(rb.y);
+                float qp[4];
+                quad_max_powers(ra.x, ra.y, ra.z, ra.w, rb.x, bx0, by0, qp);
+                // a quad whose pixels have all stopped takes no more entries
+                h0 = ((alive & 0x000000000000ffffull) != 0ull) && qp[0] >= thr;
+                h1 = ((alive & 0x00000000ffff0000ull) != 0ull) && qp[1] >= thr;
+                h2 = ((alive & 0x0000ffff00000000ull) != 0ull) && qp[2] >= thr;
+                h3 = ((alive & 0xffff000000000000ull) != 0ull) && qp[3] >= thr;
+            }
+            const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
+            if ((m0 | m1 | m2 | m3) != 0ull) {
+                uint8_t (*qlw)[80] = qlist[QUAD ? wave : 0];
+                if (h0 | h1 | h2 | h3) { sa[lane] = ra; sb[lane] = rb; sc[lane] = rc; }
+                if (h0) qlw[0][lanes_below(m0)] = (uint8_t)lane;
+                if (h1) qlw[1][lanes_below(m1)] = (uint8_t)lane;
+                if (h2) qlw[2][lanes_below(m2)] = (uint8_t)lane;
+                if (h3) qlw[3][lanes_below(m3)] = (uint8_t)lane;
+                const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
+                const int nmax = max(max(n0, n1), max(n2, n3));
+                const int nmine = row == 0 ? n0 : (row == 1 ? n1 : (row == 2 ? n2 : n3));
+                const uint32_t pos1 = rel + 1u;           // 1-based list position of staged slot 0
+                const uint8_t* __restrict__ ql = qlw[row];
+                wave_lds_handoff();
+                for (int jb = 0; jb < nmax; jb += 8) {
+                    const uint2 sl = *reinterpret_cast<const uint2*>(ql + jb);
+                    uint32_t slot[8];
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) slot[b] = ((b < 4 ? sl.x : sl.y) >> (8 * (b & 3))) & 0xffu;
+                    float4 e0a = sa[slot[0]], e0b = sb[slot[0]], e0c = sc[slot[0]];
+#pragma unroll
+                    for (int b = 0; b < 8; b += 2) {
+                        if (jb + b < nmax) {              // wave-uniform
+                            const float4 e1a = sa[slot[b + 1]], e1b = sb[slot[b + 1]], e1c = sc[slot[b + 1]];   // in flight during entry b
+                            GSR_COMPOSITE(e0a, e0b, e0c, pos1 + slot[b], jb + b < nmine, 1.f, true)
+                            if (b + 2 < 8) { e0a = sa[slot[b + 2]]; e0b = sb[slot[b + 2]]; e0c = sc[slot[b + 2]]; }   // in flight during entry b+1
+                            GSR_COMPOSITE(e1a, e1b, e1c, pos1 + slot[b + 1], jb + b + 1 < nmine, 1.f, true)
+                        }
+                    }
+                }
+                wave_lds_handoff();                       // reads above precede the next round's writes
+            }
+        }
+        ra = na; rb = nb; rc = nc; na = ma; nb = mb; nc = mc; id_next = id_next2;
+    }
+    if (inside) {
+        const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
+        final_T[pix] = T;
+        n_contrib[pix] = last;
+        out_color[pix] = fmaf(T, bg[0], C0);
+        out_color[HW + pix] = fmaf(T, bg[1], C1);
+        out_color[2 * HW + pix] = fmaf(T, bg[2], C2);
+        out_depth[pix] = D;
+        out_alpha[pix] = A;
+        totals[pix] = C0; totals[HW + pix] = C1; totals[2 * HW + pix] = C2;   // sums without background
+        totals[3 * HW + pix] = D; totals[4 * HW + pix] = A;
+    }
+    // ---- how deep the backward has to walk this tile's list, and its (tile, segment) work items
+    {
+        const uint32_t wmax = wave_max_u32(inside ? last : 0u);
+        if (lane == 0) wl[wave] = wmax;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t tl = max(max(wl[0], wl[1]), max(wl[2], wl[3]));
+        const uint32_t segs = (tl + (1u << seg_shift) - 1u) >> seg_shift;
+        const uint32_t base = segs ? (uint32_t)atomicAdd(plan_total, (unsigned long long)segs) : 0u;
+        plan_off[tg] = base;
+        plan_base = base;
+        wl[0] = segs;
+    }
+    __syncthreads();
+    {
+        const uint32_t segs = wl[0], base = plan_base;
+        for (uint32_t q = threadIdx.x; q < segs; q += 256)
+            if (base + q < plan_cap) plan_tile[base + q] = (uint32_t)tg;
+    }
+}
+template __global__ void gsr_render_fwd_serial<false>(const uint32_t*, const SplatRec*, const uint32_t*, int, int, int, float*, float*, float*, float*,
+                                                      uint32_t*, float*, float*, const uint32_t*, const uint32_t*, int, uint32_t*, uint32_t*,
+                                                      unsigned long long*, uint32_t, const unsigned long long*, uint32_t, uint32_t, ViewSplit);
+template __global__ void gsr_render_fwd_serial<true>(const uint32_t*, const SplatRec*, const uint32_t*, int, int, int, float*, float*, float*, float*,
+                                                     uint32_t*, float*, float*, const uint32_t*, const uint32_t*, int, uint32_t*, uint32_t*,
+                                                     unsigned long long*, uint32_t, const unsigned long long*, uint32_t, uint32_t, ViewSplit);
+
 // The exact walk of list positions [lo, hi) of a tile for the lanes with done == false (lane = pixel, row-major 8x8 block at
 // (bx0, by0)), `gate` = their transmittance in front of the segment. Updates T, C0, C1, C2, D, A, last, done: the segment's own
 // numbers up to the stopping entry (done is set by a stop only). Same fetch / exact cull / stage / composite as K5a, block lists.
@@ -349,7 +547,6 @@ gsr_render_fwd_combine(const uint32_t* __restrict__ tile_off, const SplatRec* __
                        uint32_t* __restrict__ plan_off, uint32_t* __restrict__ plan_tile,
                        unsigned long long* __restrict__ plan_total, uint32_t plan_cap,
                        uint2* __restrict__ walk_items, unsigned long long* __restrict__ walk_total,
-                       int sequential /* no segment records exist: this kernel composites the tile's list front to back itself */,
                        const unsigned long long* __restrict__ counters, uint32_t capacity, uint32_t maxc_cap, ViewSplit vs) {
     if (counters[2] > (unsigned long long)capacity || counters[3] > (unsigned long long)maxc_cap) return;
     __shared__ float4 stage[4][3][GSR_RB + 2];
@@ -390,69 +587,6 @@ gsr_render_fwd_combine(const uint32_t* __restrict__ tile_off, const SplatRec* __
     uint32_t carry_last = 0;                              // ... and the pixel's deepest blended position in front of that segment
     uint32_t nwalk = 0;                                   // (wave-uniform) items handed to K5c
     bool alive = inside;
-    if (sequential) {
-        // ---- long lists (seg_mode_for): the serial walk. A wave fetches 64 list entries per round, three rounds ahead (the
-        // gathers miss the XCD's L2 half of the time), tests each record exactly against its 8x8 block, stages the survivors
-        // and composites them; the per-pixel stop is exact where it happens, and the wave leaves when its 64 pixels have
-        // stopped. At every segment cut it leaves the checkpoint the backward's segment starts from.
-        for (int q = lane; q < 3 * (GSR_RB + 2); q += 64) (&stage[wave][0][0])[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        wave_lds_handoff();
-        float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, A = 0.f;
-        uint32_t last = 0;
-        bool done = !inside;
-        float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra, na = ra, nb = ra, nc = ra;
-        uint32_t id_next = 0;                              // list entry of round r+2 (r+3 after the loads below)
-        if (lane < n) {
-            const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + ids[start + lane]);
-            ra = p[0]; rb = p[1]; rc = p[2];
-        }
-        if (GSR_RB + lane < n) {
-            const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + ids[start + GSR_RB + lane]);
-            na = p[0]; nb = p[1]; nc = p[2];
-        }
-        if (2 * GSR_RB + lane < n) id_next = ids[start + 2 * GSR_RB + lane];
-        for (uint32_t rel = 0; rel < n; rel += GSR_RB) {
-            if (__ballot(!done) == 0ull) break;
-            float4 ma = make_float4(0.f, 0.f, 0.f, 0.f), mb = ma, mc = ma;
-            uint32_t id_next2 = 0;
-            {
-                if (rel + 2 * GSR_RB + lane < n) {
-                    const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + id_next);
-                    ma = p[0]; mb = p[1]; mc = p[2];
-                }
-                if (rel + 3 * GSR_RB + lane < n) id_next2 = ids[start + rel + 3 * GSR_RB + lane];
-            }
-            if (rel != 0u && (rel & ((1u << seg_shift) - 1u)) == 0u && inside) {    // segment cut: checkpoint for the backward
-                float* c = rec0 + (size_t)((rel >> seg_shift) - 1u) * GSR_CKPT_FLOATS;
-                c[0] = T; c[256] = C0; c[512] = C1; c[768] = C2; c[1024] = D; c[1280] = A;
-            }
-            const uint32_t i = rel + lane;
-            bool hit = false;
-            if (i < n)      // can alpha reach 1/255 anywhere in this wave's 8x8 block?
-                hit = rect_max_power(ra.x, ra.y, ra.z, ra.w, rb.x, bx0, bx0 + 7.f, by0, by0 + 7.f) >= min_visible_power(rb.y);
-            const unsigned long long mask = __ballot(hit);
-            if (mask != 0ull) {
-                const int nhit = __popcll(mask);
-                if (hit) {
-                    const uint32_t pos = lanes_below(mask);
-                    rc.z = __uint_as_float(i + 1u);       // 1-based list position replaces the box
-                    sa[pos] = ra; sb[pos] = rb; sc[pos] = rc;
-                }
-                wave_lds_handoff();
-                float4 e0a = sa[0], e0b = sb[0], e0c = sc[0];
-                for (int j = 0; j < nhit; j += 2) {
-                    const float4 e1a = sa[j + 1], e1b = sb[j + 1], e1c = sc[j + 1];
-                    GSR_COMPOSITE(e0a, e0b, e0c, __float_as_uint(e0c.z), true, 1.f, true)
-                    e0a = sa[j + 2]; e0b = sb[j + 2]; e0c = sc[j + 2];
-                    GSR_COMPOSITE(e1a, e1b, e1c, __float_as_uint(e1c.z), j + 1 < nhit, 1.f, true)
-                }
-                wave_lds_handoff();
-            }
-            ra = na; rb = nb; rc = nc; na = ma; nb = mb; nc = mc; id_next = id_next2;
-        }
-        P = T; S0 = C0; S1 = C1; S2 = C2; SD = D; SA = A; last_abs = last;
-        alive = false;
-    }
     // The records of the next GSR_CQ segments are in flight while one is chained: a queue in registers, one record
     // requested per segment passed (the chain is a string of dependent ~1 us loads otherwise: 30-80 segments per tile)
 #define GSR_CQ 4
@@ -461,7 +595,7 @@ gsr_render_fwd_combine(const uint32_t* __restrict__ tile_off, const SplatRec* __
 #pragma unroll
     for (int j = 0; j < GSR_CQ; ++j) {
         qT[j] = 0.f; q0[j] = 0.f; q1[j] = 0.f; q2[j] = 0.f; qD[j] = 0.f; qA[j] = 0.f; qL[j] = 0u;
-        if ((uint32_t)j < nseg && inside && !sequential) {
+        if ((uint32_t)j < nseg && inside) {
             const float* __restrict__ r = rec0 + (size_t)j * GSR_CKPT_FLOATS;
             qT[j] = r[0]; q0[j] = r[256]; q1[j] = r[512]; q2[j] = r[768]; qD[j] = r[1024]; qA[j] = r[1280];
             qL[j] = reinterpret_cast<const uint32_t*>(r)[GSR_REC_LAST];

@@ -279,7 +279,12 @@ def composite_tile(pix, xy, conic, opac, color, depth, bg):
         gpow = torch.sqrt((conic[:, 0:1] * dx + conic[:, 1:2] * dy) ** 2 + (conic[:, 2:3] * dy + conic[:, 1:2] * dx) ** 2)
         band = FRAGILE_ALPHA_REL + gpow * FRAGILE_PX[0]          # relative alpha uncertainty of this pair
         frag = (power <= 1e-6) & ((alpha_raw.clamp_max(0.99) * 255.0 - 1.0).abs() < band)
-        frag = frag | (ok & ((T_after * 1e4 - 1.0).abs() < FRAGILE_T_REL[0])) | (power.abs() < 1e-6)
+        # the transmittance inherits the alpha errors of every Gaussian in front: d(1 - a) / (1 - a) = a / (1 - a) * da / a, i.e.
+        # amplified ~99x behind a near-opaque (alpha -> 0.99) Gaussian -- the trained stage-1 model is full of those, the synthetic
+        # scenes have none. Independent per-Gaussian errors add in quadrature; three sigma, never below the calibrated floor.
+        amp = torch.where(ok, a_eff / (one - a_eff), torch.zeros_like(alpha)) * band
+        t_band = torch.clamp_min(3.0 * torch.sqrt(torch.cumsum(amp * amp, dim=0)), FRAGILE_T_REL[0])
+        frag = frag | (ok & ((T_after * 1e4 - 1.0).abs() < t_band)) | (power.abs() < 1e-6)
         frag = frag & alive
         COMPOSITE_INFO["fragile_pix"] = frag.any(0)
         COMPOSITE_INFO["fragile_gauss"] = frag.any(1)
