@@ -681,18 +681,27 @@ int backward_impl(const GsrView* views, int B, int32_t N, int32_t K,
     if (lds > 160 * 1024) return fail(-1, "preprocess_bwd needs more than 160 KiB of LDS%s", "");
     auto k6 = vc.raw_act ? gsr_preprocess_bwd<true> : gsr_preprocess_bwd<false>;
     if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    // One launch per view, the LAST view first and the others added to it: the order in which autograd accumulates the
-    // parameter gradients of B separate rasterizer calls (the node created last runs first), so that the sums are
-    // bit-identical to the serial loop. dL_dmeans2D stays per view ([B,N,3]).
-    for (int v = B - 1; v >= 0; --v) {
-        const ViewConst vcv = make_view(views + v);
+    // The parameter gradients are the SUM over the views in the order autograd accumulates B separate rasterizer calls (the node
+    // created last runs first: last view first, then `earlier sum + this view`), so that the sums are bit-identical to the serial
+    // loop; dL_dmeans2D stays per view ([B,N,3]). Nothing staged through LDS (K == 1 or precomputed colours): ONE launch that
+    // reads each Gaussian once and runs through the cameras in registers. Otherwise one launch per view, adding to the first.
+    ViewTab tab;
+    memset(&tab, 0, sizeof(tab));
+    for (int v = 0; v < B; ++v) tab.v[v] = make_view(views + v);
+    if (lds == 0 || B == 1) {
         prof_begin(stream);
-        hipLaunchKernelGGL(k6, dim3(grid_n), dim3(256), lds, stream, vcv, N, K, means3D, shs, view->shs_rest, view->dL_dshs_rest,
-                           colors_precomp, opacities, scales, rotations, cov3D_precomp, radii + (size_t)v * N,
-                           (const uint8_t*)(gbuf + GL.flags8) + (size_t)v * N, g2d + (size_t)v * g2d_view,
-                           dL_dmeans3D, dL_dmeans2D + (size_t)v * N * 3, dL_dshs, dL_dcolors, dL_dopacities, dL_dscales,
-                           dL_drotations, dL_dcov3D, v == B - 1 ? 0 : 1);
+        hipLaunchKernelGGL(k6, dim3(grid_n), dim3(256), lds, stream, tab, 0, B, N, K, means3D, shs, view->shs_rest, view->dL_dshs_rest,
+                           colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, (const uint8_t*)(gbuf + GL.flags8), g2d,
+                           dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacities, dL_dscales, dL_drotations, dL_dcov3D, 0);
         LAUNCH_CHECK(view, stream, "preprocess_bwd");
+    } else {
+        for (int v = B - 1; v >= 0; --v) {
+            prof_begin(stream);
+            hipLaunchKernelGGL(k6, dim3(grid_n), dim3(256), lds, stream, tab, v, 1, N, K, means3D, shs, view->shs_rest, view->dL_dshs_rest,
+                               colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, (const uint8_t*)(gbuf + GL.flags8), g2d,
+                               dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacities, dL_dscales, dL_drotations, dL_dcov3D, v == B - 1 ? 0 : 1);
+            LAUNCH_CHECK(view, stream, "preprocess_bwd");
+        }
     }
     return 0;
 }

@@ -497,17 +497,226 @@ gsr_preprocess_fwd(ViewTab views /* camera of this workgroup: views.v[blockIdx.y
 // forward intermediates from the inputs instead of re-reading saved state.
 // dynamic LDS: blockDim.x * (3K+1) floats when shs (used for SH in, then dSH out).
 // ---------------------------------------------------------------------------------------
+// One (view, Gaussian) of K6: the gradients of this view's 2D quantities (g2d) carried to the Gaussian's parameters.
+// Outputs are THIS view's contributions (exact zeros for a Gaussian the view culled); the callers add views up.
+struct K6Out { float dm[3], dm2[2], dop, dsc[3], dq[4], dcov[6], dcol[3], dsh[3]; };
+template <bool RAW>
+__device__ __forceinline__ void k6_gaussian(const ViewConst& vc, int idx, int N, int K, bool live,
+                                            const float* __restrict__ means3D, const float* __restrict__ shs,
+                                            const float* __restrict__ opacities, const float* __restrict__ scales,
+                                            const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
+                                            const uint8_t* __restrict__ flags8, const float* __restrict__ g2d,
+                                            float* __restrict__ dL_dshs, bool stage, float* myrow, int accumulate,
+                                            bool sh_reg /* K == 1, several views per launch: dL/dSH of this view goes to out.dsh */, K6Out& out) {
+    const int rowlen = 3 * K;
+    const bool use_sh = (shs != nullptr);
+    const float* __restrict__ V = vc.view;
+    const float* __restrict__ P = vc.proj;
+    out.dm[0] = out.dm[1] = out.dm[2] = 0.f; out.dm2[0] = out.dm2[1] = 0.f; out.dop = 0.f; out.dsc[0] = out.dsc[1] = out.dsc[2] = 0.f; out.dq[0] = out.dq[1] = out.dq[2] = out.dq[3] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) out.dcov[e] = 0.f;
+    out.dcol[0] = out.dcol[1] = out.dcol[2] = 0.f;
+    out.dsh[0] = out.dsh[1] = out.dsh[2] = 0.f;
+    if (live) {
+        const float* g = g2d + (size_t)idx * GSR_G2D_STRIDE;
+        const uint32_t flags = flags8[idx];
+        const float mx = means3D[3 * idx], my = means3D[3 * idx + 1], mz = means3D[3 * idx + 2];
+        float3 pv;
+        pv.x = V[0] * mx + V[4] * my + V[8] * mz + V[12];
+        pv.y = V[1] * mx + V[5] * my + V[9] * mz + V[13];
+        pv.z = view_depth(V, mx, my, mz);
+        const float hx = P[0] * mx + P[4] * my + P[8] * mz + P[12];
+        const float hy = P[1] * mx + P[5] * my + P[9] * mz + P[13];
+        const float hw = P[3] * mx + P[7] * my + P[11] * mz + P[15];
+        const float m_w = 1.0f / (hw + 0.0000001f);
+
+        // ---- screen-space mean ------------------------------------------------------
+        const float gmx = g[0] * (GSR_LN2 * 0.5f * vc.W);   // dL/d ndc.x
+        const float gmy = g[1] * (GSR_LN2 * 0.5f * vc.H);
+        out.dm2[0] = gmx; out.dm2[1] = gmy;
+        const float mul1 = hx * m_w * m_w, mul2 = hy * m_w * m_w;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            out.dm[k] = (P[4 * k] * m_w - P[4 * k + 3] * mul1) * gmx + (P[4 * k + 1] * m_w - P[4 * k + 3] * mul2) * gmy;
+        // ---- depth ------------------------------------------------------------------
+        const float gdepth = g[9];
+        out.dm[0] += V[2] * gdepth; out.dm[1] += V[6] * gdepth; out.dm[2] += V[10] * gdepth;
+        // ---- opacity ----------------------------------------------------------------
+        out.dop = g[5];
+        if (RAW) { const float o = act_sigmoid(opacities[idx]); out.dop *= o * (1.f - o); }   // d sigmoid
+
+        // ---- colour -----------------------------------------------------------------
+        float gr = g[6], gg = g[7], gb = g[8];
+        if (!use_sh) {
+            out.dcol[0] = gr; out.dcol[1] = gg; out.dcol[2] = gb;
+        } else {
+            if (flags & 1u) gr = 0.f;
+            if (flags & 2u) gg = 0.f;
+            if (flags & 4u) gb = 0.f;
+            float dx = mx - vc.campos[0], dy = my - vc.campos[1], dz = mz - vc.campos[2];
+            const float len2 = dx * dx + dy * dy + dz * dz;
+            const float inv = 1.f / sqrtf(len2);
+            const float x = dx * inv, y = dy * inv, z = dz * inv;
+            const int deg = vc.sh_degree;
+            const int nb = (deg + 1) * (deg + 1);
+            float B[16];
+            sh_basis(deg, x, y, z, B);
+            const float* row = stage ? myrow : (shs + (size_t)idx * rowlen);
+            // direction derivative: dRGB/d(x,y,z) contracted with (gr,gg,gb)
+            float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+            if (deg > 0) {
+                float s[16];   // s[k] = sh[k] . grad_rgb
+#pragma unroll
+                for (int k = 1; k < 16; ++k)
+                    s[k] = (k < nb) ? (row[3 * k] * gr + row[3 * k + 1] * gg + row[3 * k + 2] * gb) : 0.f;
+                ddx = -SH_C1 * s[3]; ddy = -SH_C1 * s[1]; ddz = SH_C1 * s[2];
+                if (deg > 1) {
+                    const float xx = x * x, yy = y * y, zz = z * z;
+                    ddx += SH_C2_0 * y * s[4] + SH_C2_2 * (-2.f * x) * s[6] + SH_C2_3 * z * s[7] + SH_C2_4 * (2.f * x) * s[8];
+                    ddy += SH_C2_0 * x * s[4] + SH_C2_1 * z * s[5] + SH_C2_2 * (-2.f * y) * s[6] + SH_C2_4 * (-2.f * y) * s[8];
+                    ddz += SH_C2_1 * y * s[5] + SH_C2_2 * (4.f * z) * s[6] + SH_C2_3 * x * s[7];
+                    if (deg > 2) {
+                        ddx += SH_C3_0 * (6.f * x * y) * s[9] + SH_C3_1 * (y * z) * s[10] + SH_C3_2 * (-2.f * x * y) * s[11]
+                             + SH_C3_3 * (-6.f * x * z) * s[12] + SH_C3_4 * (4.f * zz - 3.f * xx - yy) * s[13]
+                             + SH_C3_5 * (2.f * x * z) * s[14] + SH_C3_6 * (3.f * xx - 3.f * yy) * s[15];
+                        ddy += SH_C3_0 * (3.f * xx - 3.f * yy) * s[9] + SH_C3_1 * (x * z) * s[10]
+                             + SH_C3_2 * (4.f * zz - xx - 3.f * yy) * s[11] + SH_C3_3 * (-6.f * y * z) * s[12]
+                             + SH_C3_4 * (-2.f * x * y) * s[13] + SH_C3_5 * (-2.f * y * z) * s[14]
+                             + SH_C3_6 * (-6.f * x * y) * s[15];
+                        ddz += SH_C3_1 * (x * y) * s[10] + SH_C3_2 * (8.f * y * z) * s[11]
+                             + SH_C3_3 * (6.f * zz - 3.f * xx - 3.f * yy) * s[12] + SH_C3_4 * (8.f * x * z) * s[13]
+                             + SH_C3_5 * (xx - yy) * s[14];
+                    }
+                }
+                // through the normalisation: (I - d d^T)/|p| applied to (ddx,ddy,ddz)
+                const float dot = x * ddx + y * ddy + z * ddz;
+                out.dm[0] += (ddx - x * dot) * inv; out.dm[1] += (ddy - y * dot) * inv; out.dm[2] += (ddz - z * dot) * inv;
+            }
+            // dL/dSH: write this lane's row (the staged input row is dead now)
+            if (sh_reg) { out.dsh[0] = B[0] * gr; out.dsh[1] = B[0] * gg; out.dsh[2] = B[0] * gb; }
+            float* o = stage ? myrow : (dL_dshs + (size_t)idx * rowlen);
+#pragma unroll
+            for (int k = 0; k < 16 && !sh_reg; ++k) {
+                if (k < K) {
+                    const float bk = (k < nb) ? B[k] : 0.f;
+                    if (!stage && accumulate && !sh_reg) { o[3 * k] += bk * gr; o[3 * k + 1] += bk * gg; o[3 * k + 2] += bk * gb; }   // K == 1: straight to HBM
+                    else { o[3 * k] = bk * gr; o[3 * k + 1] = bk * gg; o[3 * k + 2] = bk * gb; }
+                }
+            }
+            if (!sh_reg && (stage || !accumulate)) for (int e = 48; e < rowlen; ++e) o[e] = 0.f;   // K > 16: inactive coefficients
+        }
+
+        // ---- conic -> cov2D -> (Sigma, t) -------------------------------------------
+        Cov3 S;
+        float R[9];
+        float3 s = make_float3(0.f, 0.f, 0.f);
+        float4 q = make_float4(1.f, 0.f, 0.f, 0.f);
+        float3 s_act = make_float3(1.f, 1.f, 1.f);
+        float q_inv_norm = 1.f;
+        if (cov3D_precomp) {
+            const float* c = cov3D_precomp + 6 * (size_t)idx;
+            S.c0 = c[0]; S.c1 = c[1]; S.c2 = c[2]; S.c3 = c[3]; S.c4 = c[4]; S.c5 = c[5];
+        } else {
+            q = reinterpret_cast<const float4*>(rotations)[idx];
+            s.x = scales[3 * idx]; s.y = scales[3 * idx + 1]; s.z = scales[3 * idx + 2];
+            if (RAW) { q = act_normalize(q, &q_inv_norm); s.x = __expf(s.x); s.y = __expf(s.y); s.z = __expf(s.z); }
+            s_act = s;
+            s.x *= vc.scale_modifier; s.y *= vc.scale_modifier; s.z *= vc.scale_modifier;
+            quat_to_R(q, R);
+            S = cov3d_from_scale_rot(s, R);
+        }
+        const Proj2D pj = project_cov(vc, V, pv, S);
+        const float a = pj.a, b = pj.b, c = pj.c;
+        const float det = a * c - b * b;
+        const float d2i = 1.f / (det * det + 0.0000001f);   // the external package's guard (denom2inv); det >= 0.09 for PSD covariances
+        const float gA = g[2], gB = g[3], gC = g[4];
+        const float dLa = d2i * (-c * c * gA + b * c * gB - b * b * gC);
+        const float dLb = d2i * (2.f * b * c * gA - (a * c + b * b) * gB + 2.f * a * b * gC);
+        const float dLc = d2i * (-b * b * gA + a * b * gB - a * a * gC);
+
+        // G = dLa T0^T T0 + dLb sym(T0^T T1) + dLc T1^T T1   (gradient w.r.t. Sigma entries)
+        const float* T0 = pj.T0; const float* T1 = pj.T1;
+        float Gm[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                Gm[3 * i + j] = dLa * T0[i] * T0[j] + 0.5f * dLb * (T0[i] * T1[j] + T1[i] * T0[j]) + dLc * T1[i] * T1[j];
+        if (cov3D_precomp) {
+            out.dcov[0] = Gm[0]; out.dcov[1] = 2.f * Gm[1]; out.dcov[2] = 2.f * Gm[2];
+            out.dcov[3] = Gm[4]; out.dcov[4] = 2.f * Gm[5]; out.dcov[5] = Gm[8];
+        } else {
+            // Sigma = M M^T, M = R diag(s): dL/dM = 2 G M
+            float M[9], dM[9];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { M[3 * i] = R[3 * i] * s.x; M[3 * i + 1] = R[3 * i + 1] * s.y; M[3 * i + 2] = R[3 * i + 2] * s.z; }
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    dM[3 * i + j] = 2.f * (Gm[3 * i] * M[j] + Gm[3 * i + 1] * M[3 + j] + Gm[3 * i + 2] * M[6 + j]);
+            const float sv[3] = {s.x, s.y, s.z};
+            float dR[9];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                out.dsc[j] = vc.scale_modifier * (dM[j] * R[j] + dM[3 + j] * R[3 + j] + dM[6 + j] * R[6 + j]);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) dR[3 * i + j] = dM[3 * i + j] * sv[j];
+            }
+            const float r = q.x, x = q.y, y = q.z, z = q.w;
+            out.dq[0] = 2.f * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
+            out.dq[1] = 2.f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.f * x * dR[8]);
+            out.dq[2] = 2.f * (-2.f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.f * y * dR[8]);
+            out.dq[3] = 2.f * (-2.f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
+            if (RAW) {                              // d exp and d normalise
+                out.dsc[0] *= s_act.x; out.dsc[1] *= s_act.y; out.dsc[2] *= s_act.z;
+                const float qd = q.x * out.dq[0] + q.y * out.dq[1] + q.z * out.dq[2] + q.w * out.dq[3];
+                out.dq[0] = (out.dq[0] - q.x * qd) * q_inv_norm; out.dq[1] = (out.dq[1] - q.y * qd) * q_inv_norm;
+                out.dq[2] = (out.dq[2] - q.z * qd) * q_inv_norm; out.dq[3] = (out.dq[3] - q.w * qd) * q_inv_norm;
+            }
+        }
+        // dL/dT rows: dT0 = 2 dLa Sigma T0 + dLb Sigma T1 ; dT1 = 2 dLc Sigma T1 + dLb Sigma T0
+        const float u0 = S.c0 * T0[0] + S.c1 * T0[1] + S.c2 * T0[2];
+        const float u1 = S.c1 * T0[0] + S.c3 * T0[1] + S.c4 * T0[2];
+        const float u2 = S.c2 * T0[0] + S.c4 * T0[1] + S.c5 * T0[2];
+        const float w0 = S.c0 * T1[0] + S.c1 * T1[1] + S.c2 * T1[2];
+        const float w1 = S.c1 * T1[0] + S.c3 * T1[1] + S.c4 * T1[2];
+        const float w2 = S.c2 * T1[0] + S.c4 * T1[1] + S.c5 * T1[2];
+        const float dT0[3] = {2.f * dLa * u0 + dLb * w0, 2.f * dLa * u1 + dLb * w1, 2.f * dLa * u2 + dLb * w2};
+        const float dT1[3] = {2.f * dLc * w0 + dLb * u0, 2.f * dLc * w1 + dLb * u1, 2.f * dLc * w2 + dLb * u2};
+        // T = J Wr, Wr[i][k] = V[4k+i]:  dJ[r][i] = sum_k dT[r][k] * V[4k+i]
+        float dJ00 = 0.f, dJ02 = 0.f, dJ11 = 0.f, dJ12 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            dJ00 += dT0[k] * V[4 * k + 0]; dJ02 += dT0[k] * V[4 * k + 2];
+            dJ11 += dT1[k] * V[4 * k + 1]; dJ12 += dT1[k] * V[4 * k + 2];
+        }
+        const float tz = 1.f / pj.tz, tz2 = tz * tz, tz3 = tz2 * tz;
+        const float dtx = pj.clampx ? 0.f : -vc.focal_x * tz2 * dJ02;
+        const float dty = pj.clampy ? 0.f : -vc.focal_y * tz2 * dJ12;
+        const float dtz = -vc.focal_x * tz2 * dJ00 - vc.focal_y * tz2 * dJ11
+                        + (2.f * vc.focal_x * pj.tx) * tz3 * dJ02 + (2.f * vc.focal_y * pj.ty) * tz3 * dJ12;
+        // t_i = sum_k m_k V[4k+i]
+#pragma unroll
+        for (int k = 0; k < 3; ++k) out.dm[k] += V[4 * k] * dtx + V[4 * k + 1] * dty + V[4 * k + 2] * dtz;
+    } else if (idx < N && use_sh && !sh_reg) {
+        if (stage) { for (int e = 0; e < rowlen; ++e) myrow[e] = 0.f; }
+        else if (!accumulate) { float* o = dL_dshs + (size_t)idx * rowlen; for (int e = 0; e < rowlen; ++e) o[e] = 0.f; }
+    }
+
+}
+
 template <bool RAW>   // RAW: inputs are the raw parameters (fused sigmoid / exp / normalise backward)
 __global__ void __launch_bounds__(256)
-gsr_preprocess_bwd(ViewConst vc, int N, int K,
+gsr_preprocess_bwd(ViewTab tab, int first_view, int B /* views first_view .. first_view + B - 1 of the table in THIS launch */, int N, int K,
                    const float* __restrict__ means3D, const float* __restrict__ shs,
                    const float* __restrict__ shs_rest /* split layout (GsrView.shs_rest) or NULL */,
                    float* __restrict__ dL_dshs_rest,
                    const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
                    const float* __restrict__ scales, const float* __restrict__ rotations,
-                   const float* __restrict__ cov3D_precomp, const int32_t* __restrict__ radii,
-                   const uint8_t* __restrict__ flags8, const float* __restrict__ g2d,
-                   float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
+                   const float* __restrict__ cov3D_precomp, const int32_t* __restrict__ radii /* [views][N] */,
+                   const uint8_t* __restrict__ flags8 /* [views][N] */, const float* __restrict__ g2d /* [views][N][12] */,
+                   float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D /* [views][N][3] */,
                    float* __restrict__ dL_dshs, float* __restrict__ dL_dcolors,
                    float* __restrict__ dL_dopac, float* __restrict__ dL_dscales,
                    float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D,
@@ -518,9 +727,17 @@ gsr_preprocess_bwd(ViewConst vc, int N, int K,
     const int rowlen = 3 * K;
     const bool use_sh = (shs != nullptr);
     const bool stage = use_sh && (K > 1);
-    const float* __restrict__ V = vc.view;
-    const float* __restrict__ P = vc.proj;
-
+    // Several views in one launch (B > 1; the host does this when nothing is staged through LDS: K == 1 -- DreamGaussian's
+    // sh_degree 0 -- or precomputed colours): every Gaussian is read ONCE and the cameras are run through in registers, last
+    // view first and `earlier sum + this view` after that -- the additions of B separate launches (= the order autograd
+    // accumulates B separate calls) in the same order, so the sums are bit-identical to them, without B - 1 read-modify-write
+    // passes over the gradients. The cameras go from the by-value table to LDS (they are indexed with a run-time view number).
+    __shared__ ViewConst sv[GSR_MAX_VIEWS];
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int v = 0; v < GSR_MAX_VIEWS; ++v) sv[v] = tab.v[v];
+    }
+    __syncthreads();
     for (int base = blockIdx.x * blockDim.x; base < N; base += gridDim.x * blockDim.x) {
         const int cnt = min((int)blockDim.x, N - base);
         if (stage) {
@@ -530,222 +747,55 @@ gsr_preprocess_bwd(ViewConst vc, int N, int K,
             __syncthreads();
         }
         const int idx = base + threadIdx.x;
-        float dm[3] = {0.f, 0.f, 0.f};
-        float dm2[2] = {0.f, 0.f};
-        float dop = 0.f, dsc[3] = {0.f, 0.f, 0.f}, dq[4] = {0.f, 0.f, 0.f, 0.f};
-        float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        float dcol[3] = {0.f, 0.f, 0.f};
+        K6Out out, cur;
+        float tsh[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 3; ++e) { out.dm[e] = 0.f; out.dsc[e] = 0.f; out.dcol[e] = 0.f; }
+        out.dop = 0.f; out.dm2[0] = out.dm2[1] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out.dq[e] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) out.dcov[e] = 0.f;
         float* myrow = shbuf + threadIdx.x * (rowlen + 1);
-        const bool live = (idx < N) && (radii[idx] > 0);
-
-        if (live) {
-            const float* g = g2d + (size_t)idx * GSR_G2D_STRIDE;
-            const uint32_t flags = flags8[idx];
-            const float mx = means3D[3 * idx], my = means3D[3 * idx + 1], mz = means3D[3 * idx + 2];
-            float3 pv;
-            pv.x = V[0] * mx + V[4] * my + V[8] * mz + V[12];
-            pv.y = V[1] * mx + V[5] * my + V[9] * mz + V[13];
-            pv.z = view_depth(V, mx, my, mz);
-            const float hx = P[0] * mx + P[4] * my + P[8] * mz + P[12];
-            const float hy = P[1] * mx + P[5] * my + P[9] * mz + P[13];
-            const float hw = P[3] * mx + P[7] * my + P[11] * mz + P[15];
-            const float m_w = 1.0f / (hw + 0.0000001f);
-
-            // ---- screen-space mean ------------------------------------------------------
-            const float gmx = g[0] * (GSR_LN2 * 0.5f * vc.W);   // dL/d ndc.x
-            const float gmy = g[1] * (GSR_LN2 * 0.5f * vc.H);
-            dm2[0] = gmx; dm2[1] = gmy;
-            const float mul1 = hx * m_w * m_w, mul2 = hy * m_w * m_w;
+        const bool sh_in_regs = B > 1;                    // (then K == 1: three numbers per view)
+        for (int v = first_view + B - 1; v >= first_view; --v) {
+            const ViewConst vc = sv[v];
+            const bool live = (idx < N) && (radii[(size_t)v * N + idx] > 0);
+            k6_gaussian<RAW>(vc, idx, N, K, live, means3D, shs, opacities, scales, rotations, cov3D_precomp, flags8 + (size_t)v * N,
+                             g2d + (size_t)v * N * GSR_G2D_STRIDE, dL_dshs, stage, myrow, accumulate, sh_in_regs, cur);
+            if (idx < N) { float* m2 = dL_dmeans2D + ((size_t)v * N + idx) * 3; m2[0] = cur.dm2[0]; m2[1] = cur.dm2[1]; m2[2] = 0.f; }
+            // first pass (the last view): 0 + x = x exactly
 #pragma unroll
-            for (int k = 0; k < 3; ++k)
-                dm[k] = (P[4 * k] * m_w - P[4 * k + 3] * mul1) * gmx + (P[4 * k + 1] * m_w - P[4 * k + 3] * mul2) * gmy;
-            // ---- depth ------------------------------------------------------------------
-            const float gdepth = g[9];
-            dm[0] += V[2] * gdepth; dm[1] += V[6] * gdepth; dm[2] += V[10] * gdepth;
-            // ---- opacity ----------------------------------------------------------------
-            dop = g[5];
-            if (RAW) { const float o = act_sigmoid(opacities[idx]); dop *= o * (1.f - o); }   // d sigmoid
-
-            // ---- colour -----------------------------------------------------------------
-            float gr = g[6], gg = g[7], gb = g[8];
-            if (!use_sh) {
-                dcol[0] = gr; dcol[1] = gg; dcol[2] = gb;
-            } else {
-                if (flags & 1u) gr = 0.f;
-                if (flags & 2u) gg = 0.f;
-                if (flags & 4u) gb = 0.f;
-                float dx = mx - vc.campos[0], dy = my - vc.campos[1], dz = mz - vc.campos[2];
-                const float len2 = dx * dx + dy * dy + dz * dz;
-                const float inv = 1.f / sqrtf(len2);
-                const float x = dx * inv, y = dy * inv, z = dz * inv;
-                const int deg = vc.sh_degree;
-                const int nb = (deg + 1) * (deg + 1);
-                float B[16];
-                sh_basis(deg, x, y, z, B);
-                const float* row = stage ? myrow : (shs + (size_t)idx * rowlen);
-                // direction derivative: dRGB/d(x,y,z) contracted with (gr,gg,gb)
-                float ddx = 0.f, ddy = 0.f, ddz = 0.f;
-                if (deg > 0) {
-                    float s[16];   // s[k] = sh[k] . grad_rgb
+            for (int e = 0; e < 3; ++e) { out.dm[e] = out.dm[e] + cur.dm[e]; out.dsc[e] = out.dsc[e] + cur.dsc[e]; out.dcol[e] = out.dcol[e] + cur.dcol[e]; tsh[e] = tsh[e] + cur.dsh[e]; }
+            out.dop = out.dop + cur.dop;
 #pragma unroll
-                    for (int k = 1; k < 16; ++k)
-                        s[k] = (k < nb) ? (row[3 * k] * gr + row[3 * k + 1] * gg + row[3 * k + 2] * gb) : 0.f;
-                    ddx = -SH_C1 * s[3]; ddy = -SH_C1 * s[1]; ddz = SH_C1 * s[2];
-                    if (deg > 1) {
-                        const float xx = x * x, yy = y * y, zz = z * z;
-                        ddx += SH_C2_0 * y * s[4] + SH_C2_2 * (-2.f * x) * s[6] + SH_C2_3 * z * s[7] + SH_C2_4 * (2.f * x) * s[8];
-                        ddy += SH_C2_0 * x * s[4] + SH_C2_1 * z * s[5] + SH_C2_2 * (-2.f * y) * s[6] + SH_C2_4 * (-2.f * y) * s[8];
-                        ddz += SH_C2_1 * y * s[5] + SH_C2_2 * (4.f * z) * s[6] + SH_C2_3 * x * s[7];
-                        if (deg > 2) {
-                            ddx += SH_C3_0 * (6.f * x * y) * s[9] + SH_C3_1 * (y * z) * s[10] + SH_C3_2 * (-2.f * x * y) * s[11]
-                                 + SH_C3_3 * (-6.f * x * z) * s[12] + SH_C3_4 * (4.f * zz - 3.f * xx - yy) * s[13]
-                                 + SH_C3_5 * (2.f * x * z) * s[14] + SH_C3_6 * (3.f * xx - 3.f * yy) * s[15];
-                            ddy += SH_C3_0 * (3.f * xx - 3.f * yy) * s[9] + SH_C3_1 * (x * z) * s[10]
-                                 + SH_C3_2 * (4.f * zz - xx - 3.f * yy) * s[11] + SH_C3_3 * (-6.f * y * z) * s[12]
-                                 + SH_C3_4 * (-2.f * x * y) * s[13] + SH_C3_5 * (-2.f * y * z) * s[14]
-                                 + SH_C3_6 * (-6.f * x * y) * s[15];
-                            ddz += SH_C3_1 * (x * y) * s[10] + SH_C3_2 * (8.f * y * z) * s[11]
-                                 + SH_C3_3 * (6.f * zz - 3.f * xx - 3.f * yy) * s[12] + SH_C3_4 * (8.f * x * z) * s[13]
-                                 + SH_C3_5 * (xx - yy) * s[14];
-                        }
-                    }
-                    // through the normalisation: (I - d d^T)/|p| applied to (ddx,ddy,ddz)
-                    const float dot = x * ddx + y * ddy + z * ddz;
-                    dm[0] += (ddx - x * dot) * inv; dm[1] += (ddy - y * dot) * inv; dm[2] += (ddz - z * dot) * inv;
-                }
-                // dL/dSH: write this lane's row (the staged input row is dead now)
-                float* o = stage ? myrow : (dL_dshs + (size_t)idx * rowlen);
+            for (int e = 0; e < 4; ++e) out.dq[e] = out.dq[e] + cur.dq[e];
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    if (k < K) {
-                        const float bk = (k < nb) ? B[k] : 0.f;
-                        if (!stage && accumulate) { o[3 * k] += bk * gr; o[3 * k + 1] += bk * gg; o[3 * k + 2] += bk * gb; }   // K == 1: straight to HBM
-                        else { o[3 * k] = bk * gr; o[3 * k + 1] = bk * gg; o[3 * k + 2] = bk * gb; }
-                    }
-                }
-                if (stage || !accumulate) for (int e = 48; e < rowlen; ++e) o[e] = 0.f;   // K > 16: inactive coefficients
-            }
-
-            // ---- conic -> cov2D -> (Sigma, t) -------------------------------------------
-            Cov3 S;
-            float R[9];
-            float3 s = make_float3(0.f, 0.f, 0.f);
-            float4 q = make_float4(1.f, 0.f, 0.f, 0.f);
-            float3 s_act = make_float3(1.f, 1.f, 1.f);
-            float q_inv_norm = 1.f;
-            if (cov3D_precomp) {
-                const float* c = cov3D_precomp + 6 * (size_t)idx;
-                S.c0 = c[0]; S.c1 = c[1]; S.c2 = c[2]; S.c3 = c[3]; S.c4 = c[4]; S.c5 = c[5];
-            } else {
-                q = reinterpret_cast<const float4*>(rotations)[idx];
-                s.x = scales[3 * idx]; s.y = scales[3 * idx + 1]; s.z = scales[3 * idx + 2];
-                if (RAW) { q = act_normalize(q, &q_inv_norm); s.x = __expf(s.x); s.y = __expf(s.y); s.z = __expf(s.z); }
-                s_act = s;
-                s.x *= vc.scale_modifier; s.y *= vc.scale_modifier; s.z *= vc.scale_modifier;
-                quat_to_R(q, R);
-                S = cov3d_from_scale_rot(s, R);
-            }
-            const Proj2D pj = project_cov(vc, V, pv, S);
-            const float a = pj.a, b = pj.b, c = pj.c;
-            const float det = a * c - b * b;
-            const float d2i = 1.f / (det * det + 0.0000001f);   // the external package's guard (denom2inv); det >= 0.09 for PSD covariances
-            const float gA = g[2], gB = g[3], gC = g[4];
-            const float dLa = d2i * (-c * c * gA + b * c * gB - b * b * gC);
-            const float dLb = d2i * (2.f * b * c * gA - (a * c + b * b) * gB + 2.f * a * b * gC);
-            const float dLc = d2i * (-b * b * gA + a * b * gB - a * a * gC);
-
-            // G = dLa T0^T T0 + dLb sym(T0^T T1) + dLc T1^T T1   (gradient w.r.t. Sigma entries)
-            const float* T0 = pj.T0; const float* T1 = pj.T1;
-            float Gm[9];
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 3; ++j)
-                    Gm[3 * i + j] = dLa * T0[i] * T0[j] + 0.5f * dLb * (T0[i] * T1[j] + T1[i] * T0[j]) + dLc * T1[i] * T1[j];
-            if (cov3D_precomp) {
-                dcov[0] = Gm[0]; dcov[1] = 2.f * Gm[1]; dcov[2] = 2.f * Gm[2];
-                dcov[3] = Gm[4]; dcov[4] = 2.f * Gm[5]; dcov[5] = Gm[8];
-            } else {
-                // Sigma = M M^T, M = R diag(s): dL/dM = 2 G M
-                float M[9], dM[9];
-#pragma unroll
-                for (int i = 0; i < 3; ++i) { M[3 * i] = R[3 * i] * s.x; M[3 * i + 1] = R[3 * i + 1] * s.y; M[3 * i + 2] = R[3 * i + 2] * s.z; }
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int j = 0; j < 3; ++j)
-                        dM[3 * i + j] = 2.f * (Gm[3 * i] * M[j] + Gm[3 * i + 1] * M[3 + j] + Gm[3 * i + 2] * M[6 + j]);
-                const float sv[3] = {s.x, s.y, s.z};
-                float dR[9];
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    dsc[j] = vc.scale_modifier * (dM[j] * R[j] + dM[3 + j] * R[3 + j] + dM[6 + j] * R[6 + j]);
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) dR[3 * i + j] = dM[3 * i + j] * sv[j];
-                }
-                const float r = q.x, x = q.y, y = q.z, z = q.w;
-                dq[0] = 2.f * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
-                dq[1] = 2.f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.f * x * dR[8]);
-                dq[2] = 2.f * (-2.f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.f * y * dR[8]);
-                dq[3] = 2.f * (-2.f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
-                if (RAW) {                              // d exp and d normalise
-                    dsc[0] *= s_act.x; dsc[1] *= s_act.y; dsc[2] *= s_act.z;
-                    const float qd = q.x * dq[0] + q.y * dq[1] + q.z * dq[2] + q.w * dq[3];
-                    dq[0] = (dq[0] - q.x * qd) * q_inv_norm; dq[1] = (dq[1] - q.y * qd) * q_inv_norm;
-                    dq[2] = (dq[2] - q.z * qd) * q_inv_norm; dq[3] = (dq[3] - q.w * qd) * q_inv_norm;
-                }
-            }
-            // dL/dT rows: dT0 = 2 dLa Sigma T0 + dLb Sigma T1 ; dT1 = 2 dLc Sigma T1 + dLb Sigma T0
-            const float u0 = S.c0 * T0[0] + S.c1 * T0[1] + S.c2 * T0[2];
-            const float u1 = S.c1 * T0[0] + S.c3 * T0[1] + S.c4 * T0[2];
-            const float u2 = S.c2 * T0[0] + S.c4 * T0[1] + S.c5 * T0[2];
-            const float w0 = S.c0 * T1[0] + S.c1 * T1[1] + S.c2 * T1[2];
-            const float w1 = S.c1 * T1[0] + S.c3 * T1[1] + S.c4 * T1[2];
-            const float w2 = S.c2 * T1[0] + S.c4 * T1[1] + S.c5 * T1[2];
-            const float dT0[3] = {2.f * dLa * u0 + dLb * w0, 2.f * dLa * u1 + dLb * w1, 2.f * dLa * u2 + dLb * w2};
-            const float dT1[3] = {2.f * dLc * w0 + dLb * u0, 2.f * dLc * w1 + dLb * u1, 2.f * dLc * w2 + dLb * u2};
-            // T = J Wr, Wr[i][k] = V[4k+i]:  dJ[r][i] = sum_k dT[r][k] * V[4k+i]
-            float dJ00 = 0.f, dJ02 = 0.f, dJ11 = 0.f, dJ12 = 0.f;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                dJ00 += dT0[k] * V[4 * k + 0]; dJ02 += dT0[k] * V[4 * k + 2];
-                dJ11 += dT1[k] * V[4 * k + 1]; dJ12 += dT1[k] * V[4 * k + 2];
-            }
-            const float tz = 1.f / pj.tz, tz2 = tz * tz, tz3 = tz2 * tz;
-            const float dtx = pj.clampx ? 0.f : -vc.focal_x * tz2 * dJ02;
-            const float dty = pj.clampy ? 0.f : -vc.focal_y * tz2 * dJ12;
-            const float dtz = -vc.focal_x * tz2 * dJ00 - vc.focal_y * tz2 * dJ11
-                            + (2.f * vc.focal_x * pj.tx) * tz3 * dJ02 + (2.f * vc.focal_y * pj.ty) * tz3 * dJ12;
-            // t_i = sum_k m_k V[4k+i]
-#pragma unroll
-            for (int k = 0; k < 3; ++k) dm[k] += V[4 * k] * dtx + V[4 * k + 1] * dty + V[4 * k + 2] * dtz;
-        } else if (idx < N && use_sh) {
-            if (stage) { for (int e = 0; e < rowlen; ++e) myrow[e] = 0.f; }
-            else if (!accumulate) { float* o = dL_dshs + (size_t)idx * rowlen; for (int e = 0; e < rowlen; ++e) o[e] = 0.f; }
+            for (int e = 0; e < 6; ++e) out.dcov[e] = out.dcov[e] + cur.dcov[e];
         }
+        if (sh_in_regs && use_sh && idx < N) { float* o = dL_dshs + (size_t)idx * rowlen; o[0] = tsh[0]; o[1] = tsh[1]; o[2] = tsh[2]; }
 
         if (idx < N) {
             if (accumulate) {   // old + new, the order autograd's AccumulateGrad adds a later view's gradient in
-                dm[0] = dL_dmeans3D[3 * idx] + dm[0]; dm[1] = dL_dmeans3D[3 * idx + 1] + dm[1]; dm[2] = dL_dmeans3D[3 * idx + 2] + dm[2];
-                dop = dL_dopac[idx] + dop;
-                if (dL_dcolors) { dcol[0] = dL_dcolors[3 * idx] + dcol[0]; dcol[1] = dL_dcolors[3 * idx + 1] + dcol[1]; dcol[2] = dL_dcolors[3 * idx + 2] + dcol[2]; }
+                out.dm[0] = dL_dmeans3D[3 * idx] + out.dm[0]; out.dm[1] = dL_dmeans3D[3 * idx + 1] + out.dm[1]; out.dm[2] = dL_dmeans3D[3 * idx + 2] + out.dm[2];
+                out.dop = dL_dopac[idx] + out.dop;
+                if (dL_dcolors) { out.dcol[0] = dL_dcolors[3 * idx] + out.dcol[0]; out.dcol[1] = dL_dcolors[3 * idx + 1] + out.dcol[1]; out.dcol[2] = dL_dcolors[3 * idx + 2] + out.dcol[2]; }
                 if (dL_dcov3D) {
 #pragma unroll
-                    for (int e = 0; e < 6; ++e) dcov[e] = dL_dcov3D[6 * (size_t)idx + e] + dcov[e];
+                    for (int e = 0; e < 6; ++e) out.dcov[e] = dL_dcov3D[6 * (size_t)idx + e] + out.dcov[e];
                 }
-                if (dL_dscales) { dsc[0] = dL_dscales[3 * idx] + dsc[0]; dsc[1] = dL_dscales[3 * idx + 1] + dsc[1]; dsc[2] = dL_dscales[3 * idx + 2] + dsc[2]; }
-                if (dL_drots) { const float4 o = reinterpret_cast<const float4*>(dL_drots)[idx]; dq[0] = o.x + dq[0]; dq[1] = o.y + dq[1]; dq[2] = o.z + dq[2]; dq[3] = o.w + dq[3]; }
+                if (dL_dscales) { out.dsc[0] = dL_dscales[3 * idx] + out.dsc[0]; out.dsc[1] = dL_dscales[3 * idx + 1] + out.dsc[1]; out.dsc[2] = dL_dscales[3 * idx + 2] + out.dsc[2]; }
+                if (dL_drots) { const float4 o = reinterpret_cast<const float4*>(dL_drots)[idx]; out.dq[0] = o.x + out.dq[0]; out.dq[1] = o.y + out.dq[1]; out.dq[2] = o.z + out.dq[2]; out.dq[3] = o.w + out.dq[3]; }
             }
-            dL_dmeans3D[3 * idx] = dm[0]; dL_dmeans3D[3 * idx + 1] = dm[1]; dL_dmeans3D[3 * idx + 2] = dm[2];
-            dL_dmeans2D[3 * idx] = dm2[0]; dL_dmeans2D[3 * idx + 1] = dm2[1]; dL_dmeans2D[3 * idx + 2] = 0.f;
-            dL_dopac[idx] = dop;
-            if (dL_dcolors) { dL_dcolors[3 * idx] = dcol[0]; dL_dcolors[3 * idx + 1] = dcol[1]; dL_dcolors[3 * idx + 2] = dcol[2]; }
+            dL_dmeans3D[3 * idx] = out.dm[0]; dL_dmeans3D[3 * idx + 1] = out.dm[1]; dL_dmeans3D[3 * idx + 2] = out.dm[2];
+            dL_dopac[idx] = out.dop;
+            if (dL_dcolors) { dL_dcolors[3 * idx] = out.dcol[0]; dL_dcolors[3 * idx + 1] = out.dcol[1]; dL_dcolors[3 * idx + 2] = out.dcol[2]; }
             if (dL_dcov3D) {
 #pragma unroll
-                for (int e = 0; e < 6; ++e) dL_dcov3D[6 * (size_t)idx + e] = dcov[e];
+                for (int e = 0; e < 6; ++e) dL_dcov3D[6 * (size_t)idx + e] = out.dcov[e];
             }
-            if (dL_dscales) { dL_dscales[3 * idx] = dsc[0]; dL_dscales[3 * idx + 1] = dsc[1]; dL_dscales[3 * idx + 2] = dsc[2]; }
-            if (dL_drots) reinterpret_cast<float4*>(dL_drots)[idx] = make_float4(dq[0], dq[1], dq[2], dq[3]);
+            if (dL_dscales) { dL_dscales[3 * idx] = out.dsc[0]; dL_dscales[3 * idx + 1] = out.dsc[1]; dL_dscales[3 * idx + 2] = out.dsc[2]; }
+            if (dL_drots) reinterpret_cast<float4*>(dL_drots)[idx] = make_float4(out.dq[0], out.dq[1], out.dq[2], out.dq[3]);
         }
         if (stage) {
             __syncthreads();
@@ -755,8 +805,8 @@ gsr_preprocess_bwd(ViewConst vc, int N, int K,
     }
 }
 
-template __global__ void gsr_preprocess_bwd<false>(ViewConst, int, int, const float*, const float*, const float*, float*, const float*, const float*, const float*, const float*, const float*, const int32_t*, const uint8_t*, const float*, float*, float*, float*, float*, float*, float*, float*, float*, int);
-template __global__ void gsr_preprocess_bwd<true>(ViewConst, int, int, const float*, const float*, const float*, float*, const float*, const float*, const float*, const float*, const float*, const int32_t*, const uint8_t*, const float*, float*, float*, float*, float*, float*, float*, float*, float*, int);
+template __global__ void gsr_preprocess_bwd<false>(ViewTab, int, int, int, int, const float*, const float*, const float*, float*, const float*, const float*, const float*, const float*, const float*, const int32_t*, const uint8_t*, const float*, float*, float*, float*, float*, float*, float*, float*, float*, int);
+template __global__ void gsr_preprocess_bwd<true>(ViewTab, int, int, int, int, const float*, const float*, const float*, float*, const float*, const float*, const float*, const float*, const float*, const int32_t*, const uint8_t*, const float*, float*, float*, float*, float*, float*, float*, float*, float*, int);
 
 // visible[i] = view-space z > 0.2  (frustum rule of A.3)
 extern "C" __global__ void __launch_bounds__(256)
