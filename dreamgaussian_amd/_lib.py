@@ -16,7 +16,7 @@ GSR_MAX_VIEWS = 16      # include/gsr.h
 GSR_ABI_VERSION = 3     # include/gsr.h
 
 EXPORTS = ("gsr_forward", "gsr_backward", "gsr_forward_views", "gsr_backward_views", "gsr_mark_visible", "gsr_dist2", "gsr_extract_fields", "gsr_densify_stats",
-           "gsr_adam_step", "gsr_mask_compact", "gsr_gather_rows",
+           "gsr_adam_step", "gsr_mask_compact", "gsr_gather_rows", "gsr_concat_rows",
            "gsr_profile_enable", "gsr_profile_read", "gsr_profile_reset",
            "gsr_geom_bytes", "gsr_img_bytes", "gsr_last_error", "gsr_version", "gsr_abi_version")
 
@@ -46,6 +46,10 @@ class GsrAdamTensor(C.Structure):
 
 class GsrGatherTensor(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("width", C.c_int32), ("reserved", C.c_int32)]
+
+
+class GsrConcatTensor(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("dst", C.c_void_p), ("width", C.c_int32), ("reserved", C.c_int32)]
 
 
 class GsrStats(C.Structure):
@@ -103,6 +107,8 @@ def load() -> C.CDLL:
         lib.gsr_mask_compact.argtypes = [i32, p, p, p, GsrAlloc, vp]
         lib.gsr_gather_rows.restype = C.c_int
         lib.gsr_gather_rows.argtypes = [i32, C.POINTER(GsrGatherTensor), i32, p, vp]
+        lib.gsr_concat_rows.restype = C.c_int
+        lib.gsr_concat_rows.argtypes = [i32, C.POINTER(GsrConcatTensor), i32, i32, vp]
         lib.gsr_geom_bytes.restype = C.c_size_t
         lib.gsr_geom_bytes.argtypes = [i32, i32, i32]
         lib.gsr_img_bytes.restype = C.c_size_t
@@ -120,20 +126,42 @@ def load() -> C.CDLL:
         return lib
 
 
-class Scratch:
-    """GsrAlloc backed by the torch caching allocator; keeps the tensor it handed out."""
+_tls = threading.local()
 
-    def __init__(self, device):
+
+class Scratch:
+    """GsrAlloc backed by the torch caching allocator; keeps the tensor it handed out.
+
+    The ctypes callback object is the expensive part (a few microseconds to create, and it closes a reference cycle through
+    the bound method): instances are pooled per thread -- `Scratch(dev)` takes one, `release()` hands back the tensor and
+    returns the instance to the pool."""
+
+    __slots__ = ("device", "tensor", "_cb", "alloc")
+
+    def __new__(cls, device):
+        pool = getattr(_tls, "pool", None)
+        if pool:
+            self = pool.pop()
+        else:
+            self = object.__new__(cls)
+            self._cb = RESIZE_FN(self._resize)
+            self.alloc = GsrAlloc(None, self._cb)
         self.device = device
         self.tensor = None
-        self._cb = RESIZE_FN(self._resize)
-        self.alloc = GsrAlloc(None, self._cb)
+        return self
+
+    def __init__(self, device):
+        pass
 
     def release(self):
-        """Drop the ctypes callback (it closes a reference cycle through the bound method, which
-        would keep the scratch tensor alive until the cyclic GC runs); keeps `tensor`."""
-        self._cb = None
-        self.alloc = None
+        """The tensor the library asked for (or None); the instance goes back to the pool and must not be used again."""
+        t, self.tensor = self.tensor, None
+        pool = getattr(_tls, "pool", None)
+        if pool is None:
+            pool = _tls.pool = []
+        if len(pool) < 16:
+            pool.append(self)
+        return t
 
     def _resize(self, _ctx, nbytes):
         try:

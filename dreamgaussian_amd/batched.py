@@ -64,7 +64,7 @@ class _RasterizeViews(torch.autograd.Function):
             rc = lib.gsr_forward_views(views, B, N, K, P(m3), P(shc), P(col), P(op), P(sc), P(rot), P(cov),
                                        P(color), P(depth), P(alpha), P(radii), geom.alloc, binb.alloc, img.alloc,
                                        C.byref(st), stream)
-        geom.release(); binb.release(); img.release()
+        geom_t, bin_t, img_t = geom.release(), binb.release(), img.release()
         _lib.check(rc, "gsr_forward_views")
         ctx.views, ctx.keeps, ctx.stats = views, keeps, st
         ctx.dims = (B, N, K, H, W)
@@ -72,7 +72,7 @@ class _RasterizeViews(torch.autograd.Function):
         empty = torch.empty(0, device=dev)
         # the camera constants travel as raw pointers: saved too, so that an in-place edit between forward and backward raises
         ctx.save_for_backward(*[t if t is not None else empty for t in (m3, shc, col, op, sc, rot, cov)], radii,
-                              geom.tensor, binb.tensor, img.tensor, *[t for keep in keeps for t in keep])
+                              geom_t, bin_t, img_t, *[t for keep in keeps for t in keep])
         ctx.shapes = (means3D.shape, None if sh is None else sh.shape,
                       None if colors_precomp is None else colors_precomp.shape, opacities.shape,
                       None if scales is None else scales.shape, None if rotations is None else rotations.shape,

@@ -898,6 +898,29 @@ extern "C" int gsr_gather_rows(int32_t count, const GsrGatherTensor* tensors, in
     return 0;
 }
 
+extern "C" int gsr_concat_rows(int32_t count, const GsrConcatTensor* tensors, int32_t rows_a, int32_t rows_b, gsr_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (count < 0 || count > GSR_GATHER_MAX_TENSORS) return fail(-1, "gsr_concat_rows takes 0..24 tensors per call%s", "");
+    if (rows_a < 0 || rows_b < 0) return fail(-1, "rows must be >= 0%s", "");
+    if (count == 0 || rows_a + rows_b == 0) return 0;
+    if (!tensors) return fail(-1, "tensors are required%s", "");
+    ConcatArgs a;
+    memset(&a, 0, sizeof(a));
+    int wmax = 1;
+    for (int i = 0; i < count; ++i) {
+        if (!tensors[i].dst || tensors[i].width < 1) return fail(-1, "dst and width >= 1 are required%s", "");
+        a.seg[i].a = tensors[i].a; a.seg[i].b = tensors[i].b; a.seg[i].dst = tensors[i].dst; a.seg[i].width = tensors[i].width;
+        if (tensors[i].width > wmax) wmax = tensors[i].width;
+    }
+    a.count = count; a.rows_a = rows_a; a.rows_b = rows_b;
+    const long long total = ((long long)rows_a + rows_b) * wmax;
+    const int gx = (int)fmin((double)((total + 255) / 256), 4096.0);
+    GsrView dbg; memset(&dbg, 0, sizeof(dbg));
+    prof_begin(stream); hipLaunchKernelGGL(gsr_concat_rows_kernel, dim3(gx, count), dim3(256), 0, stream, a);
+    LAUNCH_CHECK(&dbg, stream, "concat_rows");
+    return 0;
+}
+
 extern "C" int gsr_dist2(int32_t P, const float* points, float* out, GsrAlloc tmp, gsr_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (P < 0) return fail(-1, "P must be >= 0%s", "");

@@ -121,3 +121,17 @@ gsr_gather_rows_kernel(GatherArgs a, const uint32_t* __restrict__ idx) {
         s.dst[e] = s.src[(size_t)idx[r] * s.width + c];
     }
 }
+
+// ---- dst_t = [a_t ; b_t] (rows_a rows of a, then rows_b rows of b; a NULL source stands for zeros) for up to 24 tensors
+// of different row widths, one launch: cat_tensors_to_optimizer / densification_postfix (gs_renderer.py:513-552) -- the six
+// parameters extended by the new Gaussians, their twelve Adam moments extended by zeros, the three accumulators reset.
+struct ConcatSeg { const float* a; const float* b; float* dst; int width; };
+struct ConcatArgs { ConcatSeg seg[GSR_GATHER_MAX_TENSORS]; int count; int rows_a; int rows_b; };
+
+extern "C" __global__ void __launch_bounds__(256)
+gsr_concat_rows_kernel(ConcatArgs a) {
+    const ConcatSeg s = a.seg[blockIdx.y];
+    const long long na = (long long)a.rows_a * s.width, total = na + (long long)a.rows_b * s.width;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256)
+        s.dst[e] = e < na ? (s.a ? s.a[e] : 0.f) : (s.b ? s.b[e - na] : 0.f);
+}

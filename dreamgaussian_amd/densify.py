@@ -1,7 +1,9 @@
 """Per-step densification bookkeeping on the MI355X: the consumer of the rasterizer's `means2D`
 gradient holder and `radii` (main.py:276-281, `GaussianModel.add_densification_stats`
 gs_renderer.py:625-627) as ONE launch with no host synchronisation -- in torch each of the three
-boolean-mask updates is a `nonzero()` (device->host sync) plus gathers and scatters."""
+boolean-mask updates is a `nonzero()` (device->host sync) plus gathers and scatters -- and the structural half of the
+densification (gs_renderer.py:479-609): prune, clone, split and the optimiser-state surgery behind them as one mask
+compaction + one gather / concatenation launch instead of one boolean-mask indexing or `torch.cat` per tensor."""
 from __future__ import annotations
 
 import ctypes as C
@@ -132,3 +134,108 @@ def prune_points(gaussians, mask: torch.Tensor) -> None:
     gaussians._xyz, gaussians._features_dc, gaussians._features_rest = new_params["xyz"], new_params["f_dc"], new_params["f_rest"]
     gaussians._opacity, gaussians._scaling, gaussians._rotation = new_params["opacity"], new_params["scaling"], new_params["rotation"]
     gaussians.xyz_gradient_accum, gaussians.denom, gaussians.max_radii2D = outs[len(slots)], outs[len(slots) + 1], outs[len(slots) + 2]
+
+
+def _optimizer_slots(gaussians):
+    """(tensor, kind, group, state) of the six parameters and their Adam moments, in the optimiser's group order."""
+    out = []
+    for g in gaussians.optimizer.param_groups:
+        p = g["params"][0]
+        st = gaussians.optimizer.state.get(p, None)
+        out.append((p.data, "param", g, st))
+        if st is not None:
+            out.append((st["exp_avg"], "exp_avg", g, st))
+            out.append((st["exp_avg_sq"], "exp_avg_sq", g, st))
+    return out
+
+
+def _rebind(gaussians, slots, outs):
+    new_params = {}
+    for (_, kind, g, st), t in zip(slots, outs):
+        if kind == "param":
+            old = g["params"][0]
+            newp = torch.nn.Parameter(t.requires_grad_(True))
+            if st is not None:
+                del gaussians.optimizer.state[old]
+                gaussians.optimizer.state[newp] = st
+            g["params"][0] = newp
+            new_params[g["name"]] = newp
+        else:
+            st[kind] = t
+    gaussians._xyz, gaussians._features_dc, gaussians._features_rest = new_params["xyz"], new_params["f_dc"], new_params["f_rest"]
+    gaussians._opacity, gaussians._scaling, gaussians._rotation = new_params["opacity"], new_params["scaling"], new_params["rotation"]
+
+
+@torch.no_grad()
+def densification_postfix(gaussians, new_xyz, new_features_dc, new_features_rest, new_opacities, new_scaling, new_rotation) -> None:
+    """`GaussianModel.densification_postfix` with `cat_tensors_to_optimizer` (gs_renderer.py:513-552) on a reference
+    GaussianModel instance: the six parameters extended by the new rows, their Adam moments by zeros, the three
+    accumulators reset to zeros of the new length -- ONE launch (`gsr_concat_rows`) instead of 18 `torch.cat` + 12 `zeros_like`."""
+    new = {"xyz": new_xyz, "f_dc": new_features_dc, "f_rest": new_features_rest, "opacity": new_opacities,
+           "scaling": new_scaling, "rotation": new_rotation}
+    slots = _optimizer_slots(gaussians)
+    dev = gaussians._xyz.device
+    n_old, n_new = int(gaussians._xyz.shape[0]), int(new_xyz.shape[0])
+    outs, keep, arr = [], [], []
+    for t, kind, g, _ in slots:
+        ext = new[g["name"]].detach().to(torch.float32).contiguous() if kind == "param" else None
+        if kind == "param" and tuple(ext.shape[1:]) != tuple(t.shape[1:]):
+            raise RuntimeError(f"new rows of '{g['name']}' have shape {tuple(ext.shape)}, the model's {tuple(t.shape)}")
+        o = torch.empty((n_old + n_new,) + tuple(t.shape[1:]), dtype=torch.float32, device=dev)
+        outs.append(o)
+        width = 1
+        for d in t.shape[1:]:
+            width *= int(d)
+        if o.numel() > 0:
+            src = t.detach().contiguous()
+            keep += [src, ext]
+            arr.append(_lib.GsrConcatTensor(src.data_ptr(), None if ext is None else ext.data_ptr(), o.data_ptr(), width, 0))
+    acc = [torch.empty((n_old + n_new, 1), dtype=torch.float32, device=dev), torch.empty((n_old + n_new, 1), dtype=torch.float32, device=dev),
+           torch.empty((n_old + n_new,), dtype=torch.float32, device=dev)]
+    for o in acc:
+        arr.append(_lib.GsrConcatTensor(None, None, o.data_ptr(), 1, 0))
+    if n_old + n_new > 0:
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            for i0 in range(0, len(arr), 24):
+                chunk = (_lib.GsrConcatTensor * len(arr[i0:i0 + 24]))(*arr[i0:i0 + 24])
+                _lib.check(lib.gsr_concat_rows(len(chunk), chunk, n_old, n_new, stream), "gsr_concat_rows")
+    _rebind(gaussians, slots, outs)
+    gaussians.xyz_gradient_accum, gaussians.denom, gaussians.max_radii2D = acc
+
+
+@torch.no_grad()
+def densify_and_clone(gaussians, grads: torch.Tensor, grad_threshold: float, scene_extent: float) -> None:
+    """`GaussianModel.densify_and_clone` (gs_renderer.py:582-595): the selection as the reference writes it, then ONE mask
+    compaction, one gather of the six parameters' selected rows and the one-launch postfix."""
+    sel = torch.logical_and(torch.norm(grads, dim=-1) >= grad_threshold,
+                            torch.max(gaussians.get_scaling, dim=1).values <= gaussians.percent_dense * scene_extent)
+    idx, count = compact_mask(sel)
+    rows = gather_rows(idx, [gaussians._xyz, gaussians._features_dc, gaussians._features_rest, gaussians._opacity,
+                             gaussians._scaling, gaussians._rotation])
+    densification_postfix(gaussians, *rows)
+
+
+@torch.no_grad()
+def densify_and_split(gaussians, grads: torch.Tensor, grad_threshold: float, scene_extent: float, N: int = 2, build_rotation=None) -> None:
+    """`GaussianModel.densify_and_split` (gs_renderer.py:554-580): selection and the random offsets as the reference computes
+    them (same torch calls, same RNG stream), the rows through one compaction + one gather, then the one-launch postfix and
+    the one-gather prune of the split originals. `build_rotation` = gs_renderer.build_rotation (quaternion -> matrix)."""
+    n_init = int(gaussians.get_xyz.shape[0])
+    dev = gaussians._xyz.device
+    padded = torch.zeros(n_init, device=dev)
+    padded[:grads.shape[0]] = grads.squeeze()
+    sel = torch.logical_and(padded >= grad_threshold,
+                            torch.max(gaussians.get_scaling, dim=1).values > gaussians.percent_dense * scene_extent)
+    idx, count = compact_mask(sel)
+    xyz, f_dc, f_rest, opac, scaling_raw, rot = gather_rows(idx, [gaussians._xyz, gaussians._features_dc, gaussians._features_rest,
+                                                                    gaussians._opacity, gaussians._scaling, gaussians._rotation])
+    scaling = gaussians.scaling_activation(scaling_raw)
+    stds = scaling.repeat(N, 1)
+    samples = torch.normal(mean=torch.zeros((stds.size(0), 3), device=dev), std=stds)
+    rots = build_rotation(rot).repeat(N, 1, 1)
+    new_xyz = torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + xyz.repeat(N, 1)
+    new_scaling = gaussians.scaling_inverse_activation(scaling.repeat(N, 1) / (0.8 * N))
+    densification_postfix(gaussians, new_xyz, f_dc.repeat(N, 1, 1), f_rest.repeat(N, 1, 1), opac.repeat(N, 1), new_scaling, rot.repeat(N, 1))
+    prune_points(gaussians, torch.cat((sel, torch.zeros(N * count, device=dev, dtype=torch.bool))))

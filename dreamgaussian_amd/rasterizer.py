@@ -129,8 +129,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                                  _lib.ptr(op), _lib.ptr(sc), _lib.ptr(rot), _lib.ptr(cov),
                                  _lib.ptr(color), _lib.ptr(depth), _lib.ptr(alpha), _lib.ptr(radii),
                                  geom.alloc, binb.alloc, img.alloc, C.byref(stats), stream)
-        for sc_ in (geom, binb, img):
-            sc_.release()
+        geom_t, bin_t, img_t = geom.release(), binb.release(), img.release()
         _lib.check(rc, "gsr_forward")
         _last_stats.update(M=stats.num_instances, M_ref=stats.num_instances_ref,
                            V=stats.num_visible, max_tile=stats.max_tile_count, N=N, H=H, W=W, K=K,
@@ -146,7 +145,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.save_for_backward(m3 if m3 is not None else empty, shc if shc is not None else empty,
                               col if col is not None else empty, op if op is not None else empty, sc if sc is not None else empty,
                               rot if rot is not None else empty, cov if cov is not None else empty,
-                              radii, geom.tensor, binb.tensor, img.tensor,
+                              radii, geom_t, bin_t, img_t,
                               *keep)       # the camera constants travel as raw pointers: saved, so that an in-place edit before the backward raises
         ctx.shapes = (means3D.shape, means2D.shape, None if sh is None else sh.shape,
                       None if colors_precomp is None else colors_precomp.shape, opacities.shape,

@@ -22,6 +22,8 @@
  * and, either side of the path:
  *   gsr_extract_fields <- GaussianModel.extract_fields, gs_renderer.py:218-294 (+ gaussian_3d_coeff :64-83)
  *   gsr_densify_stats  <- main.py:279-281 + GaussianModel.add_densification_stats, gs_renderer.py:625-627
+ *   gsr_mask_compact / gsr_gather_rows / gsr_concat_rows <- prune_points, densify_and_clone / _split, cat_tensors_to_optimizer,
+ *                        densification_postfix, gs_renderer.py:479-595
  *   GsrView.raw_activations <- the activations Renderer.render applies before the call,
  *                        gs_renderer.py:134-142, 762-766
  */
@@ -228,6 +230,13 @@ int gsr_mask_compact(int32_t N, const uint8_t* mask, uint32_t* idx, uint64_t* co
 typedef struct GsrGatherTensor { const float* src; float* dst; int32_t width; int32_t reserved; } GsrGatherTensor;
 int gsr_gather_rows(int32_t count, const GsrGatherTensor* tensors /* [host] */, int32_t rows, const uint32_t* idx,
                     gsr_stream_t stream);
+
+/* densification_postfix / cat_tensors_to_optimizer (gs_renderer.py:513-552) in one launch: dst_t = [a_t ; b_t] -- rows_a rows
+ * of a_t followed by rows_b rows of b_t -- for up to 24 fp32 tensors of row width width_t. A NULL source stands for zeros: the
+ * six parameters are extended by the new Gaussians (b = the new rows), their Adam moments by zeros (b = NULL), the three
+ * densification accumulators are reset (a = b = NULL). dst must hold rows_a + rows_b rows and may not alias a source. */
+typedef struct GsrConcatTensor { const float* a; const float* b; float* dst; int32_t width; int32_t reserved; } GsrConcatTensor;
+int gsr_concat_rows(int32_t count, const GsrConcatTensor* tensors /* [host] */, int32_t rows_a, int32_t rows_b, gsr_stream_t stream);
 
 /* Bytes of scratch the forward will request for geom / img (bin is data dependent). */
 size_t gsr_geom_bytes(int32_t N, int32_t image_height, int32_t image_width);

@@ -108,3 +108,113 @@ def test_gather_rows_with_an_empty_feature_tensor(gpu):
     idx, count = D.compact_mask(torch.rand(100, generator=g).to(gpu) > 0.5)
     oa, ob = D.gather_rows(idx, [a, b])
     assert ob.shape == (count, 0, 3) and torch.equal(oa, a[idx.long()])
+
+
+class _Model:
+    """The attributes of the reference's GaussianModel that its densification code touches (gs_renderer.py:134-216)."""
+    percent_dense = 0.01
+    scaling_activation = staticmethod(torch.exp)
+    scaling_inverse_activation = staticmethod(torch.log)
+
+    @property
+    def get_xyz(self):
+        return self._xyz
+
+    @property
+    def get_scaling(self):
+        return torch.exp(self._scaling)
+
+
+def _build_rotation(r):                                        # gs_renderer.py:86-106, restated for the checker
+    q = r / torch.norm(r, dim=1, keepdim=True)
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                        2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                        2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], -1).reshape(-1, 3, 3)
+
+
+def _ref_postfix(m, new):                                      # cat_tensors_to_optimizer + densification_postfix, gs_renderer.py:513-552
+    for grp in m.optimizer.param_groups:
+        ext = new[grp["name"]]
+        p = grp["params"][0]
+        st = m.optimizer.state[p]
+        st["exp_avg"] = torch.cat((st["exp_avg"], torch.zeros_like(ext)), 0)
+        st["exp_avg_sq"] = torch.cat((st["exp_avg_sq"], torch.zeros_like(ext)), 0)
+        del m.optimizer.state[p]
+        grp["params"][0] = torch.nn.Parameter(torch.cat((p, ext), 0).requires_grad_(True))
+        m.optimizer.state[grp["params"][0]] = st
+    ps = {g["name"]: g["params"][0] for g in m.optimizer.param_groups}
+    m._xyz, m._features_dc, m._features_rest, m._opacity, m._scaling, m._rotation = (ps[k] for k in ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"))
+    n = m._xyz.shape[0]
+    m.xyz_gradient_accum, m.denom, m.max_radii2D = torch.zeros(n, 1, device=m._xyz.device), torch.zeros(n, 1, device=m._xyz.device), torch.zeros(n, device=m._xyz.device)
+
+
+def test_densify_clone_and_split_equal_reference_algorithm(gpu):
+    """dreamgaussian_amd.densify_and_clone / densify_and_split (one compaction + one gather + one concatenation launch) on an
+    object with GaussianModel's attributes against the reference's own sequence (boolean-mask indexing, 18 torch.cat, the same
+    torch.normal draw; gs_renderer.py:513-595): parameters, Adam moments and accumulators equal bit for bit."""
+    N = 3000
+    names = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+
+    def build():
+        params, opt = _make(N, gpu, D.FusedAdam, seed=11)
+        with torch.no_grad():
+            params[4].mul_(0.5).sub_(4.0)                       # log-scales around e^-4: both sides of percent_dense * extent
+        for p in params:
+            p.grad = torch.ones_like(p) * 0.1
+        opt.step()
+        m = _Model()
+        m.optimizer = opt
+        ga = torch.Generator().manual_seed(7)
+        m.xyz_gradient_accum, m.denom, m.max_radii2D = torch.rand(N, 1, generator=ga).to(gpu), torch.rand(N, 1, generator=ga).to(gpu), torch.rand(N, generator=ga).to(gpu)
+        for n, p in zip(names, params):
+            setattr(m, n, p)
+        return m
+    a, b = build(), build()
+    grads = torch.rand(N, 1, generator=torch.Generator().manual_seed(3)).to(gpu)
+    thr, extent = 0.4, 2.0
+    # ---- clone
+    D.densify_and_clone(a, grads, thr, extent)
+    sel = torch.logical_and(torch.norm(grads, dim=-1) >= thr, torch.max(b.get_scaling, dim=1).values <= b.percent_dense * extent)
+    _ref_postfix(b, {"xyz": b._xyz[sel], "f_dc": b._features_dc[sel], "f_rest": b._features_rest[sel], "opacity": b._opacity[sel],
+                     "scaling": b._scaling[sel], "rotation": b._rotation[sel]})
+    assert 0 < int(sel.sum()) < N
+
+    def same():
+        for ga_, gb_, n in zip(a.optimizer.param_groups, b.optimizer.param_groups, names):
+            pa, pb = ga_["params"][0], gb_["params"][0]
+            assert pa is getattr(a, n) and pa.requires_grad and pa.shape == pb.shape, n
+            assert torch.equal(pa.detach(), pb.detach()), n
+            assert torch.equal(a.optimizer.state[pa]["exp_avg"], b.optimizer.state[pb]["exp_avg"]), n
+            assert torch.equal(a.optimizer.state[pa]["exp_avg_sq"], b.optimizer.state[pb]["exp_avg_sq"]), n
+        assert torch.equal(a.xyz_gradient_accum, b.xyz_gradient_accum) and torch.equal(a.denom, b.denom) and torch.equal(a.max_radii2D, b.max_radii2D)
+    same()
+    # ---- split (the same random draw on both sides)
+    torch.manual_seed(5); torch.cuda.manual_seed(5)
+    D.densify_and_split(a, grads, thr, extent, N=2, build_rotation=_build_rotation)
+    torch.manual_seed(5); torch.cuda.manual_seed(5)
+    n_init = b.get_xyz.shape[0]
+    padded = torch.zeros(n_init, device=gpu); padded[:grads.shape[0]] = grads.squeeze()
+    sel = torch.logical_and(padded >= thr, torch.max(b.get_scaling, dim=1).values > b.percent_dense * extent)
+    stds = b.get_scaling[sel].repeat(2, 1)
+    samples = torch.normal(mean=torch.zeros((stds.size(0), 3), device=gpu), std=stds)
+    rots = _build_rotation(b._rotation[sel]).repeat(2, 1, 1)
+    new_xyz = torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + b.get_xyz[sel].repeat(2, 1)
+    with torch.no_grad():
+        _ref_postfix(b, {"xyz": new_xyz, "f_dc": b._features_dc[sel].repeat(2, 1, 1), "f_rest": b._features_rest[sel].repeat(2, 1, 1),
+                         "opacity": b._opacity[sel].repeat(2, 1), "scaling": torch.log(b.get_scaling[sel].repeat(2, 1) / (0.8 * 2)),
+                         "rotation": b._rotation[sel].repeat(2, 1)})
+    keep = ~torch.cat((sel, torch.zeros(2 * int(sel.sum()), device=gpu, dtype=torch.bool)))
+    for grp in b.optimizer.param_groups:                        # prune_points, gs_renderer.py:479-511
+        p = grp["params"][0]
+        st = b.optimizer.state[p]
+        st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"][keep], st["exp_avg_sq"][keep]
+        del b.optimizer.state[p]
+        grp["params"][0] = torch.nn.Parameter(p[keep].requires_grad_(True))
+        b.optimizer.state[grp["params"][0]] = st
+    b.xyz_gradient_accum, b.denom, b.max_radii2D = b.xyz_gradient_accum[keep], b.denom[keep], b.max_radii2D[keep]
+    assert 0 < int(sel.sum()) < n_init
+    same()
+    for p in (g["params"][0] for g in a.optimizer.param_groups):   # the optimiser keeps stepping on the new tensors
+        p.grad = torch.ones_like(p)
+    a.optimizer.step()
