@@ -141,8 +141,8 @@ def cpu_baseline(wl, kind, azimuth, budget_s=20.0, procs=None):
     t_comp = max(r[1] for r in res)
     pairs_s = float(sum(cnt[t] for t in sample)) * 256.0
     t_full = t_pg + t_comp * total_pairs / pairs_s
-    return dict(value=H * W / t_full / 1e6, unit="Mrays/s", cores=max(procs, nthreads), kind="port",
-                sample=(f"oracle fwd+bwd, same scene/camera/loss, on {ncpu} host cores: per-Gaussian stage + binning "
+    return dict(value=H * W / t_full / 1e6, unit="Mrays/s", cores=max(len(jobs), nthreads), kind="port",
+                sample=(f"oracle fwd+bwd, same scene/camera/loss; the box has {ncpu} host cores, `cores` = the most that were busy at once: per-Gaussian stage + binning "
                         f"in full on {nthreads} torch threads ({t_pg:.1f} s); compositing in {len(jobs)} single-threaded "
                         f"processes on {len(sample)} of {len(nonempty)} non-empty tiles ({100.0 * pairs_s / total_pairs:.1f}% "
                         f"of instance-pixel pairs, slowest worker {t_comp:.1f} s); frame time scaled by pair count "

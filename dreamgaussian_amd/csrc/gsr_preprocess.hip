@@ -5,9 +5,13 @@
 // (rotation/covariance), sh_utils.py:57-112 + gs_renderer.py:793 (SH -> RGB),
 // gs_renderer.py:629-671 (projection conventions). Spec: SURVEY.md Appendix A.3 / A.7.
 //
-// Both kernels are HBM-streaming: one lane per Gaussian, SH rows staged through LDS with
-// coalesced loads/stores (row pitch 3K+1 dwords: odd => conflict-free per-lane row walks),
-// per-tile instance counts privatised in an LDS histogram and flushed once per workgroup.
+// Both kernels stream the Gaussians from HBM. K1: three phases per wave of 64 Gaussians without a workgroup barrier --
+// lane = Gaussian (frustum test, view direction, SH basis -> LDS), lane = SH coefficient (16 lanes share a Gaussian: the SH
+// rows are read straight from HBM, 768 contiguous bytes per wave instruction, and reduced with a 16-lane DPP row sum),
+// lane = Gaussian again (projection, conic, radius, exact per-tile support test); per-tile instance counts privatised in an
+// LDS histogram and flushed once per workgroup. K6: lane = Gaussian, SH in / dSH out staged through LDS for K > 1 (row pitch
+// 3K+1 dwords: odd => conflict-free per-lane row walks); with nothing to stage (K == 1) one launch runs through all the
+// cameras of a batch in registers.
 #include "gsr_device.h"
 
 namespace {

@@ -106,8 +106,8 @@ def psnr_fixed_view(gui):
 def install_optin(gs_renderer):
     """The opt-in replacements either side of the rasterizer, patched onto the reference's
     GaussianModel from OUTSIDE (its files stay unmodified): FusedAdam for the Adam of `training_setup`
-    (gs_renderer.py:370), the fused densification statistics (gs_renderer.py:625-627) and the one-gather prune
-    (gs_renderer.py:479-511)."""
+    (gs_renderer.py:370), the fused densification statistics (gs_renderer.py:625-627), the one-gather prune
+    (gs_renderer.py:479-511) and the one-launch clone / split / postfix (gs_renderer.py:513-595)."""
     import dreamgaussian_amd as D
     GM = gs_renderer.GaussianModel
     orig_setup = GM.training_setup
@@ -123,9 +123,20 @@ def install_optin(gs_renderer):
 
     def prune_points(self, mask):
         D.prune_points(self, mask)
-    saved = (GM.training_setup, GM.add_densification_stats, GM.prune_points)
-    GM.training_setup, GM.add_densification_stats, GM.prune_points = training_setup, add_densification_stats, prune_points
-    return lambda: [setattr(GM, n, f) for n, f in zip(("training_setup", "add_densification_stats", "prune_points"), saved)]
+
+    def densification_postfix(self, *new_rows):
+        D.densification_postfix(self, *new_rows)
+
+    def densify_and_clone(self, grads, grad_threshold, scene_extent):
+        D.densify_and_clone(self, grads, grad_threshold, scene_extent)
+
+    def densify_and_split(self, grads, grad_threshold, scene_extent, N=2):
+        D.densify_and_split(self, grads, grad_threshold, scene_extent, N, build_rotation=gs_renderer.build_rotation)
+    names = ("training_setup", "add_densification_stats", "prune_points", "densification_postfix", "densify_and_clone", "densify_and_split")
+    saved = tuple(getattr(GM, n) for n in names)
+    for n, f in zip(names, (training_setup, add_densification_stats, prune_points, densification_postfix, densify_and_clone, densify_and_split)):
+        setattr(GM, n, f)
+    return lambda: [setattr(GM, n, f) for n, f in zip(names, saved)]
 
 
 def trained_gaussians(gui):
@@ -263,7 +274,8 @@ def main():
     if a.optin:
         out["optin_run"] = run(ref, a.iters, input_path, profiled=False, optin=True)
         out["optin_run"]["what"] = ("same trainer, same seed; GaussianModel.training_setup -> dreamgaussian_amd.FusedAdam, "
-                                    "add_densification_stats -> the fused kernel, prune_points -> compact_mask + gather_rows")
+                                    "add_densification_stats -> the fused kernel, prune_points / densify_and_clone / densify_and_split / "
+                                    "densification_postfix -> compact_mask + gather_rows + concat_rows")
     os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
     json.dump(out, open(a.out, "w"), indent=1)
     print(json.dumps(out, indent=1))
