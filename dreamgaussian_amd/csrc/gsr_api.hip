@@ -679,7 +679,8 @@ int backward_impl(const GsrView* views, int B, int32_t N, int32_t K,
     const int grid_n = (int)fmin((double)((N + 255) / 256), 2048.0);
     const size_t lds = (shs && K > 1) ? (size_t)256 * (3 * K + 1) * 4 : 0;
     if (lds > 160 * 1024) return fail(-1, "preprocess_bwd needs more than 160 KiB of LDS%s", "");
-    auto k6 = vc.raw_act ? gsr_preprocess_bwd<true> : gsr_preprocess_bwd<false>;
+    auto k6 = vc.raw_act ? gsr_preprocess_bwd<true, false> : gsr_preprocess_bwd<false, false>;
+    auto k6m = vc.raw_act ? gsr_preprocess_bwd<true, true> : gsr_preprocess_bwd<false, true>;
     if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // The parameter gradients are the SUM over the views in the order autograd accumulates B separate rasterizer calls (the node
     // created last runs first: last view first, then `earlier sum + this view`), so that the sums are bit-identical to the serial
@@ -687,19 +688,22 @@ int backward_impl(const GsrView* views, int B, int32_t N, int32_t K,
     // reads each Gaussian once and runs through the cameras in registers. Otherwise one launch per view, adding to the first.
     ViewTab tab;
     memset(&tab, 0, sizeof(tab));
-    for (int v = 0; v < B; ++v) tab.v[v] = make_view(views + v);
-    if (lds == 0 || B == 1) {
+    const uint8_t* flags8 = (const uint8_t*)(gbuf + GL.flags8);
+    if (lds == 0 && B > 1) {
+        for (int v = 0; v < B; ++v) tab.v[v] = make_view(views + v);
         prof_begin(stream);
-        hipLaunchKernelGGL(k6, dim3(grid_n), dim3(256), lds, stream, tab, 0, B, N, K, means3D, shs, view->shs_rest, view->dL_dshs_rest,
-                           colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, (const uint8_t*)(gbuf + GL.flags8), g2d,
+        hipLaunchKernelGGL(k6m, dim3(grid_n), dim3(256), lds, stream, tab, 0, B, N, K, means3D, shs, view->shs_rest, view->dL_dshs_rest,
+                           colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, flags8, g2d,
                            dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacities, dL_dscales, dL_drotations, dL_dcov3D, 0);
         LAUNCH_CHECK(view, stream, "preprocess_bwd");
     } else {
         for (int v = B - 1; v >= 0; --v) {
+            tab.v[0] = make_view(views + v);
             prof_begin(stream);
-            hipLaunchKernelGGL(k6, dim3(grid_n), dim3(256), lds, stream, tab, v, 1, N, K, means3D, shs, view->shs_rest, view->dL_dshs_rest,
-                               colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, (const uint8_t*)(gbuf + GL.flags8), g2d,
-                               dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacities, dL_dscales, dL_drotations, dL_dcov3D, v == B - 1 ? 0 : 1);
+            hipLaunchKernelGGL(k6, dim3(grid_n), dim3(256), lds, stream, tab, 0, 1, N, K, means3D, shs, view->shs_rest, view->dL_dshs_rest,
+                               colors_precomp, opacities, scales, rotations, cov3D_precomp, radii + (size_t)v * N, flags8 + (size_t)v * N,
+                               g2d + (size_t)v * g2d_view, dL_dmeans3D, dL_dmeans2D + (size_t)v * N * 3, dL_dshs, dL_dcolors, dL_dopacities,
+                               dL_dscales, dL_drotations, dL_dcov3D, v == B - 1 ? 0 : 1);
             LAUNCH_CHECK(view, stream, "preprocess_bwd");
         }
     }

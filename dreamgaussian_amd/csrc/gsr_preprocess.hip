@@ -503,6 +503,12 @@ gsr_preprocess_fwd(ViewTab views /* camera of this workgroup: views.v[blockIdx.y
 // ---------------------------------------------------------------------------------------
 // One (view, Gaussian) of K6: the gradients of this view's 2D quantities (g2d) carried to the Gaussian's parameters.
 // Outputs are THIS view's contributions (exact zeros for a Gaussian the view culled); the callers add views up.
+// a pointer every lane holds the same value of, moved to scalar registers (loads through it become scalar loads)
+__device__ __forceinline__ const void* uniform_ptr(const void* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)v), hi = __builtin_amdgcn_readfirstlane((unsigned int)(v >> 32));
+    return (const void*)(((unsigned long long)hi << 32) | lo);
+}
 struct K6Out { float dm[3], dm2[2], dop, dsc[3], dq[4], dcov[6], dcol[3], dsh[3]; };
 template <bool RAW>
 __device__ __forceinline__ void k6_gaussian(const ViewConst& vc, int idx, int N, int K, bool live,
@@ -710,9 +716,10 @@ __device__ __forceinline__ void k6_gaussian(const ViewConst& vc, int idx, int N,
 
 }
 
-template <bool RAW>   // RAW: inputs are the raw parameters (fused sigmoid / exp / normalise backward)
+template <bool RAW, bool MULTI>   // RAW: inputs are the raw parameters (fused sigmoid / exp / normalise backward); MULTI: B > 1
 __global__ void __launch_bounds__(256)
-gsr_preprocess_bwd(ViewTab tab, int first_view, int B /* views first_view .. first_view + B - 1 of the table in THIS launch */, int N, int K,
+gsr_preprocess_bwd(ViewTab tab, int first_view, int B /* B == 1: the view tab.v[0], per-view arrays already offset by the host;
+                                                           B > 1: views 0 .. B - 1 of the table, first_view = 0 */, int N, int K,
                    const float* __restrict__ means3D, const float* __restrict__ shs,
                    const float* __restrict__ shs_rest /* split layout (GsrView.shs_rest) or NULL */,
                    float* __restrict__ dL_dshs_rest,
@@ -736,12 +743,14 @@ gsr_preprocess_bwd(ViewTab tab, int first_view, int B /* views first_view .. fir
     // view first and `earlier sum + this view` after that -- the additions of B separate launches (= the order autograd
     // accumulates B separate calls) in the same order, so the sums are bit-identical to them, without B - 1 read-modify-write
     // passes over the gradients. The cameras go from the by-value table to LDS (they are indexed with a run-time view number).
-    __shared__ ViewConst sv[GSR_MAX_VIEWS];
-    if (threadIdx.x == 0) {
+    __shared__ ViewConst sv[MULTI ? GSR_MAX_VIEWS : 1];
+    if (MULTI) {
+        if (threadIdx.x == 0) {
 #pragma unroll
-        for (int v = 0; v < GSR_MAX_VIEWS; ++v) sv[v] = tab.v[v];
+            for (int v = 0; v < GSR_MAX_VIEWS; ++v) sv[MULTI ? v : 0] = tab.v[v];
+        }
+        __syncthreads();
     }
-    __syncthreads();
     for (int base = blockIdx.x * blockDim.x; base < N; base += gridDim.x * blockDim.x) {
         const int cnt = min((int)blockDim.x, N - base);
         if (stage) {
@@ -761,9 +770,18 @@ gsr_preprocess_bwd(ViewTab tab, int first_view, int B /* views first_view .. fir
 #pragma unroll
         for (int e = 0; e < 6; ++e) out.dcov[e] = 0.f;
         float* myrow = shbuf + threadIdx.x * (rowlen + 1);
-        const bool sh_in_regs = B > 1;                    // (then K == 1: three numbers per view)
-        for (int v = first_view + B - 1; v >= first_view; --v) {
-            const ViewConst vc = sv[v];
+        const bool sh_in_regs = MULTI;                    // (then K == 1: three numbers per view)
+        for (int v = MULTI ? first_view + B - 1 : 0; v >= (MULTI ? first_view : 0); --v) {
+            // one view per launch (the common case): the camera stays a kernel argument = scalar registers, its matrices are read
+            // with scalar loads; several: from LDS, made wave-uniform again lane 0's copy
+            ViewConst vc = tab.v[0];
+            if (MULTI) {
+                vc = sv[MULTI ? v : 0];
+                vc.view = reinterpret_cast<const float*>(uniform_ptr(vc.view)); vc.proj = reinterpret_cast<const float*>(uniform_ptr(vc.proj));
+                vc.campos = reinterpret_cast<const float*>(uniform_ptr(vc.campos));
+                vc.W = __builtin_amdgcn_readfirstlane(vc.W); vc.H = __builtin_amdgcn_readfirstlane(vc.H);
+                vc.sh_degree = __builtin_amdgcn_readfirstlane(vc.sh_degree);
+            }
             const bool live = (idx < N) && (radii[(size_t)v * N + idx] > 0);
             k6_gaussian<RAW>(vc, idx, N, K, live, means3D, shs, opacities, scales, rotations, cov3D_precomp, flags8 + (size_t)v * N,
                              g2d + (size_t)v * N * GSR_G2D_STRIDE, dL_dshs, stage, myrow, accumulate, sh_in_regs, cur);
@@ -809,8 +827,8 @@ gsr_preprocess_bwd(ViewTab tab, int first_view, int B /* views first_view .. fir
     }
 }
 
-template __global__ void gsr_preprocess_bwd<false>(ViewTab, int, int, int, int, const float*, const float*, const float*, float*, const float*, const float*, const float*, const float*, const float*, const int32_t*, const uint8_t*, const float*, float*, float*, float*, float*, float*, float*, float*, float*, int);
-template __global__ void gsr_preprocess_bwd<true>(ViewTab, int, int, int, int, const float*, const float*, const float*, float*, const float*, const float*, const float*, const float*, const float*, const int32_t*, const uint8_t*, const float*, float*, float*, float*, float*, float*, float*, float*, float*, int);
+template __global__ void gsr_preprocess_bwd<false, false>(ViewTab, int, int, int, int, const float*, const float*, const float*, float*, const float*, const float*, const float*, const float*, const float*, const int32_t*, const uint8_t*, const float*, float*, float*, float*, float*, float*, float*, float*, float*, int);
+template __global__ void gsr_preprocess_bwd<true, false>(ViewTab, int, int, int, int, const float*, const float*, const float*, float*, const float*, const float*, const float*, const float*, const float*, const int32_t*, const uint8_t*, const float*, float*, float*, float*, float*, float*, float*, float*, float*, int);
 
 // visible[i] = view-space z > 0.2  (frustum rule of A.3)
 extern "C" __global__ void __launch_bounds__(256)

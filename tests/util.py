@@ -61,7 +61,7 @@ ROW_REL_FLOOR = 1e-3
 ROW_REL_P999 = 5e-3         # small scenes (a few thousand rows: the 99.9th percentile is the second-worst row); fp32-vs-fp64 of the
                             # ORACLE ITSELF reaches 1.2e-3 there (tests/test_oracle.py): fp32 rounding, not a kernel property
 ROW_REL_P999_FULL = 1e-3    # BASELINE configs[1]-[3] at full size (>= 20k rows): observed on the MI355X <= 5.2e-4
-ROW_REL_MEDIAN = 2e-5
+ROW_REL_MEDIAN = 5e-5       # observed on the MI355X: <= 1.8e-5 (BASELINE configs[3], means2D)
 REPORT = {}              # what the last assert_* calls observed (printed by the full-size tests)
 
 

@@ -44,7 +44,7 @@ pmc)
     (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_$tag -o r03 -- python $R/bench.py --steps 3 --warmup 1 --cpu-budget 0 --no-roofline > $R/gpurun_out/pmc_$tag.log 2>&1)
     tail -1 gpurun_out/pmc_$tag.log | cut -c1-200
   done
-  python tools/pmc_summary.py gpurun_out 2>&1 | tail -40;;
+  python tools/pmc_summary.py gpurun_out --json gpurun_out/pmc_traffic.json --key 1M-800-sh3/blob 2>&1 | tee gpurun_out/pmc_summary.txt | tail -40;;
 stage1)
   echo "== stage-1 (BASELINE configs[4]) through libgsr.so"
   timeout 1200 python tools/run_stage1.py --out gpurun_out/stage1.json $STAGE1_ARGS 2>&1 | tail -25;;
@@ -59,5 +59,12 @@ viewsprof)
   f=$(find gpurun_out/prof_views -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -16 "$f" | cut -c1-50,180-330;;
 sds)
   echo "== bench --gpus 2 on a 1-GPU box must fail loudly"; timeout 120 python bench.py --gpus 2 --steps 2 --warmup 1 2>&1 | tail -3
-  echo "== bench --step sds (1 GPU)"; timeout 300 python bench.py --step sds --cpu-budget 0 2>&1 | tail -2;;
+  echo "== bench --step sds (1 GPU, no collectives)"; timeout 300 python bench.py --step sds --cpu-budget 0 2>&1 | grep -a "^{" | tee gpurun_out/sds_plain.json | cut -c1-400
+  echo "== bench --step sds --force-collectives (1 GPU, 1-rank RCCL group)"; timeout 300 python bench.py --step sds --cpu-budget 0 --force-collectives 2>&1 | grep -a "^{" | tee gpurun_out/sds_rccl.json | cut -c1-400;;
+smoke)
+  echo "== __graft_entry__ smoke"; timeout 600 python __graft_entry__.py --smoke 2>&1 | tail -3;;
+cpubase)
+  for wl in 100k-800-sh3 5k-256-sh0; do
+    echo "== bench $wl with the CPU oracle"; timeout 900 python bench.py --workload $wl --cpu-budget ${CPU_BUDGET:-10} 2> gpurun_out/benchcpu_$wl.err | tee gpurun_out/benchcpu_$wl.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['cpu_baseline'])"
+  done;;
 esac; done

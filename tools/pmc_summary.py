@@ -21,7 +21,7 @@ from collections import defaultdict
 def short(name):
     n = name.split("(")[0]
     n = n.replace("void ", "")
-    for fam in ("gsr_tile_sort", "gsr_render_fwd_combine", "gsr_render_fwd_seg", "gsr_render_bwd"):
+    for fam in ("gsr_tile_sort", "gsr_render_fwd_combine", "gsr_render_fwd_seg", "gsr_render_fwd_serial", "gsr_render_fwd_fix", "gsr_render_bwd"):
         if fam in n and "v0" not in n:
             return fam
     return n.strip()
