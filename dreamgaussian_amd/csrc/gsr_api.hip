@@ -667,7 +667,11 @@ int backward_impl(const GsrView* views, int B, int32_t N, int32_t K,
         const uint32_t* plan_tile = (const uint32_t*)((const char*)bin + BL.plan_tile);
         const uint32_t* plan_off = (const uint32_t*)(gbuf + GL.plan_off);
         const unsigned long long* plan_total = counters + 4;
-        const unsigned grid = (unsigned)BL.plan_cap;
+        // one workgroup per (tile, segment) of the work list: at most M / 2^shift + tiles of them (M = the exact instance count when
+        // the caller handed the forward's statistics back; the list's capacity otherwise)
+        size_t gmax = BL.plan_cap;
+        if (fwd_stats && fwd_stats->num_instances > 0) gmax = ((size_t)fwd_stats->num_instances >> shift) + (size_t)TA + 1;
+        const unsigned grid = (unsigned)(gmax < BL.plan_cap ? gmax : BL.plan_cap);
         // workgroup table: [2^shift][10] 64-bit fixed-point sums
         const size_t dyn = ((size_t)GSR_Q2_ROW * 8) << shift;
         hipLaunchKernelGGL(gsr_render_bwd_q2, dim3(grid), dim3(256), dyn, stream, tile_off, recs, sorted_ids, W, H, vc.gx,

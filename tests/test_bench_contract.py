@@ -55,8 +55,8 @@ def test_committed_traffic_file_uses_the_calibrated_read_factors():
     if doc["source_digest"] != build.kernel_digest():
         import pytest
         pytest.skip("profiles/pmc_traffic.json was collected with other kernel sources: bench.py reports traffic null until "
-                    "the PMC passes are re-collected (tools/gpu_r2.sh pmc)")
+                    "the PMC passes are re-collected (tools/gpu_r3.sh pmc)")
     rb = doc["1M-800-sh3/blob"]["render_bwd"]
     assert rb["read_factor"] == 1.0 and abs(rb["hbm_bytes"] - (rb["read_bytes_raw"] + rb["write_bytes"])) < 1.0
-    k6 = doc["1M-800-sh3/blob"]["preprocess_bwd<false>"]
+    k6 = doc["1M-800-sh3/blob"]["preprocess_bwd<false, false>"]
     assert k6["read_factor"] == 2.0
