@@ -33,10 +33,10 @@ prof)
   echo "== rocprofv3 kernel trace (1M)"
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_1M -o r03 -- python $R/bench.py --steps 20 --warmup 5 --cpu-budget 0 --no-roofline > $R/gpurun_out/prof_1M.log 2>&1)
   tail -2 gpurun_out/prof_1M.log
-  f=$(find gpurun_out/prof_1M -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -16 "$f" | cut -c1-60,200-320;;
+  f=$(find gpurun_out/prof_1M -name "r03*kernel_stats.csv" | head -1); [ -n "$f" ] && head -16 "$f" | cut -c1-60,200-320;;
 prof5k)
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_5k -o r03 -- python $R/bench.py --workload 5k-256-sh0 --steps 20 --warmup 5 --cpu-budget 0 --no-roofline > $R/gpurun_out/prof_5k.log 2>&1)
-  f=$(find gpurun_out/prof_5k -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -16 "$f" | cut -c1-60,200-320;;
+  f=$(find gpurun_out/prof_5k -name "r03*kernel_stats.csv" | head -1); [ -n "$f" ] && head -16 "$f" | cut -c1-60,200-320;;
 pmc)
   echo "== rocprofv3 PMC passes (1M)"
   for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE SQ_INSTS_VMEM SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS"; do
@@ -56,7 +56,7 @@ views)
 viewsprof)
   echo "== rocprofv3 kernel trace, 8 views in one chain (250k / 512^2)"
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_views -o r03v -- python $R/bench.py --workload 250k-512-sh0 --views 8 --steps 5 --warmup 2 --cpu-budget 0 --no-roofline > $R/gpurun_out/prof_views.log 2>&1)
-  f=$(find gpurun_out/prof_views -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -16 "$f" | cut -c1-50,180-330;;
+  f=$(find gpurun_out/prof_views -name "r03*kernel_stats.csv" | head -1); [ -n "$f" ] && head -16 "$f" | cut -c1-50,180-330;;
 sds)
   echo "== bench --gpus 2 on a 1-GPU box must fail loudly"; timeout 120 python bench.py --gpus 2 --steps 2 --warmup 1 2>&1 | tail -3
   echo "== bench --step sds (1 GPU, no collectives)"; timeout 300 python bench.py --step sds --cpu-budget 0 2>&1 | grep -a "^{" | tee gpurun_out/sds_plain.json | cut -c1-400
