@@ -52,6 +52,46 @@ def test_fuzz(gpu, seed):
         assert torch.isfinite(hg[k]).all(), k
 
 
+def fuzz_case_large(seed):
+    """Tens of thousands of Gaussians, frames on both sides of the 1 024-tile line where the forward changes its mode, lists of
+    several hundred to several thousand entries per tile (many depth segments, every sort class below the HBM fallback)."""
+    rs = np.random.RandomState(5000 + seed)
+    N = int(rs.randint(2000, 40000))
+    W, H = int(rs.randint(100, 620)), int(rs.randint(100, 560))
+    deg_max = int(rs.randint(0, 3))
+    deg = int(rs.randint(0, deg_max + 1))
+    kind = "trained" if rs.rand() < 0.6 else "blob"
+    sc = O.make_scene(N, deg_max, 100 + seed, kind)
+    g = torch.Generator().manual_seed(seed)
+    idx = torch.randperm(N, generator=g)
+    n_bad = N // 20
+    sc["means3D"][idx[:n_bad], 2] += 3.0 + 3.0 * torch.rand(n_bad, generator=g)
+    sc["scales"][idx[n_bad:2 * n_bad]] *= 3.0                                           # a few big splats: long lists
+    sc["opacities"][idx[2 * n_bad:3 * n_bad]] = 0.97
+    el, az, r = rs.uniform(-40, 40), rs.uniform(-180, 180), rs.uniform(1.6, 2.6)
+    S = O.make_settings(O.orbit_pose(el, az, r), W, H, fovy_deg=float(rs.uniform(35, 60)), sh_degree=deg, bg=tuple(rs.rand(3)))
+    return sc, S, W, H
+
+
+@pytest.mark.parametrize("seed,env", [(0, {}), (1, {}), (2, {}), (3, {}), (4, {"GSR_FWD_MODE": "seg", "GSR_SEG_SHIFT": "7"}),
+                                      (5, {"GSR_FWD_MODE": "seg", "GSR_SEG_SHIFT": "8"}), (6, {"GSR_FWD_MODE": "seq"}),
+                                      (7, {"GSR_FWD_MODE": "seq", "GSR_SEG_SHIFT": "7", "GSR_FWD": "block"})],
+                         ids=lambda v: "-".join(f"{k[4:]}={x}" for k, x in v.items()) or "auto" if isinstance(v, dict) else str(v))
+def test_fuzz_large(gpu, monkeypatch, seed, env):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    sc, S, W, H = fuzz_case_large(seed)
+    w = weights_for(H, W, seed=seed)
+    ho, hg, st = run_hip(sc, S, gpu, w)
+    oo, og, aux = run_oracle(sc, S, w, torch.float64)
+    _, og32, _ = run_oracle(sc, S, w, torch.float32)          # near-opaque Gaussians in the scene: tests/util.py assert_grads_close(og32=)
+    assert st["V"] == aux["V"] and abs(st["M_ref"] - aux["M"]) <= 1e-4 * aux["M"] + 8
+    assert_forward_close(ho, oo, aux)
+    assert_grads_close(hg, og, aux, floors=grad_floors(sc, og), og32=og32)
+    for k in hg:
+        assert torch.isfinite(hg[k]).all(), k
+
+
 def test_large_frame_global_histogram_path(gpu):
     """More than 16384 tiles: the per-tile counters no longer fit the LDS histogram and K1 / K3
     fall back to global atomics (gsr_api.hip kHistLdsMaxTiles)."""
