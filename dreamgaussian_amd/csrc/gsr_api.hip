@@ -465,13 +465,13 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
             vs.view_mask = mask_q;
             hipLaunchKernelGGL(gsr_render_fwd_serial<true>, dim3(TA), dim3(256), 0, stream, tile_off, recs, sorted_ids, W, H, vc.gx,
                                out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, order, shift,
-                               plan_off, plan_tile, counters + 4, (uint32_t)BL.plan_cap, counters, (uint32_t)M, maxc_cap, vs);
+                               plan_off, plan_tile, counters + 4, (uint32_t)BL.plan_cap, (unsigned long long)mask_q, counters, (uint32_t)M, maxc_cap, vs);
         }
         if (mask_q != mask_all) {
             vs.view_mask = mask_all & ~mask_q;
             hipLaunchKernelGGL(gsr_render_fwd_serial<false>, dim3(TA), dim3(256), 0, stream, tile_off, recs, sorted_ids, W, H, vc.gx,
                                out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, order, shift,
-                               plan_off, plan_tile, counters + 4, (uint32_t)BL.plan_cap, counters, (uint32_t)M, maxc_cap, vs);
+                               plan_off, plan_tile, counters + 4, (uint32_t)BL.plan_cap, (unsigned long long)mask_q, counters, (uint32_t)M, maxc_cap, vs);
         }
         LAUNCH_CHECK(view, stream, "render_fwd");
         return 0;

@@ -4,6 +4,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef GSR_MAX_VIEWS
+#define GSR_MAX_VIEWS 16       // also in include/gsr.h
+#endif
 #define GSR_TILE 16          // binning granularity in pixels (numerics: SURVEY 7, hard part 2)
 #define GSR_LOG2E 1.4426950408889634f
 #define GSR_LN2 0.6931471805599453f
@@ -41,6 +44,12 @@ static_assert(sizeof(SplatRec) == 64, "SplatRec must be 64 bytes");
 #define GSR_CKPT_FLOATS (GSR_REC_PLANES * 256)
 #define GSR_REC_LAST (6 * 256)
 #define GSR_REC_HINT (7 * 256)
+// Serial walk with quad lists (gsr_render_fwd_serial<true>): plane 7 holds the four per-quad hit masks of every round of the
+// segment instead -- u64 [round in segment (<= 4)][block (4)][quad (4)], bit = lane = list entry of the round -- and word
+// GSR_CNT_QMASK of the counters names the views that have them: the backward re-uses them instead of repeating the
+// exact ellipse-vs-quad tests (129 vector instructions per wave and round).
+#define GSR_CNT_PLAN 4
+#define GSR_CNT_QMASK (8 + 2 * GSR_MAX_VIEWS + 1)
 #define GSR_REC_SKIPPED (-1.0f)     // plane 0 of a segment gsr_render_fwd_seg did not composite (every pixel had stopped, by its hints)
 // Depth-major work list of the segment forward: level c = the c-th segment of every tile that has one; levels
 // 0 .. GSR_NLEV-2 hold one segment per item, an item of the last level walks the rest of its tile's list.
@@ -77,9 +86,6 @@ struct ViewConst {           // by-value kernel argument (scalar registers)
 // Several cameras in one launch chain (gsr_forward_views / gsr_backward_views): the per-Gaussian kernels take the
 // cameras as a by-value table and pick theirs with blockIdx.y; the per-tile kernels run over views * tiles_per_view
 // tiles and find the view of a tile by division. One view = the same kernels with a table of one.
-#ifndef GSR_MAX_VIEWS
-#define GSR_MAX_VIEWS 16       // also in include/gsr.h
-#endif
 struct ViewTab { ViewConst v[GSR_MAX_VIEWS]; };
 struct ViewSplit {
     int tiles_per_view;                  // gx * gy

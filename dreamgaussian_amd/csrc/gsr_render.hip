@@ -307,13 +307,14 @@ gsr_render_fwd_serial(const uint32_t* __restrict__ tile_off, const SplatRec* __r
                       float* __restrict__ rec_base, const uint32_t* __restrict__ tile_seg,
                       const uint32_t* __restrict__ order, int seg_shift,
                       uint32_t* __restrict__ plan_off, uint32_t* __restrict__ plan_tile,
-                      unsigned long long* __restrict__ plan_total, uint32_t plan_cap,
+                      unsigned long long* __restrict__ plan_total, uint32_t plan_cap, unsigned long long qmask_views,
                       const unsigned long long* __restrict__ counters, uint32_t capacity, uint32_t maxc_cap, ViewSplit vs) {
     if (counters[2] > (unsigned long long)capacity || counters[3] > (unsigned long long)maxc_cap) return;
     __shared__ float4 stage[4][3][GSR_RB + 2];
     __shared__ __attribute__((aligned(8))) uint8_t qlist[QUAD ? 4 : 1][4][80];
     __shared__ uint32_t wl[4];
     __shared__ uint32_t plan_base;
+    if (blockIdx.x == 0 && threadIdx.x == 0) plan_total[GSR_CNT_QMASK - GSR_CNT_PLAN] = qmask_views;   // the views whose records carry quad masks
     const int tg = (int)order[blockIdx.x];                // heaviest tiles first
     const int view = tg / vs.tiles_per_view;
     if (!((vs.view_mask >> view) & 1u)) return;           // (workgroup-uniform) this view composites with the other instantiation
@@ -337,7 +338,8 @@ gsr_render_fwd_serial(const uint32_t* __restrict__ tile_off, const SplatRec* __r
     const float bx0 = (float)bx, by0 = (float)by;
     const uint32_t start = tile_off[tg];
     const uint32_t n = (bx < W && by < H) ? tile_off[tg + 1] - start : 0u;   // a block outside the image walks nothing
-    float* __restrict__ rec0 = rec_base + (size_t)tile_seg[tg] * GSR_CKPT_FLOATS + (wave * 64 + ly * 8 + lx);
+    float* __restrict__ recw = rec_base + (size_t)tile_seg[tg] * GSR_CKPT_FLOATS;     // (wave-uniform) the tile's first segment record
+    float* __restrict__ rec0 = recw + (wave * 64 + ly * 8 + lx);
     float4* __restrict__ sa = stage[wave][0];
     float4* __restrict__ sb = stage[wave][1];
     float4* __restrict__ sc = stage[wave][2];
@@ -411,6 +413,11 @@ gsr_render_fwd_serial(const uint32_t* __restrict__ tile_off, const SplatRec* __r
                 h3 = ((alive & 0xffff000000000000ull) != 0ull) && qp[3] >= thr;
             }
             const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
+            if (lane == 0) {   // the round's four hit masks: the backward's quad tests (GSR_CNT_QMASK)
+                unsigned long long* mp = reinterpret_cast<unsigned long long*>(recw + (size_t)(rel >> seg_shift) * GSR_CKPT_FLOATS + GSR_REC_HINT)
+                                         + (((rel >> 6) & ((1u << (seg_shift - 6)) - 1u)) * 16u + (uint32_t)wave * 4u);
+                mp[0] = m0; mp[1] = m1; mp[2] = m2; mp[3] = m3;
+            }
             if ((m0 | m1 | m2 | m3) != 0ull) {
                 uint8_t (*qlw)[80] = qlist[QUAD ? wave : 0];
                 if (h0 | h1 | h2 | h3) { sa[lane] = ra; sb[lane] = rb; sc[lane] = rc; }
@@ -480,10 +487,10 @@ gsr_render_fwd_serial(const uint32_t* __restrict__ tile_off, const SplatRec* __r
 }
 template __global__ void gsr_render_fwd_serial<false>(const uint32_t*, const SplatRec*, const uint32_t*, int, int, int, float*, float*, float*, float*,
                                                       uint32_t*, float*, float*, const uint32_t*, const uint32_t*, int, uint32_t*, uint32_t*,
-                                                      unsigned long long*, uint32_t, const unsigned long long*, uint32_t, uint32_t, ViewSplit);
+                                                      unsigned long long*, uint32_t, unsigned long long, const unsigned long long*, uint32_t, uint32_t, ViewSplit);
 template __global__ void gsr_render_fwd_serial<true>(const uint32_t*, const SplatRec*, const uint32_t*, int, int, int, float*, float*, float*, float*,
                                                      uint32_t*, float*, float*, const uint32_t*, const uint32_t*, int, uint32_t*, uint32_t*,
-                                                     unsigned long long*, uint32_t, const unsigned long long*, uint32_t, uint32_t, ViewSplit);
+                                                     unsigned long long*, uint32_t, unsigned long long, const unsigned long long*, uint32_t, uint32_t, ViewSplit);
 
 // The exact walk of list positions [lo, hi) of a tile for the lanes with done == false (lane = pixel, row-major 8x8 block at
 // (bx0, by0)), `gate` = their transmittance in front of the segment. Updates T, C0, C1, C2, D, A, last, done: the segment's own
@@ -554,6 +561,7 @@ gsr_render_fwd_combine(const uint32_t* __restrict__ tile_off, const SplatRec* __
     __shared__ uint32_t plan_base;
     __shared__ uint16_t wseg[4][GSR_WALK_SLOTS];          // segments this wave hands to K5c
     __shared__ uint32_t wcnt[4], walk_base;
+    if (blockIdx.x == 0 && threadIdx.x == 0) plan_total[GSR_CNT_QMASK - GSR_CNT_PLAN] = 0ull;   // plane 7 holds hints here, no quad masks
     const int tg = (int)order[blockIdx.x];                // heaviest tiles first
     const int view = tg / vs.tiles_per_view;
     const int tile = tg - view * vs.tiles_per_view;
@@ -886,6 +894,7 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
     }
     const uint32_t seg_lo = seg << seg_shift;
     if (seg_lo >= n) return;                              // (block-uniform)
+    const bool have_masks = ((plan_total[GSR_CNT_QMASK - GSR_CNT_PLAN] >> view) & 1ull) != 0ull;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int row = lane >> 4, l15 = lane & 15;
@@ -917,6 +926,19 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
 
     float T_final = 1.f, gC0 = 0.f, gC1 = 0.f, gC2 = 0.f, gD = 0.f, gA = 0.f, Cg_total = 0.f;
     uint32_t last_contrib = 0;
+    // the segment's checkpoint: requested here, with the other per-pixel loads, not behind the two barriers below (a workgroup is a
+    // latency chain and only four of them fit a CU: every dependent load taken out of the chain is kernel time)
+    float ck0 = 1.f, ck1 = 0.f, ck2 = 0.f, ck3 = 0.f, ck4 = 0.f, ck5 = 0.f;
+    if (seg > 0) {
+        const float* c = ckpt + (size_t)(tile_seg[tg] + seg - 1u) * GSR_CKPT_FLOATS + cidx;
+        ck0 = c[0]; ck1 = c[256]; ck2 = c[512]; ck3 = c[768]; ck4 = c[1024]; ck5 = c[1280];
+    }
+    unsigned long long km0 = 0ull, km1 = 0ull, km2 = 0ull, km3 = 0ull;     // ... and the first round's quad masks
+    if (have_masks) {
+        const unsigned long long* __restrict__ mp = reinterpret_cast<const unsigned long long*>(ckpt + ((size_t)tile_seg[tg] + seg) * GSR_CKPT_FLOATS + GSR_REC_HINT)
+                                                    + (uint32_t)wave * 4u;
+        km0 = mp[0]; km1 = mp[1]; km2 = mp[2]; km3 = mp[3];
+    }
     if (inside) {
         const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
         T_final = final_T[pix];
@@ -949,12 +971,9 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
     const uint32_t seg_hi = active ? min(seg_lo + (1u << seg_shift), wave_last) : seg_lo;
     const float Cg_behind0 = Cg_total + T_final * (bg[0] * gC0 + bg[1] * gC1 + bg[2] * gC2);
 
-    float T = 1.f, Cgf = 0.f;
-    if (seg > 0) {
-        const float* c = ckpt + (size_t)(tile_seg[tg] + seg - 1u) * GSR_CKPT_FLOATS + cidx;
-        T = c[0];
-        Cgf = c[256] * gC0 + c[512] * gC1 + c[768] * gC2 + c[1024] * gD + c[1280] * gA;
-    }
+    const float T_in = ck0;
+    float T = T_in, Cgf = 0.f;
+    if (seg > 0) Cgf = ck1 * gC0 + ck2 * gC1 + ck3 * gC2 + ck4 * gD + ck5 * gA;
     const float bx0 = (float)bx, by0 = (float)by;
     // pass 1 writes (m, w) of pixel l15 of entry k to mw1[k * KSTRIDE]; pass 2 lane (h2, k2) reads mw2[0..15]
     float* __restrict__ mw1 = &mw[wave][row][(l15 >> 3) * GSR_Q2_HSTRIDE + (l15 & 7) * 2];
@@ -997,7 +1016,18 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
             const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + ids[start + i + GSR_RB]);
             pa = p[0]; pb = p[1]; pc = p[2];
         }
-        if (i < seg_hi) {
+        if (have_masks) {   // the forward's serial walk left the round's four quad masks: the same tests, already made
+            const unsigned long long* __restrict__ mp = reinterpret_cast<const unsigned long long*>(ckpt + ((size_t)tile_seg[tg] + seg) * GSR_CKPT_FLOATS + GSR_REC_HINT)
+                                                        + (((pos0 >> 6) & ((1u << (seg_shift - 6)) - 1u)) * 16u + (uint32_t)wave * 4u);
+            unsigned long long k0 = km0, k1 = km1, k2 = km2, k3 = km3;       // first round: requested at the top of the kernel
+            if (pos0 != seg_lo) { k0 = mp[0]; k1 = mp[1]; k2 = mp[2]; k3 = mp[3]; }
+            if (i < seg_hi) {
+                h0 = (i < ql0) && ((k0 >> lane) & 1ull);
+                h1 = (i < ql1) && ((k1 >> lane) & 1ull);
+                h2q = (i < ql2) && ((k2 >> lane) & 1ull);
+                h3 = (i < ql3) && ((k3 >> lane) & 1ull);
+            }
+        } else if (i < seg_hi) {
             const float thr = min_visible_power(rb.y);
             // exact ellipse-vs-quad support tests; an entry behind a quad's deepest contributor is never blended there
             float qp[4];
