@@ -148,7 +148,7 @@ BinLayout bin_layout(size_t M, int nTiles, int shift) {
     L.ckpt = o; o += align_up((L.items + 1) * (size_t)GSR_CKPT_FLOATS * 4);
     // backward work list: sum over tiles of ceil(last_t / 2^shift) <= the same bound
     L.plan_cap = L.items + 1;
-    L.plan_tile = o; o += align_up(L.plan_cap * 4);
+    L.plan_tile = o; o += align_up(L.plan_cap * 16);      // 16-byte (tile, segment, list start, list length) items
     L.item_recs = o; o += align_up(L.items * 16);        // the forward's work items (written by gsr_scatter)
     L.walk_items = o; o += align_up(L.items * 4 * 8);    // (tile, block, segment) items of the fix-up kernel: <= one per block and segment
     L.total = o < 256 ? 256 : o;
@@ -457,7 +457,7 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
     }
     const uint32_t mask_all = B >= 32 ? ~0u : ((1u << B) - 1u);
     uint32_t* plan_off = (uint32_t*)(gbuf + GL.plan_off);
-    uint32_t* plan_tile = (uint32_t*)(bbuf + BL.plan_tile);
+    uint4* plan_tile = (uint4*)(bbuf + BL.plan_tile);
     if (sequential) {
         // ---- K5s: the serial walk, one workgroup per tile
         prof_begin(stream);
@@ -664,7 +664,7 @@ int backward_impl(const GsrView* views, int B, int32_t N, int32_t K,
         const BinLayout BL = bin_layout((size_t)M, TA, shift);
         const float* ckpt = (const float*)((const char*)bin + BL.ckpt);
         // the work list ((tile, segment) up to each tile's deepest blended position) was left by the forward's chaining kernel
-        const uint32_t* plan_tile = (const uint32_t*)((const char*)bin + BL.plan_tile);
+        const uint4* plan_tile = (const uint4*)((const char*)bin + BL.plan_tile);
         const uint32_t* plan_off = (const uint32_t*)(gbuf + GL.plan_off);
         const unsigned long long* plan_total = counters + 4;
         // one workgroup per (tile, segment) of the work list: at most M / 2^shift + tiles of them (M = the exact instance count when

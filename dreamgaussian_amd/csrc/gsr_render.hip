@@ -306,7 +306,7 @@ gsr_render_fwd_serial(const uint32_t* __restrict__ tile_off, const SplatRec* __r
                       uint32_t* __restrict__ n_contrib, float* __restrict__ totals /*[5][H*W]*/,
                       float* __restrict__ rec_base, const uint32_t* __restrict__ tile_seg,
                       const uint32_t* __restrict__ order, int seg_shift,
-                      uint32_t* __restrict__ plan_off, uint32_t* __restrict__ plan_tile,
+                      uint32_t* __restrict__ plan_off, uint4* __restrict__ plan_items,
                       unsigned long long* __restrict__ plan_total, uint32_t plan_cap, unsigned long long qmask_views,
                       const unsigned long long* __restrict__ counters, uint32_t capacity, uint32_t maxc_cap, ViewSplit vs) {
     if (counters[2] > (unsigned long long)capacity || counters[3] > (unsigned long long)maxc_cap) return;
@@ -337,7 +337,8 @@ gsr_render_fwd_serial(const uint32_t* __restrict__ tile_off, const SplatRec* __r
     const float pxf = (float)px, pyf = (float)py;
     const float bx0 = (float)bx, by0 = (float)by;
     const uint32_t start = tile_off[tg];
-    const uint32_t n = (bx < W && by < H) ? tile_off[tg + 1] - start : 0u;   // a block outside the image walks nothing
+    const uint32_t tile_n = tile_off[tg + 1] - start;
+    const uint32_t n = (bx < W && by < H) ? tile_n : 0u;   // a block outside the image walks nothing
     float* __restrict__ recw = rec_base + (size_t)tile_seg[tg] * GSR_CKPT_FLOATS;     // (wave-uniform) the tile's first segment record
     float* __restrict__ rec0 = recw + (wave * 64 + ly * 8 + lx);
     float4* __restrict__ sa = stage[wave][0];
@@ -482,14 +483,14 @@ gsr_render_fwd_serial(const uint32_t* __restrict__ tile_off, const SplatRec* __r
     {
         const uint32_t segs = wl[0], base = plan_base;
         for (uint32_t q = threadIdx.x; q < segs; q += 256)
-            if (base + q < plan_cap) plan_tile[base + q] = (uint32_t)tg;
+            if (base + q < plan_cap) plan_items[base + q] = make_uint4((uint32_t)tg, q, start, tile_n);   // {tile, segment, list start, list length}
     }
 }
 template __global__ void gsr_render_fwd_serial<false>(const uint32_t*, const SplatRec*, const uint32_t*, int, int, int, float*, float*, float*, float*,
-                                                      uint32_t*, float*, float*, const uint32_t*, const uint32_t*, int, uint32_t*, uint32_t*,
+                                                      uint32_t*, float*, float*, const uint32_t*, const uint32_t*, int, uint32_t*, uint4*,
                                                       unsigned long long*, uint32_t, unsigned long long, const unsigned long long*, uint32_t, uint32_t, ViewSplit);
 template __global__ void gsr_render_fwd_serial<true>(const uint32_t*, const SplatRec*, const uint32_t*, int, int, int, float*, float*, float*, float*,
-                                                     uint32_t*, float*, float*, const uint32_t*, const uint32_t*, int, uint32_t*, uint32_t*,
+                                                     uint32_t*, float*, float*, const uint32_t*, const uint32_t*, int, uint32_t*, uint4*,
                                                      unsigned long long*, uint32_t, unsigned long long, const unsigned long long*, uint32_t, uint32_t, ViewSplit);
 
 // The exact walk of list positions [lo, hi) of a tile for the lanes with done == false (lane = pixel, row-major 8x8 block at
@@ -551,7 +552,7 @@ gsr_render_fwd_combine(const uint32_t* __restrict__ tile_off, const SplatRec* __
                        uint32_t* __restrict__ n_contrib, float* __restrict__ totals /*[5][H*W]*/,
                        float* __restrict__ rec_base, const uint32_t* __restrict__ tile_seg,
                        const uint32_t* __restrict__ order, int seg_shift,
-                       uint32_t* __restrict__ plan_off, uint32_t* __restrict__ plan_tile,
+                       uint32_t* __restrict__ plan_off, uint4* __restrict__ plan_items,
                        unsigned long long* __restrict__ plan_total, uint32_t plan_cap,
                        uint2* __restrict__ walk_items, unsigned long long* __restrict__ walk_total,
                        const unsigned long long* __restrict__ counters, uint32_t capacity, uint32_t maxc_cap, ViewSplit vs) {
@@ -582,6 +583,7 @@ gsr_render_fwd_combine(const uint32_t* __restrict__ tile_off, const SplatRec* __
     const float bx0 = (float)bx, by0 = (float)by;
     const uint32_t start = tile_off[tg];
     const uint32_t n = tile_off[tg + 1] - start;
+    const uint32_t tile_n = n;
     const uint32_t nseg = (n + (1u << seg_shift) - 1u) >> seg_shift;
     float* __restrict__ rec0 = rec_base + (size_t)tile_seg[tg] * GSR_CKPT_FLOATS + (wave * 64 + lane);
     float4* __restrict__ sa = stage[wave][0];
@@ -690,7 +692,7 @@ gsr_render_fwd_combine(const uint32_t* __restrict__ tile_off, const SplatRec* __
     {
         const uint32_t segs = wl[0], base = plan_base;
         for (uint32_t q = threadIdx.x; q < segs; q += 256)
-            if (base + q < plan_cap) plan_tile[base + q] = (uint32_t)tg;
+            if (base + q < plan_cap) plan_items[base + q] = make_uint4((uint32_t)tg, q, start, tile_n);   // {tile, segment, list start, list length}
         uint32_t wb = walk_base;
         for (int w = 0; w < wave; ++w) wb += wcnt[w];
         if ((uint32_t)lane < nwalk) walk_items[wb + lane] = make_uint2((uint32_t)tg * 4u + (uint32_t)wave, (uint32_t)wseg[wave][lane]);
@@ -800,7 +802,7 @@ gsr_render_fwd_fix(const uint2* __restrict__ walk_items, const unsigned long lon
     const float* __restrict__ totals, const float* __restrict__ ckpt,                             \
     const uint32_t* __restrict__ tile_seg, const float* __restrict__ dL_dcolor,                   \
     const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha,                     \
-    float* __restrict__ g2d, int seg_shift, const uint32_t* __restrict__ plan_tile,               \
+    float* __restrict__ g2d, int seg_shift, const uint4* __restrict__ plan_items,                 \
     const uint32_t* __restrict__ plan_off, const unsigned long long* __restrict__ plan_total,     \
     ViewSplit vs
 
@@ -875,13 +877,14 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
     __shared__ float4 stage[4][3][GSR_RB];                                   // 12 KiB staged records, slot = fetching lane
     __shared__ __attribute__((aligned(8))) uint8_t qlist[4][4][GSR_QL_PITCH]; // 1.25 KiB [wave][quad][k] = staged slot of the quad's k-th entry
     __shared__ __attribute__((aligned(16))) float mw[4][4][GSR_Q2_BATCH * GSR_Q2_KSTRIDE];   // 20 KiB
-    __shared__ uint32_t gmax_bits;                                           // max over the tile of gsum (bits of a non-negative float)
+    __shared__ uint32_t gmax_w[4];                                           // per wave: max of gsum over its pixels (bits of a non-negative float)
     extern __shared__ __attribute__((aligned(16))) unsigned long long acc64[];   // [(1 << seg_shift) * GSR_Q2_ROW]
     if (blockIdx.x >= (uint32_t)plan_total[0]) return;
-    const int tg = (int)plan_tile[blockIdx.x];            // tile among all views' tiles
-    const uint32_t seg = blockIdx.x - plan_off[tg];
-    const uint32_t start = tile_off[tg];
-    const uint32_t n = tile_off[tg + 1] - start;
+    const uint4 item = plan_items[blockIdx.x];            // {tile among all views' tiles, segment, list start, list length}: ONE load, then list -> records
+    const int tg = (int)item.x;
+    const uint32_t seg = item.y;
+    const uint32_t start = item.z;
+    const uint32_t n = item.w;
     const int view = tg / vs.tiles_per_view;
     const int tile = tg - view * vs.tiles_per_view;
     const float* __restrict__ bg = vs.bg[view];
@@ -902,16 +905,20 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
     // (index, record) overlap the per-pixel set-up below; entries past this wave's own end are masked later
     const uint32_t seg_end = min(seg_lo + (1u << seg_shift), n);
     float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa, pc = pa;
+    uint32_t id_first = 0;
     if (seg_lo + lane < seg_end) {
-        const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + ids[start + seg_lo + lane]);
+        id_first = ids[start + seg_lo + lane];
+        const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + id_first);
         pa = p[0]; pb = p[1]; pc = p[2];
     }
+    // wave 0 keeps what the flush needs of its first-round records (index, x, y, qa, qb, qc, opacity): table row r of the flush
+    // is list entry seg_lo + r, i.e. exactly lane r's record here -- no second trip list -> record at the end of the chain
+    const float4 keep_a = pa;
+    const float keep_qc = pb.x, keep_op = pb.y;
     const int tx0 = (tile % gx) * GSR_TILE, ty0 = (tile / gx) * GSR_TILE;
     const int bx = tx0 + (wave & 1) * 8, by = ty0 + (wave >> 1) * 8;
     for (int q = threadIdx.x; q < (GSR_Q2_ROW << seg_shift); q += 256) acc64[q] = 0ull;
     for (int q = threadIdx.x; q < 4 * 4 * GSR_QL_PITCH / 4; q += 256) reinterpret_cast<uint32_t*>(&qlist[0][0][0])[q] = 0u;   // stale reads stay inside the stage
-    if (threadIdx.x == 0) gmax_bits = 0u;
-    __syncthreads();
     bool active = (bx < W) && (by < H);                   // wave-uniform; no early return: barriers below
     const int qx = bx + (row & 1) * 4, qy = by + (row >> 1) * 4;         // this row's quad
     const int lx = (row & 1) * 4 + (l15 & 3), ly = (row >> 1) * 4 + (l15 >> 2);
@@ -953,9 +960,10 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
     {
         const float gsum = fabsf(gC0) + fabsf(gC1) + fabsf(gC2) + fabsf(gD) + fabsf(gA);
         const uint32_t wm = wave_max_u32(__float_as_uint(gsum));          // non-negative floats order like their bits
-        if (lane == 0) atomicMax(&gmax_bits, wm);
+        if (lane == 0) gmax_w[wave] = wm;
     }
     __syncthreads();
+    const uint32_t gmax_bits = max(max(gmax_w[0], gmax_w[1]), max(gmax_w[2], gmax_w[3]));   // (one barrier covers the zeroing above and these)
     const bool poisoned = gmax_bits >= 0x7f800000u;       // an infinite or NaN incoming gradient somewhere in the tile
     const float gmax = poisoned ? 1.f : __uint_as_float(gmax_bits);
     if (!(gmax > 0.f)) return;                            // block-uniform: a zero incoming gradient adds nothing anywhere
@@ -1125,10 +1133,14 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
         for (int q = 0; q < GSR_Q2_ROW; ++q) { v[q] = a[q]; any = any || (v[q] != 0ull); }
         any = any || poisoned;                            // non-finite input: the fixed-point sums mean nothing -> NaN out, like float arithmetic
         if (any) {
-            gid = ids[start + seg_lo + threadIdx.x];
-            const SplatRec* __restrict__ g = recs + gid;
-            const float qa = g->qa, qb = g->qb, qc = g->qc, op = g->opac;
-            const int eR = row_radius_exp(g->x, g->y, tcx, tcy);
+            float gxr = keep_a.x, gyr = keep_a.y, qa = keep_a.z, qb = keep_a.w, qc = keep_qc, op = keep_op;
+            gid = id_first;
+            if (threadIdx.x >= GSR_RB) {                  // segments of more than 64 entries: rows beyond the first round
+                gid = ids[start + seg_lo + threadIdx.x];
+                const SplatRec* __restrict__ g = recs + gid;
+                gxr = g->x; gyr = g->y; qa = g->qa; qb = g->qb; qc = g->qc; op = g->opac;
+            }
+            const int eR = row_radius_exp(gxr, gyr, tcx, tcy);
             const float Sx = from_fixed(v[0], e0 - eR), Sy = from_fixed(v[1], e0 - eR);
             const float Sxx = from_fixed(v[2], e0 - 2 * eR), Sxy = from_fixed(v[3], e0 - 2 * eR), Syy = from_fixed(v[4], e0 - 2 * eR);
             const float S0 = from_fixed(v[5], e0);
@@ -1145,9 +1157,10 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
             }
         }
     }
-    __syncthreads();                                      // every row is in registers: the table may be overwritten
-    float* accf = reinterpret_cast<float*>(acc64);        // [len][12] floats (48 B per row <= 80 B per row before)
-    uint32_t* gids = reinterpret_cast<uint32_t*>(&mw[0][0][0]);   // pass 2 is over: reuse as [len] Gaussian indices
+    // pass 2 is over (barrier above): its buffer takes the converted rows [len][12] and the Gaussian indices [len] -- a region of
+    // its own, so no barrier between reading the table and writing them
+    float* accf = &mw[0][0][0] + 256;
+    uint32_t* gids = reinterpret_cast<uint32_t*>(&mw[0][0][0]);
     if (threadIdx.x < len) {
         gids[threadIdx.x] = any ? gid : 0xffffffffu;
 #pragma unroll
