@@ -175,6 +175,9 @@ def run_sds(a, dev, rank, world):
     wl = WORKLOADS["250k-512-sh0"]
     azimuth = 360.0 * rank / max(world, 1)
     sc, _, rs, _ = build_inputs(wl, a.kind, dev, azimuth)
+    if a.order == "morton":
+        perm = D.morton_order(sc["means3D"]).long()
+        sc = {k: v[perm].contiguous() for k, v in sc.items()}
     t = {k: v.to(dev).requires_grad_(True) for k, v in sc.items()}
     m2d = torch.zeros(wl["N"], 3, device=dev, requires_grad=True)
     rast = D.GaussianRasterizer(raster_settings=rs)
@@ -236,6 +239,9 @@ def main():
     ap.add_argument("--step", default="render", choices=["render", "sds"],
                     help="render = rasterizer fwd+bwd (+ RCCL gather of the images when N>1): the headline metric; "
                          "sds = the multi-view SDS exchange on BASELINE configs[3] (see the module docstring)")
+    ap.add_argument("--order", default="given", choices=["given", "morton"],
+                    help="given = the Gaussians in the order the scene generator made them (random in space: the reference's init and "
+                         "the headline metric); morton = rows permuted along a Z-order curve first (dreamgaussian_amd.reorder_gaussians)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--force-collectives", action="store_true",
                     help="with --gpus 1: initialise a ONE-rank nccl group and run every collective of the step through RCCL "
@@ -469,7 +475,7 @@ def main():
             "config": {"workload": f"BASELINE.json configs[{wl['cfg']}]: {wl['N']} Gaussians, SH degree "
                                    f"{wl['deg']}, {wl['W']}x{wl['H']}, fwd+bwd, scene '{a.kind}' seed 0, "
                                    f"orbit camera r=2 fovy=49.1",
-                       "views_per_step": world * a.views, "activations": a.activations, "views_mode": ("single" if a.views == 1 else ("serial loop" if a.views_serial else "rasterize_views/chain")), "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU",
+                       "views_per_step": world * a.views, "order": a.order, "activations": a.activations, "views_mode": ("single" if a.views == 1 else ("serial loop" if a.views_serial else "rasterize_views/chain")), "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU",
                        "N": wl["N"], "K": K, "V": st.get("V"), "M": st.get("M_ref"), "M_emitted": st.get("M"),
                        "max_tile_list": st.get("max_tile"), "seg_shift": st.get("seg_shift")},
             "roofline": roof, "path_roofline": path_roof, "cpu_baseline": cpu,

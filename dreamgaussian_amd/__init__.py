@@ -7,7 +7,7 @@ Beside the drop-in names: rasterize_views (several cameras in flight), rasterize
 (fused activations), rasterize_gaussians_split (fused activations + features_dc / features_rest read in place),
 extract_fields (GaussianModel.extract_fields, gs_renderer.py:218-294), FusedAdam (torch.optim.Adam with a
 one-launch step), add_densification_stats / compact_mask / gather_rows / prune_points / densification_postfix /
-densify_and_clone / densify_and_split (densification without per-tensor nonzero() synchronisations, boolean-mask
+densify_and_clone / densify_and_split / morton_order / reorder_gaussians (densification without per-tensor nonzero() synchronisations, boolean-mask
 indexings and `torch.cat`s).
 """
 from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer,
@@ -16,9 +16,9 @@ from .knn import distCUDA2
 from .batched import rasterize_views
 from .fields import extract_fields
 from .densify import (add_densification_stats, compact_mask, gather_rows, prune_points, densification_postfix,
-                      densify_and_clone, densify_and_split)
+                      densify_and_clone, densify_and_split, morton_order, reorder_gaussians)
 from .optim import FusedAdam
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_gaussians_raw", "rasterize_gaussians_split",
            "last_stats", "distCUDA2", "rasterize_views", "extract_fields", "add_densification_stats", "compact_mask", "gather_rows", "prune_points",
-           "densification_postfix", "densify_and_clone", "densify_and_split", "FusedAdam"]
+           "densification_postfix", "densify_and_clone", "densify_and_split", "morton_order", "reorder_gaussians", "FusedAdam"]

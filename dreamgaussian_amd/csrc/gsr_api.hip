@@ -121,7 +121,7 @@ GeomLayout geom_layout(int N, int H, int W, int B = 1) {
     L.recs = o; o += align_up(BN * sizeof(SplatRec));
     L.emit = o; o += align_up(BN * sizeof(EmitRec));
     L.flags8 = o; o += align_up(BN);
-    L.block_stats = o; o += align_up((size_t)B * 2048 * 3 * 8);       // K1 grid <= 2048 workgroups per view
+    L.block_stats = o; o += align_up((size_t)B * 2048 * 3 * 8 + 256);  // K1 grid <= 2048 workgroups per view; + 256 B nobody reads (K1's store sink)
     // tile_count | cursor | counters are contiguous: one memset in front of K1
     L.tile_count = o; o += align_up(BT * 4);
     L.cursor = o; o += align_up(BT * 4);
@@ -214,7 +214,11 @@ int check_inputs(int N, int K, const GsrView* v, const float* means3D, const flo
     return 0;
 }
 
-constexpr int kHistLdsMaxTiles = 16384;   // 64 KiB of LDS histogram
+// Largest tile grid whose per-tile counters a workgroup of K1 / the scatter keeps in LDS (64 KiB); GSR_HIST_MAX=<tiles> for A/B runs
+static int hist_lds_max_tiles() {
+    static const int v = [] { const char* e = getenv("GSR_HIST_MAX"); const int t = e ? atoi(e) : 16384; return t < 0 ? 0 : (t > 16384 ? 16384 : t); }();
+    return v;
+}
 
 // Environment switches kept for same-box A/B measurements (defaults = the shipped path), read at every call:
 //   GSR_FWD=q|block       segment forward with quad lists / 8x8 block lists (default: chosen per view from its statistics)
@@ -332,21 +336,29 @@ int begin_impl(const GsrView* views, int B, int32_t N, int32_t K,
     uint32_t* tile_count = (uint32_t*)(gbuf + GL.tile_count);
     unsigned long long* counters = (unsigned long long*)(gbuf + GL.counters);
 
-    const int hist_in_lds = T <= kHistLdsMaxTiles;
+    const int hist_in_lds = T <= hist_lds_max_tiles();
     prof_begin(stream);
     HIP_TRY(hipMemsetAsync(gbuf + GL.tile_count, 0, GL.tile_off - GL.tile_count, stream));
     prof_end(stream, "memset_fwd");
 
-    static const int k1_grid = [] {   // GSR_K1_GRID: workgroups of the per-Gaussian kernel (block_stats holds 2048 per view)
-        const char* e = getenv("GSR_K1_GRID");
-        const int g = e ? atoi(e) : 1280;            // 5 workgroups per CU (96 VGPRs, 31 KiB of LDS each): 0.102 -> 0.097 ms at 1M against 4 per CU
-        return g < 1 ? 1 : (g > 2048 ? 2048 : g);
-    }();
-    const int grid_pre = N > 0 ? (int)fmin((double)((N + 255) / 256), (double)k1_grid) : 0;
+    // K1 is a persistent grid (per-workgroup tile histogram + statistics): four workgroups per CU (115 VGPRs), every wave walks
+    // batches of 64 Gaussians. The grid is SHRUNK to ceil(batches / rounds) so that no workgroup walks one batch more than the
+    // others (at 1M Gaussians: 977 workgroups x 4 batches; 1280 workgroups gave 67 of them a fourth batch and every tile counter
+    // 1280 flush atomics instead of 977: 0.102 -> 0.096 ms by the grid alone). GSR_K1_GRID=<n> pins the grid (A/B runs).
+    static const int k1_grid_env = [] { const char* e = getenv("GSR_K1_GRID"); const int g = e ? atoi(e) : 0; return g < 0 ? 0 : (g > 2048 ? 2048 : g); }();
+    const int k1_batches = (N + 255) / 256;
+    int grid_pre = 0;
+    if (N > 0) {
+        if (k1_grid_env) grid_pre = k1_batches < k1_grid_env ? k1_batches : k1_grid_env;
+        else {
+            const int cap = 1024, rounds = (k1_batches + cap - 1) / cap;      // block_stats holds 2048 workgroups per view
+            grid_pre = (k1_batches + rounds - 1) / rounds;
+        }
+    }
     if (N > 0) {
         const size_t hist_bytes = hist_in_lds ? (((size_t)T * 4 + 15) & ~(size_t)15) : 0;
-        const bool coop = shs && view->sh_degree > 0;                       // basis table + colour table (gsr_preprocess.hip)
-        const size_t lds = hist_bytes + (coop ? (size_t)256 * GSR_K1_BPITCH * 4 + 256 * 16 : 0);
+        const bool coop = shs && view->sh_degree > 0;                       // each wave's SH staging rows (gsr_preprocess.hip)
+        const size_t lds = hist_bytes + (size_t)4 * GSR_K1_WSLICE * 4;      // + each wave's slice: SH staging rows, then its records on their way out
         if (lds > 160 * 1024) return fail(-1, "preprocess needs more than 160 KiB of LDS%s", "");
         auto k1 = vc.raw_act ? gsr_preprocess_fwd<true> : gsr_preprocess_fwd<false>;
         if (lds > 48 * 1024)
@@ -397,7 +409,7 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
     uint32_t* n_contrib = (uint32_t*)(ibuf + align_up((size_t)H * W * 4));
     float* totals = (float*)(ibuf + 2 * align_up((size_t)H * W * 4));
 
-    const int hist_in_lds = T <= kHistLdsMaxTiles;
+    const int hist_in_lds = T <= hist_lds_max_tiles();
     const unsigned long long M = cap;
     if (M >= 0xfffffff0ull) return fail(-5, "too many tile instances (%s%lld)", "", (long long)M);
     const uint32_t maxc_cap = maxc >= 0xffffffffull ? 0xffffffffu : (uint32_t)maxc;
@@ -420,7 +432,8 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
         const uint32_t* level_off = (const uint32_t*)(gbuf + GL.level_off);
         uint4* items = (uint4*)(bbuf + BL.item_recs);
         prof_begin(stream); hipLaunchKernelGGL(gsr_scatter, dim3(grid_sc, B), dim3(256), lds, stream, N, emit, tile_off, cursor, entries,
-                           vc.gx, T, hist_in_lds, (uint32_t)M, counters, level_off, order, tile_seg, shift, items, (uint32_t)BL.items);
+                           vc.gx, T, hist_in_lds, (uint32_t)M, counters, level_off, order, tile_seg, shift, items,
+                           sequential ? 0u : (uint32_t)BL.items /* the serial walk takes its tiles from `order`: no work items */);
         LAUNCH_CHECK(view, stream, "scatter");
         // per-tile sort, size classes by list length
         constexpr size_t lds_s = 2048 * 8 + (512 + 1 + 512 + 40) * 4;
@@ -680,7 +693,8 @@ int backward_impl(const GsrView* views, int B, int32_t N, int32_t K,
     }
     LAUNCH_CHECK(view, stream, "render_bwd");
 
-    const int grid_n = (int)fmin((double)((N + 255) / 256), 2048.0);
+    static const int k6_grid = [] { const char* e = getenv("GSR_K6_GRID"); const int g = e ? atoi(e) : 2048; return g < 1 ? 1 : g; }();   // A/B runs
+    const int grid_n = (int)fmin((double)((N + 255) / 256), (double)k6_grid);
     const size_t lds = (shs && K > 1) ? (size_t)256 * (3 * K + 1) * 4 : 0;
     if (lds > 160 * 1024) return fail(-1, "preprocess_bwd needs more than 160 KiB of LDS%s", "");
     auto k6 = vc.raw_act ? gsr_preprocess_bwd<true, false> : gsr_preprocess_bwd<false, false>;

@@ -163,6 +163,7 @@ gsr_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ ti
 // K3: scatter (depth bits, id) keys into the tile segments.
 // dynamic LDS: nTiles uint32 when hist_in_lds.
 // ---------------------------------------------------------------------------------------
+#define GSR_SC_R 8      // emission records a thread of gsr_scatter holds in registers per round
 extern "C" __global__ void __launch_bounds__(256)
 gsr_scatter(int N, const EmitRec* __restrict__ emit, const uint32_t* __restrict__ tile_off,
             uint32_t* __restrict__ cursor, unsigned long long* __restrict__ entries,
@@ -197,42 +198,69 @@ gsr_scatter(int N, const EmitRec* __restrict__ emit, const uint32_t* __restrict_
     emit += (size_t)blockIdx.y * (size_t)N;
     tile_off += (size_t)blockIdx.y * nTiles;
     cursor += (size_t)blockIdx.y * nTiles;
-    if (hist_in_lds) {
-        for (int t = threadIdx.x; t < nTiles; t += blockDim.x) hist[t] = 0;
-        __syncthreads();
+    if (!hist_in_lds) {       // grids beyond the LDS histogram: one pass, a global cursor per tile
         for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < N; idx += gridDim.x * blockDim.x) {
             const uint4 em = reinterpret_cast<const uint4*>(emit)[idx];
             const int x0 = em.x & 0xffff, x1 = em.x >> 16, y0 = em.y & 0xffff, y1 = em.y >> 16;
+            const unsigned long long key = ((unsigned long long)em.z << 32) | (uint32_t)idx;
+            const bool masked = (x1 - x0) * (y1 - y0) <= GSR_EMIT_MASK_TILES;
+            uint32_t bit = 1u;
+            for (int ty = y0; ty < y1; ++ty)
+                for (int tx = x0; tx < x1; ++tx, bit <<= 1) {
+                    if (masked && !(em.w & bit)) continue;
+                    const int t = ty * gx + tx;
+                    const uint32_t pos = tile_off[t] + atomicAdd(&cursor[t], 1u);
+                    if (pos < capacity) entries[pos] = key;
+                }
+        }
+        return;
+    }
+    // The workgroup counts its Gaussians' emissions per tile in LDS, reserves one range per tile it touches (one global atomic
+    // each), and hands the positions out from LDS. Both passes need the emission records: a thread keeps its GSR_SC_R records in
+    // REGISTERS -- all loads of a pass in flight at once and no second trip to memory (the kernel is a latency chain on two
+    // workgroups per CU: with the records re-read per pass and per iteration it spent 2 x 8 dependent load latencies).
+    const int stride = gridDim.x * 256;
+    for (int round0 = 0; round0 < N; round0 += GSR_SC_R * stride) {          // (block-uniform trip count: barriers inside)
+        const int base = round0 + blockIdx.x * 256 + threadIdx.x;
+        uint4 em[GSR_SC_R];
+#pragma unroll
+        for (int r = 0; r < GSR_SC_R; ++r) {
+            const int idx = base + r * stride;
+            em[r] = idx < N ? reinterpret_cast<const uint4*>(emit)[idx] : make_uint4(0u, 0u, 0u, 0u);     // all-zero = empty rectangle
+        }
+        for (int t = threadIdx.x; t < nTiles; t += 256) hist[t] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < GSR_SC_R; ++r) {
+            const int x0 = em[r].x & 0xffff, x1 = em[r].x >> 16, y0 = em[r].y & 0xffff, y1 = em[r].y >> 16;
             const bool masked = (x1 - x0) * (y1 - y0) <= GSR_EMIT_MASK_TILES;
             uint32_t bit = 1u;
             for (int ty = y0; ty < y1; ++ty)
                 for (int tx = x0; tx < x1; ++tx, bit <<= 1)
-                    if (!masked || (em.w & bit)) atomicAdd(&hist[ty * gx + tx], 1u);
+                    if (!masked || (em[r].w & bit)) atomicAdd(&hist[ty * gx + tx], 1u);
         }
         __syncthreads();
         const int t0 = (int)((blockIdx.x * 67u) % (unsigned)nTiles);   // staggered: see K1's flush
-        for (int i = threadIdx.x; i < nTiles; i += blockDim.x) {
+        for (int i = threadIdx.x; i < nTiles; i += 256) {
             int t = t0 + i; if (t >= nTiles) t -= nTiles;
             const uint32_t c = hist[t];
             hist[t] = c ? (tile_off[t] + atomicAdd(&cursor[t], c)) : 0u;
         }
         __syncthreads();
-    }
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < N; idx += gridDim.x * blockDim.x) {
-        const uint4 em = reinterpret_cast<const uint4*>(emit)[idx];
-        const int x0 = em.x & 0xffff, x1 = em.x >> 16, y0 = em.y & 0xffff, y1 = em.y >> 16;
-        const unsigned long long key = ((unsigned long long)em.z << 32) | (uint32_t)idx;
-        const bool masked = (x1 - x0) * (y1 - y0) <= GSR_EMIT_MASK_TILES;
-        uint32_t bit = 1u;
-        for (int ty = y0; ty < y1; ++ty)
-            for (int tx = x0; tx < x1; ++tx, bit <<= 1) {
-                if (masked && !(em.w & bit)) continue;
-                const int t = ty * gx + tx;
-                uint32_t pos;
-                if (hist_in_lds) pos = atomicAdd(&hist[t], 1u);
-                else pos = tile_off[t] + atomicAdd(&cursor[t], 1u);
-                if (pos < capacity) entries[pos] = key;
-            }
+#pragma unroll
+        for (int r = 0; r < GSR_SC_R; ++r) {
+            const int x0 = em[r].x & 0xffff, x1 = em[r].x >> 16, y0 = em[r].y & 0xffff, y1 = em[r].y >> 16;
+            const unsigned long long key = ((unsigned long long)em[r].z << 32) | (uint32_t)(base + r * stride);
+            const bool masked = (x1 - x0) * (y1 - y0) <= GSR_EMIT_MASK_TILES;
+            uint32_t bit = 1u;
+            for (int ty = y0; ty < y1; ++ty)
+                for (int tx = x0; tx < x1; ++tx, bit <<= 1) {
+                    if (masked && !(em[r].w & bit)) continue;
+                    const uint32_t pos = atomicAdd(&hist[ty * gx + tx], 1u);
+                    if (pos < capacity) entries[pos] = key;
+                }
+        }
+        __syncthreads();                                  // the histogram is zeroed again by the next round
     }
 }
 

@@ -6,8 +6,8 @@
 // gs_renderer.py:629-671 (projection conventions). Spec: SURVEY.md Appendix A.3 / A.7.
 //
 // Both kernels stream the Gaussians from HBM. K1: three phases per wave of 64 Gaussians without a workgroup barrier --
-// lane = Gaussian (frustum test, view direction, SH basis -> LDS), lane = SH coefficient (16 lanes share a Gaussian: the SH
-// rows are read straight from HBM, 768 contiguous bytes per wave instruction, and reduced with a 16-lane DPP row sum),
+// lane = Gaussian (frustum test, view direction, SH basis), lane = SH coefficient for the loads (16 lanes share a Gaussian: the SH
+// rows are read straight from HBM, 768 contiguous bytes per wave instruction, pass through the wave's LDS slice and are evaluated by the lane that owns the Gaussian),
 // lane = Gaussian again (projection, conic, radius, exact per-tile support test); per-tile instance counts privatised in an
 // LDS histogram and flushed once per workgroup. K6: lane = Gaussian, SH in / dSH out staged through LDS for K > 1 (row pitch
 // 3K+1 dwords: odd => conflict-free per-lane row walks); with nothing to stage (K == 1) one launch runs through all the
@@ -207,26 +207,34 @@ __device__ __forceinline__ void stage_rows_out(float* __restrict__ dst, const fl
 }  // namespace
 
 // ---------------------------------------------------------------------------------------
-// K1: preprocess forward.  grid-stride over batches of 256 Gaussians, three phases per batch:
-// (per WAVE: the 64 Gaussians of a wave only touch that wave's slice of the LDS tables, no workgroup barrier)
-//   A (lane = Gaussian)      frustum test, view direction, SH basis values -> LDS table
-//   B (lane = coefficient)   16 lanes share one Gaussian: lane k loads coefficient k's three channels with one
-//                            12-byte load (a row is 16 x 12 B contiguous: four rows per wave instruction, fully
-//                            coalesced), multiplies by the basis value and the 16-lane DPP row sums the colour.
-//                            The SH rows never sit in LDS (the round-1 kernel staged 48 floats per Gaussian:
-//                            60 KiB per workgroup, 2 waves per SIMD, 34% of the HBM roofline), and the two
-//                            tensors of DreamGaussian's `get_features` (features_dc / features_rest,
-//                            gs_renderer.py:209-212) can be read where they are: lane 0 reads the first, lanes
-//                            1.. the second -- no torch.cat copy.
-//   C (lane = Gaussian)      projection, 2D covariance, conic, radius, tile rectangle, exact tile emission, record.
-// dynamic LDS: [hist: nTiles u32 when hist_in_lds][basis: 256 x 17 floats][colour: 256 x float4 (w = in-frustum flag)]
+// K1: preprocess forward.  A persistent grid walks batches of 256 Gaussians; a wave's 64 Gaussians only touch that wave's
+// slice of LDS (no workgroup barrier inside the loop: the four waves drift apart and cover each other's latency).
+//   A (lane = Gaussian)      frustum test, view direction, the SH basis values in registers
+//   B                        the wave's SH rows pass through its LDS slice 16 at a time: LOAD with 16 lanes per row, lane =
+//                            coefficient, one 12-byte load each (a row is 16 x 12 B contiguous: four rows per wave instruction,
+//                            fully coalesced; the two tensors of DreamGaussian's `get_features`, features_dc / features_rest,
+//                            gs_renderer.py:209-212, are read where they are: lane 0 the first, lanes 1.. the second -- no
+//                            torch.cat copy); EVALUATE in the lane that owns the Gaussian: 3 x nb
+//                            multiply-adds in coefficient order. (Round 2 summed 16 coefficient lanes per Gaussian with DPP:
+//                            812 vector instructions per batch against 390 now; 12.5 KiB of LDS per workgroup against 21.5.)
+//   C (lane = Gaussian)      projection, 2D covariance, conic, radius, tile rectangle, exact tile emission; the wave's 64
+//                            records leave through the same LDS slice as four coalesced 1 KiB stores.
+// What the kernel's length is made of (knock-outs at 1M Gaussians / SH 3 / 800^2, profiles/r03_k1_knockouts.txt): a batch is a
+// CHAIN of memory round trips and a wave's loads and stores share one in-order counter, so a load issued behind the stores is
+// delivered behind them. The next batch's per-Gaussian inputs are requested at the top of a batch and its first SH rows right
+// before the stores, every wait in the loop is a count that leaves the stores outstanding (the code below keeps the number of
+// stores the same on every path for that), the camera sits in LDS, and the grid is sized so that every workgroup walks the same
+// number of batches: 0.101 -> 0.083 ms.
+// dynamic LDS: [hist: nTiles u32 when hist_in_lds][4 waves x GSR_K1_WSLICE floats]
 // ---------------------------------------------------------------------------------------
 typedef float gsr_f3 __attribute__((ext_vector_type(3)));
 typedef gsr_f3 gsr_f3u __attribute__((aligned(4)));
-#define GSR_K1_BPITCH 17
+#define GSR_K1_ROWS 16           // SH rows a wave stages per round
+#define GSR_K1_PITCH 49          // floats between staged rows (16 coefficients x 3 channels, + 1: odd)
+#define GSR_K1_WSLICE 1024       // floats of LDS per wave: GSR_K1_ROWS staged rows, later the wave's 64 records (4 KiB) on their way out
 
 template <bool RAW>      // RAW: the inputs are DreamGaussian's raw parameters, activations fused (ViewConst.raw_act)
-__global__ void __launch_bounds__(256, 5)
+__global__ void __launch_bounds__(256, 4)
 gsr_preprocess_fwd(ViewTab views /* camera of this workgroup: views.v[blockIdx.y] */, int N, int K,
                    const float* __restrict__ means3D, const float* __restrict__ shs,
                    const float* __restrict__ shs_rest /* NULL: shs is [N,K,3]; else shs is [N,1,3] and this [N,K-1,3] */,
@@ -241,6 +249,8 @@ gsr_preprocess_fwd(ViewTab views /* camera of this workgroup: views.v[blockIdx.y
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_pp[];
     const ViewConst vc = views.v[blockIdx.y];
     const int nTiles = vc.gx * vc.gy;
+    // 256 bytes behind the statistics that nobody reads: where the lanes past the end of the array store (below)
+    char* const sink = reinterpret_cast<char*>(block_stats) + (size_t)gridDim.y * 2048 * 3 * 8;
     {   // per-view outputs: [views][N] records / radii / flags, [views][nTiles] counts, [views][grid][3] statistics
         const size_t vo = (size_t)blockIdx.y * (size_t)N;
         recs += vo; emit += vo; radii += vo; flags8 += vo;
@@ -248,89 +258,133 @@ gsr_preprocess_fwd(ViewTab views /* camera of this workgroup: views.v[blockIdx.y
         block_stats += (size_t)blockIdx.y * gridDim.x * 3;
     }
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem_pp);
-    float* basis = reinterpret_cast<float*>(smem_pp + (hist_in_lds ? ((nTiles * 4 + 15) & ~15) : 0));
-    float4* colour = reinterpret_cast<float4*>(basis + 256 * GSR_K1_BPITCH);
+    float* stage = reinterpret_cast<float*>(smem_pp + (hist_in_lds ? ((nTiles * 4 + 15) & ~15) : 0));
     const int nb = (vc.sh_degree + 1) * (vc.sh_degree + 1);          // active coefficients (<= 16)
     const bool coop = (shs != nullptr) && nb > 1;                     // phases A/B only for view-dependent colour
 
     if (hist_in_lds) {
         for (int t = threadIdx.x; t < nTiles; t += blockDim.x) hist[t] = 0;
     }
+    // The camera sits in LDS: read through its device pointers it comes back as VECTOR-memory loads (the compiler cannot
+    // prove the memory read-only), and waiting for one of those at the top of a batch also waits for the previous batch's
+    // stores (one in-order counter for a wave's loads and stores).
+    __shared__ __attribute__((aligned(16))) float cam[36];
+    if (threadIdx.x < 16) cam[threadIdx.x] = vc.view[threadIdx.x];
+    else if (threadIdx.x < 32) cam[threadIdx.x] = vc.proj[threadIdx.x - 16];
+    else if (threadIdx.x < 35) cam[threadIdx.x] = vc.campos[threadIdx.x - 32];
     __syncthreads();
 
-    const float* __restrict__ V = vc.view;
-    const float* __restrict__ P = vc.proj;
+    const float* V = cam;
+    const float* P = cam + 16;
+    const float* campos = cam + 32;
     unsigned long long my_ref = 0, my_vis = 0;
     float my_cmax = 0.f;              // largest colour component / depth of a listed Gaussian (bound used by the backward)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, grp = lane >> 4;
 
-    for (int base = blockIdx.x * 256; base < N; base += gridDim.x * 256) {
+    // A batch is a chain of memory round trips (inputs -> SH rows -> stores), and on this part a wave's stores count in the same
+    // in-order counter as its loads: a load issued AFTER the stores cannot be consumed before the stores have completed. So the
+    // NEXT batch's per-Gaussian inputs are requested at the top of a batch and its first SH rows right before the stores: the
+    // next batch starts on data that is already there, and the first load it issues itself is consumed ~250 instructions later.
+    float nmx = 0.f, nmy = 0.f, nmz = 0.f, nop = 0.f, nqw = 1.f, nqx = 0.f, nqy = 0.f, nqz = 0.f, nsx = 1.f, nsy = 1.f, nsz = 1.f;
+    // branch-free (index clamped, a dummy source when the 3D covariance is given): a load inside a branch comes with a register
+    // copy right behind it, i.e. a wait for memory at the top of the batch
+    const float* qbase = cov3D_precomp ? reinterpret_cast<const float*>(recs) : rotations;
+    const float* sbase = cov3D_precomp ? reinterpret_cast<const float*>(recs) : scales;
+    const int qmul = cov3D_precomp ? 0 : 4, smul = cov3D_precomp ? 0 : 3;
+    auto load_inputs = [&](int i) {                       // (culled Gaussians included: no dependent second trip)
+        const size_t ic = (size_t)min(i, N - 1);
+        const gsr_f3 m = *reinterpret_cast<const gsr_f3u*>(means3D + 3 * ic);
+        const float o = opacities[ic];
+        const float4 q = *reinterpret_cast<const float4*>(qbase + qmul * ic);
+        const gsr_f3 sc = *reinterpret_cast<const gsr_f3u*>(sbase + smul * ic);
+        nmx = m.x; nmy = m.y; nmz = m.z; nop = o;
+        nqw = q.x; nqx = q.y; nqy = q.z; nqz = q.w; nsx = sc.x; nsy = sc.y; nsz = sc.z;
+    };
+    // SH rows: 16 lanes per row, lane = coefficient, one 12-byte load each (a row is 16 x 12 B contiguous: four rows per wave
+    // instruction, fully coalesced); GSR_K1_ROWS rows per round
+    const int ki = min(l15, nb - 1);
+    const bool from_rest = shs_rest != nullptr && ki > 0;
+    const float* cbase = !coop ? nullptr : (from_rest ? shs_rest + (ki - 1) * 3 : shs + ki * 3);
+    const long long rstride = from_rest ? (long long)(K - 1) * 3 : (long long)(shs_rest ? 1 : K) * 3;   // floats per row
+    gsr_f3 cf[GSR_K1_ROWS / 4];
+    auto load_round = [&](int wbase, int r) {
+        const int g0 = wbase + r * GSR_K1_ROWS + grp;
+        if (wbase + 64 <= N) {                            // wave-uniform: only the last wave of the array needs the clamp
+            const float* p = cbase + (long long)g0 * rstride;
+#pragma unroll
+            for (int u = 0; u < GSR_K1_ROWS / 4; ++u) cf[u] = *reinterpret_cast<const gsr_f3u*>(p + (long long)(4 * u) * rstride);
+        } else {
+#pragma unroll
+            for (int u = 0; u < GSR_K1_ROWS / 4; ++u)
+                cf[u] = *reinterpret_cast<const gsr_f3u*>(cbase + (long long)min(g0 + 4 * u, N - 1) * rstride);
+        }
+    };
+    const int bstride = gridDim.x * 256;
+    load_inputs(blockIdx.x * 256 + threadIdx.x);
+    asm volatile("" : "+v"(nmx), "+v"(nmy), "+v"(nmz), "+v"(nop), "+v"(nqw), "+v"(nqx), "+v"(nqy), "+v"(nqz), "+v"(nsx), "+v"(nsy), "+v"(nsz));
+    if (coop && blockIdx.x * 256 < N) load_round(blockIdx.x * 256 + wave * 64, 0);
+    // The waits the compiler places are STATIC counts ("at most n younger operations outstanding"), the minimum over all paths into
+    // a point. Inside the loop seven stores sit between the first SH rows' request and their use; the path from here must hold as
+    // many, or the loop's wait would be "everything but the four input loads" -- i.e. all of the previous batch's stores.
+#pragma unroll
+    for (int d = 0; d < 7; ++d) reinterpret_cast<uint32_t*>(sink)[8 * d + 1] = (uint32_t)d;   // (apart: not merged into wider stores)
+
+    for (int base = blockIdx.x * 256; base < N; base += bstride) {
         const int idx = base + threadIdx.x;
-        float mx = 0.f, my = 0.f, mz = 0.f, depth = 0.f;
-        if (idx < N) {
-            const gsr_f3 m = *reinterpret_cast<const gsr_f3u*>(means3D + 3 * (size_t)idx);
-            mx = m.x; my = m.y; mz = m.z;
-            depth = view_depth(V, mx, my, mz);
-        }
+        const float mx = nmx, my = nmy, mz = nmz;
+        const float4 q_in = make_float4(nqw, nqx, nqy, nqz);
+        const gsr_f3 s_in = {nsx, nsy, nsz};
+        const float op_in = nop;
+        const float depth = idx < N ? view_depth(V, mx, my, mz) : 0.f;
         const bool front = (idx < N) && depth > 0.2f;
-        // phase C's inputs: requested now, consumed after phase B (their latency hides behind it)
-        float4 q_in = make_float4(1.f, 0.f, 0.f, 0.f);
-        gsr_f3 s_in = {1.f, 1.f, 1.f};
-        float op_in = 0.f;
-        if (front) {
-            op_in = opacities[idx];
-            if (!cov3D_precomp) {
-                q_in = reinterpret_cast<const float4*>(rotations)[idx];
-                s_in = *reinterpret_cast<const gsr_f3u*>(scales + 3 * (size_t)idx);
-            }
-        }
+        load_inputs(base + bstride + threadIdx.x);        // the next batch's inputs: in flight during this one (index clamped: unconditional)
+        float sh_r = 0.f, sh_g = 0.f, sh_b = 0.f;       // view-dependent colour of this lane's Gaussian (before the +0.5 and the clamp)
         if (coop) {
-            // The three phases of a wave's 64 Gaussians touch only this wave's slice of the two LDS tables:
-            // no workgroup barrier, the four waves drift apart and cover each other's memory latency.
-            float* wbasis = basis + wave * 64 * GSR_K1_BPITCH;
-            float4* wcolour = colour + wave * 64;
-            // ---- phase A: basis values of this lane's Gaussian
+            // A wave stages its own rows in its own slice of LDS: no workgroup barrier, the four waves drift apart and
+            // cover each other's memory latency.
+            float* wstage = stage + wave * GSR_K1_WSLICE;
+            // ---- phase A: basis values of this lane's Gaussian, kept in registers
+            float Bv[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) Bv[k] = 0.f;
             if (front) {
-                float dx = mx - vc.campos[0], dy = my - vc.campos[1], dz = mz - vc.campos[2];
+                float dx = mx - campos[0], dy = my - campos[1], dz = mz - campos[2];
                 const float inv = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
                 dx *= inv; dy *= inv; dz *= inv;
-                float B[16];
-                sh_basis(vc.sh_degree, dx, dy, dz, B);
-                float* row = wbasis + lane * GSR_K1_BPITCH;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) if (k < nb) row[k] = B[k];
+                sh_basis(vc.sh_degree, dx, dy, dz, Bv);
             }
-            wcolour[lane].w = front ? 1.f : 0.f;
-            wave_lds_handoff();
-            // ---- phase B: 16 lanes per Gaussian, lane = coefficient; 16 groups of 4 rows
+            // ---- phase B: GSR_K1_ROWS rows per round. Load: 16 lanes per row, lane = coefficient, one 12-byte load each (a row
+            // is 16 x 12 B contiguous: four rows per wave instruction, fully coalesced) -> LDS slot [row][3 coef .. +2].
+            // Evaluate: the lane that owns the Gaussian reads its row back (odd pitch: conflict-free) and runs the
+            // 3 x nb multiply-adds in registers, in coefficient order like the reference's sum (sh_utils.py:74-100).
             const int wbase = base + wave * 64;
-            for (int it0 = 0; it0 < 16; it0 += 8) {
-                // branch-free loads (address clamped into the tensors, product masked): the eight 12-byte loads of
-                // a group are all in flight before the first one is consumed
-                gsr_f3 cf[8];
-                const int ki = min(l15, nb - 1);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int gi = min(wbase + (it0 + u) * 4 + grp, N - 1);
-                    const float* src = (shs_rest && ki > 0) ? shs_rest + ((size_t)gi * (K - 1) + (ki - 1)) * 3
-                                                            : shs + ((size_t)gi * (shs_rest ? 1 : K) + ki) * 3;
-                    cf[u] = *reinterpret_cast<const gsr_f3u*>(src);
-                }
+            for (int r = 0; r < 64 / GSR_K1_ROWS; ++r) {
+                float* wr = wstage + grp * GSR_K1_PITCH + 3 * l15;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int row = (it0 + u) * 4 + grp;
-                    const bool use = wbase + row < N && l15 < nb && wcolour[row].w != 0.f;
-                    const float bk = use ? wbasis[row * GSR_K1_BPITCH + ki] : 0.f;
-                    const float pr = row_sum16(bk * cf[u].x), pg = row_sum16(bk * cf[u].y), pb = row_sum16(bk * cf[u].z);
-                    if (l15 < 3) reinterpret_cast<float*>(&wcolour[row])[l15] = l15 == 0 ? pr : (l15 == 1 ? pg : pb);
+                for (int u = 0; u < GSR_K1_ROWS / 4; ++u) {
+                    wr[u * 4 * GSR_K1_PITCH] = cf[u].x; wr[u * 4 * GSR_K1_PITCH + 1] = cf[u].y; wr[u * 4 * GSR_K1_PITCH + 2] = cf[u].z;
                 }
+                if (r + 1 < 64 / GSR_K1_ROWS) load_round(wbase, r + 1);   // in flight while this round is evaluated
+                wave_lds_handoff();
+                if (lane / GSR_K1_ROWS == r) {
+                    const float* rr = wstage + (lane % GSR_K1_ROWS) * GSR_K1_PITCH;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { sh_r += Bv[k] * rr[3 * k]; sh_g += Bv[k] * rr[3 * k + 1]; sh_b += Bv[k] * rr[3 * k + 2]; }
+                    if (nb > 4) {
+#pragma unroll
+                        for (int k = 4; k < 9; ++k) { sh_r += Bv[k] * rr[3 * k]; sh_g += Bv[k] * rr[3 * k + 1]; sh_b += Bv[k] * rr[3 * k + 2]; }
+                    }
+                    if (nb > 9) {
+#pragma unroll
+                        for (int k = 9; k < 16; ++k) { sh_r += Bv[k] * rr[3 * k]; sh_g += Bv[k] * rr[3 * k + 1]; sh_b += Bv[k] * rr[3 * k + 2]; }
+                    }
+                }
+                wave_lds_handoff();
             }
-            wave_lds_handoff();
         }
-        if (idx >= N) continue;
-
-        // ---- phase C
+        // ---- phase C (no `continue` for the lanes past the end: one path to the loop's back edge, see the prefetch below)
         SplatRec rec;
         rec.x = rec.y = rec.qa = rec.qb = rec.qc = rec.opac = rec.r = rec.g = rec.b = rec.depth = 0.f;
         rec.id = (uint32_t)idx; rec.bbx = pack16(1, 0); rec.bby = pack16(1, 0);
@@ -338,6 +392,7 @@ gsr_preprocess_fwd(ViewTab views /* camera of this workgroup: views.v[blockIdx.y
         EmitRec em; em.rectx = 0; em.recty = 0; em.depth_bits = 0; em.mask = 0;
         int32_t radius_out = 0;
 
+        if (idx < N) {
         float3 pv;
         pv.x = V[0] * mx + V[4] * my + V[8] * mz + V[12];
         pv.y = V[1] * mx + V[5] * my + V[9] * mz + V[13];
@@ -391,8 +446,7 @@ gsr_preprocess_fwd(ViewTab views /* camera of this workgroup: views.v[blockIdx.y
                         cr = c.x; cg = c.y; cb = c.z;
                     } else {
                         if (coop) {
-                            const float4 c = colour[threadIdx.x];      // (= this wave's slice, row = lane)
-                            cr = c.x; cg = c.y; cb = c.z;
+                            cr = sh_r; cg = sh_g; cb = sh_b;
                         } else {                            // degree 0: one 12-byte load per lane, no direction
                             const gsr_f3 c = *reinterpret_cast<const gsr_f3u*>(shs + (size_t)idx * (shs_rest ? 1 : K) * 3);
                             cr = SH_C0 * c.x; cg = SH_C0 * c.y; cb = SH_C0 * c.z;
@@ -458,13 +512,34 @@ gsr_preprocess_fwd(ViewTab views /* camera of this workgroup: views.v[blockIdx.y
                 }
             }
         }
-        radii[idx] = radius_out;
-        flags8[idx] = (uint8_t)rec.flags;
-        reinterpret_cast<uint4*>(recs + idx)[0] = reinterpret_cast<uint4*>(&rec)[0];
-        reinterpret_cast<uint4*>(recs + idx)[1] = reinterpret_cast<uint4*>(&rec)[1];
-        reinterpret_cast<uint4*>(recs + idx)[2] = reinterpret_cast<uint4*>(&rec)[2];
-        reinterpret_cast<uint4*>(recs + idx)[3] = reinterpret_cast<uint4*>(&rec)[3];
-        reinterpret_cast<uint4*>(emit)[idx] = *reinterpret_cast<uint4*>(&em);
+        }
+        // The next batch's inputs have long arrived: have the compiler take delivery HERE (an empty asm that "modifies" them), not
+        // at the copies it would otherwise place on the loop's back edge -- behind the stores, with a wait for everything.
+        asm volatile("" : "+v"(nmx), "+v"(nmy), "+v"(nmz), "+v"(nop), "+v"(nqw), "+v"(nqx), "+v"(nqy), "+v"(nqz), "+v"(nsx), "+v"(nsy), "+v"(nsz));
+        if (coop && base + bstride < N) load_round(base + bstride + wave * 64, 0);   // the next batch's first SH rows: requested BEFORE the stores
+        // Stores: no branch around them (the same number of stores on every path, see above) -- a lane past the end of the array
+        // stores into the sink.
+        const bool live = idx < N;
+        *(live ? radii + idx : reinterpret_cast<int32_t*>(sink)) = radius_out;
+        *(live ? flags8 + idx : reinterpret_cast<uint8_t*>(sink)) = (uint8_t)rec.flags;
+        if (base + wave * 64 + 64 <= N) {
+            // the wave's 64 records leave as four fully coalesced 1 KiB stores (lane = consecutive 16 bytes) instead of four
+            // stores of 64 sixteen-byte pieces 64 bytes apart: transposed through the wave's LDS slice
+            uint4* wrec = reinterpret_cast<uint4*>(stage + wave * GSR_K1_WSLICE);
+            wave_lds_handoff();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wrec[lane * 4 + j] = reinterpret_cast<uint4*>(&rec)[j];
+            wave_lds_handoff();
+            uint4* dst = reinterpret_cast<uint4*>(recs + (base + wave * 64));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dst[j * 64 + lane] = wrec[j * 64 + lane];
+            wave_lds_handoff();
+        } else {
+            uint4* dst = live ? reinterpret_cast<uint4*>(recs + idx) : reinterpret_cast<uint4*>(sink);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dst[j] = reinterpret_cast<uint4*>(&rec)[j];
+        }
+        *(live ? reinterpret_cast<uint4*>(emit) + idx : reinterpret_cast<uint4*>(sink)) = *reinterpret_cast<uint4*>(&em);
     }
 
     // statistics: wave -> workgroup in LDS -> one plain store per workgroup (summed by tile_scan).

@@ -239,3 +239,48 @@ def densify_and_split(gaussians, grads: torch.Tensor, grad_threshold: float, sce
     new_scaling = gaussians.scaling_inverse_activation(scaling.repeat(N, 1) / (0.8 * N))
     densification_postfix(gaussians, new_xyz, f_dc.repeat(N, 1, 1), f_rest.repeat(N, 1, 1), opac.repeat(N, 1), new_scaling, rot.repeat(N, 1))
     prune_points(gaussians, torch.cat((sel, torch.zeros(N * count, device=dev, dtype=torch.bool))))
+
+
+def _spread3(v: torch.Tensor) -> torch.Tensor:
+    """21-bit integers -> the same bits at every third position (int64)."""
+    v = v & 0x1FFFFF
+    v = (v | (v << 32)) & 0x1F00000000FFFF
+    v = (v | (v << 16)) & 0x1F0000FF0000FF
+    v = (v | (v << 8)) & 0x100F00F00F00F00F
+    v = (v | (v << 4)) & 0x10C30C30C30C30C3
+    v = (v | (v << 2)) & 0x1249249249249249
+    return v
+
+
+@torch.no_grad()
+def morton_order(xyz: torch.Tensor) -> torch.Tensor:
+    """Permutation [N] (int32) that sorts the points along a 3-D Morton (Z-order) curve of their bounding box
+    (21 bits per axis, ties by index: `torch.sort(stable=True)`). Gaussians that are close in space are close on the
+    screen of any camera, so after `reorder_gaussians` the 256 Gaussians of a preprocess workgroup emit into a
+    handful of tiles (the binning kernels write runs instead of single 8-byte entries) and the record gathers of a
+    tile's compositing hit the same cache lines. Host-side torch ops (a dozen elementwise launches and one sort):
+    meant for the densification interval (main.py:283-289), not for every step."""
+    p = xyz.detach().to(torch.float32)
+    lo = p.min(dim=0).values
+    span = (p.max(dim=0).values - lo).clamp_min(1e-20)
+    q = ((p - lo) / span * 2097151.0).to(torch.int64).clamp_(0, 2097151)
+    code = _spread3(q[:, 0]) | (_spread3(q[:, 1]) << 1) | (_spread3(q[:, 2]) << 2)
+    return torch.sort(code, stable=True).indices.to(torch.int32)
+
+
+@torch.no_grad()
+def reorder_gaussians(gaussians, perm: torch.Tensor = None) -> torch.Tensor:
+    """Permute the rows of a reference GaussianModel -- six parameters, their Adam moments, the three densification
+    accumulators -- with ONE gather launch; `perm` defaults to `morton_order(gaussians._xyz)`. The model is the same
+    set of Gaussians in another order: every per-Gaussian quantity follows its row, images change only through the
+    tie-break of equal depths inside a tile (the rasterizer orders equal keys by index, like the reference's stable
+    radix sort, rasterizer_impl.cu's `SortPairs`). Opt-in; returns the permutation it applied."""
+    if perm is None:
+        perm = morton_order(gaussians._xyz)
+    perm = perm.to(torch.int32).contiguous()
+    slots = _optimizer_slots(gaussians)
+    aux = [gaussians.xyz_gradient_accum, gaussians.denom, gaussians.max_radii2D]
+    outs = gather_rows(perm, [t for t, _, _, _ in slots] + aux)
+    _rebind(gaussians, slots, outs[:len(slots)])
+    gaussians.xyz_gradient_accum, gaussians.denom, gaussians.max_radii2D = outs[len(slots):]
+    return perm

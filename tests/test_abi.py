@@ -124,3 +124,24 @@ def test_product_never_imports_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f"{f} imports the oracle"
     for f in ("diff_gaussian_rasterization/__init__.py", "simple_knn/_C.py"):
         assert "oracle" not in open(os.path.join(ROOT, f)).read()
+
+
+def test_morton_order_is_the_z_curve_sort():
+    """dreamgaussian_amd.morton_order against a bit-by-bit interleave on the same quantised coordinates (host tensors)."""
+    import torch
+    from dreamgaussian_amd.densify import morton_order
+    x = torch.rand(500, 3, generator=torch.Generator().manual_seed(4)) * torch.tensor([2.0, 0.5, 1.0]) - 0.7
+    x[17] = x[3]                                                        # equal codes: ties stay in index order
+    p = morton_order(x).tolist()
+    lo, hi = x.min(0).values, x.max(0).values
+    q = ((x - lo) / (hi - lo) * 2097151.0).to(torch.int64).clamp(0, 2097151).tolist()
+
+    def code(v):
+        c = 0
+        for b in range(21):
+            for ax in range(3):
+                c |= ((v[ax] >> b) & 1) << (3 * b + ax)
+        return c
+    cs = [code(v) for v in q]
+    assert p == sorted(range(500), key=lambda i: (cs[i], i))
+    assert p.index(3) + 1 == p.index(17)

@@ -218,3 +218,67 @@ def test_densify_clone_and_split_equal_reference_algorithm(gpu):
     for p in (g["params"][0] for g in a.optimizer.param_groups):   # the optimiser keeps stepping on the new tensors
         p.grad = torch.ones_like(p)
     a.optimizer.step()
+
+
+def test_reorder_gaussians_moves_every_row_and_renders_the_same_model(gpu):
+    """dreamgaussian_amd.reorder_gaussians (Morton order, one gather launch): parameters, Adam moments and accumulators
+    follow their rows bit for bit; the permutation is the Z-order sort of the positions; the rendering of the permuted
+    model equals the original's (same Gaussians; only equal-depth ties inside a tile may swap) and per-Gaussian outputs
+    (radii, gradients) are the permuted originals."""
+    from dreamgaussian_amd import synthetic as syn
+    N = 20_000
+    names = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+    sc = syn.make_scene(N, 3, seed=2, kind="trained")
+    vals = [sc["means3D"], sc["shs"][:, :1].contiguous(), sc["shs"][:, 1:].contiguous(), sc["opacities"], sc["scales"], sc["rotations"]]
+    params = [torch.nn.Parameter(v.to(gpu)) for v in vals]
+    opt = D.FusedAdam([{"params": [p], "lr": lr, "name": name} for p, (name, _, lr) in zip(params, GROUPS)], lr=0.0, eps=1e-15)
+    for p in params:
+        p.grad = torch.zeros_like(p)
+    opt.step()                                                   # creates the moments
+    g = torch.Generator().manual_seed(9)
+    for p in params:
+        st = opt.state[p]
+        st["exp_avg"], st["exp_avg_sq"] = torch.rand(p.shape, generator=g).to(gpu), torch.rand(p.shape, generator=g).to(gpu)
+    m = _Model()
+    m.optimizer = opt
+    m.xyz_gradient_accum, m.denom, m.max_radii2D = torch.rand(N, 1, generator=g).to(gpu), torch.rand(N, 1, generator=g).to(gpu), torch.rand(N, generator=g).to(gpu)
+    for n, p in zip(names, params):
+        setattr(m, n, p)
+    before = {n: getattr(m, n).detach().clone() for n in names}
+    mom = {n: (opt.state[getattr(m, n)]["exp_avg"].clone(), opt.state[getattr(m, n)]["exp_avg_sq"].clone()) for n in names}
+    acc = (m.xyz_gradient_accum.clone(), m.denom.clone(), m.max_radii2D.clone())
+
+    rs_cpu = syn.make_settings(syn.orbit_pose(-10.0, 30.0, 2.0), 256, 256, sh_degree=3)
+    rs = D.GaussianRasterizationSettings(*[x.to(gpu) if torch.is_tensor(x) else x for x in rs_cpu])
+
+    def render(model):
+        ps = [getattr(model, n).detach().clone().requires_grad_(True) for n in names]
+        shs = torch.cat([ps[1], ps[2]], 1)
+        c, r, d, a = D.GaussianRasterizer(rs)(means3D=ps[0], means2D=torch.zeros_like(ps[0], requires_grad=True), opacities=ps[3], shs=shs, scales=ps[4], rotations=ps[5])
+        (c.sum() + d.sum() + a.sum()).backward()
+        return c.detach(), d.detach(), a.detach(), r, [p.grad for p in ps]
+    c0, d0, a0, r0, g0 = render(m)
+
+    perm = D.reorder_gaussians(m).long()
+    assert torch.equal(torch.sort(perm).values, torch.arange(N, device=gpu))
+    assert torch.equal(perm.cpu(), D.morton_order(before["_xyz"].cpu()).long())          # the same order on either device
+    for n in names:
+        p = getattr(m, n)
+        assert p.requires_grad and any(p is grp["params"][0] for grp in opt.param_groups), n
+        assert torch.equal(p.detach(), before[n][perm]), n
+        assert torch.equal(opt.state[p]["exp_avg"], mom[n][0][perm]) and torch.equal(opt.state[p]["exp_avg_sq"], mom[n][1][perm]), n
+    assert torch.equal(m.xyz_gradient_accum, acc[0][perm]) and torch.equal(m.denom, acc[1][perm]) and torch.equal(m.max_radii2D, acc[2][perm])
+    # neighbours on the curve are neighbours in space: the mean distance between consecutive rows collapses
+    x = m._xyz.detach()
+    assert float((x[1:] - x[:-1]).norm(dim=1).mean()) < 0.25 * float((before["_xyz"][1:] - before["_xyz"][:-1]).norm(dim=1).mean())
+
+    c1, d1, a1, r1, g1 = render(m)
+    assert torch.equal(r1, r0[perm])
+    for u, v in ((c1, c0), (d1, d0), (a1, a0)):
+        assert float((u - v).abs().max()) <= 2e-5, float((u - v).abs().max())    # fp32 order of the gradient/pixel sums does not enter here: ties only
+    for u, v in zip(g1, g0):
+        ref = v[perm]
+        assert float((u - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max())), float((u - ref).abs().max())
+    for p in (grp["params"][0] for grp in opt.param_groups):        # the optimiser keeps stepping on the new tensors
+        p.grad = torch.ones_like(p)
+    opt.step()

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-3 gpurun driver: sections chosen by arguments. Outputs -> gpurun_out/.
-#   quick | tests | bench | benchall | shifts | prof | pmc | stage1 | views | sds | rccl
+#   quick | tests | bench | benchall | morton | libs | shifts | prof | pmc | stage1 | views | sds | rccl
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -21,6 +21,19 @@ benchall)
     echo "== bench $wl"; timeout 300 python bench.py --workload $wl --cpu-budget 0 2> gpurun_out/bench_$wl.err | tee gpurun_out/bench_$wl.json | benchline
   done
   echo "== bench 1M trained"; timeout 300 python bench.py --kind trained --cpu-budget 0 2> gpurun_out/bench_1M_trained.err | tee gpurun_out/bench_1M_trained.json | benchline;;
+morton)
+  # the same scenes with the rows permuted along a Z-order curve (dreamgaussian_amd.reorder_gaussians)
+  for wl in 1M-800-sh3 100k-800-sh3 250k-512-sh0; do
+    echo "== bench $wl --order morton"; timeout 300 python bench.py --workload $wl --order morton --cpu-budget 0 2> gpurun_out/bench_${wl}_morton.err | tee gpurun_out/bench_${wl}_morton.json | benchline
+  done
+  echo "== bench 1M trained --order morton"; timeout 300 python bench.py --kind trained --order morton --cpu-budget 0 2> gpurun_out/bench_1M_trained_morton.err | tee gpurun_out/bench_1M_trained_morton.json | benchline;;
+libs)
+  # same-box A/B of alternative builds of the library (GSR_LIB=<path>, same ABI): LIBS="path1 path2", WLS="..."
+  for l in ${LIBS}; do
+    for wl in ${WLS:-1M-800-sh3 100k-800-sh3}; do
+      echo "== [$l] $wl"; GSR_LIB=$R/$l timeout 300 python bench.py --cpu-budget 0 --workload $wl $BENCH_ARGS 2>>gpurun_out/ab_err.log | benchline
+    done
+  done;;
 shifts)
   # same-box A/B of the env-selectable variants of the segment forward
   for v in ${VARIANTS:-"GSR_SEG_SHIFT=6" "GSR_SEG_SHIFT=7" "GSR_SEG_SHIFT=8" "GSR_FWD_HINTS=off" "GSR_FWD=q" "GSR_FWD=block"}; do
