@@ -145,7 +145,7 @@ BinLayout bin_layout(size_t M, int nTiles, int shift) {
     L.entries = o; o += align_up(M * 8);
     // (tile, segment) items of the forward = segment records: sum over tiles of ceil(n_t >> shift) <= (M >> shift) + nTiles
     L.items = (M >> shift) + (size_t)nTiles;
-    L.ckpt = o; o += align_up((L.items + 1) * (size_t)GSR_CKPT_FLOATS * 4);
+    L.ckpt = o; o += align_up((L.items + 3) * (size_t)GSR_CKPT_FLOATS * 4);   // + 3 spare records: the store sink of the serial walk (gsr_render.hip)
     // backward work list: sum over tiles of ceil(last_t / 2^shift) <= the same bound
     L.plan_cap = L.items + 1;
     L.plan_tile = o; o += align_up(L.plan_cap * 16);      // 16-byte (tile, segment, list start, list length) items
@@ -357,7 +357,6 @@ int begin_impl(const GsrView* views, int B, int32_t N, int32_t K,
     }
     if (N > 0) {
         const size_t hist_bytes = hist_in_lds ? (((size_t)T * 4 + 15) & ~(size_t)15) : 0;
-        const bool coop = shs && view->sh_degree > 0;                       // each wave's SH staging rows (gsr_preprocess.hip)
         const size_t lds = hist_bytes + (size_t)4 * GSR_K1_WSLICE * 4;      // + each wave's slice: SH staging rows, then its records on their way out
         if (lds > 160 * 1024) return fail(-1, "preprocess needs more than 160 KiB of LDS%s", "");
         auto k1 = vc.raw_act ? gsr_preprocess_fwd<true> : gsr_preprocess_fwd<false>;
@@ -478,13 +477,15 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
             vs.view_mask = mask_q;
             hipLaunchKernelGGL(gsr_render_fwd_serial<true>, dim3(TA), dim3(256), 0, stream, tile_off, recs, sorted_ids, W, H, vc.gx,
                                out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, order, shift,
-                               plan_off, plan_tile, counters + 4, (uint32_t)BL.plan_cap, (unsigned long long)mask_q, counters, (uint32_t)M, maxc_cap, vs);
+                               plan_off, plan_tile, counters + 4, (uint32_t)BL.plan_cap, (unsigned long long)mask_q, (uint32_t)BL.items /* the spare record: store sink */,
+                               counters, (uint32_t)M, maxc_cap, vs);
         }
         if (mask_q != mask_all) {
             vs.view_mask = mask_all & ~mask_q;
             hipLaunchKernelGGL(gsr_render_fwd_serial<false>, dim3(TA), dim3(256), 0, stream, tile_off, recs, sorted_ids, W, H, vc.gx,
                                out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, order, shift,
-                               plan_off, plan_tile, counters + 4, (uint32_t)BL.plan_cap, (unsigned long long)mask_q, counters, (uint32_t)M, maxc_cap, vs);
+                               plan_off, plan_tile, counters + 4, (uint32_t)BL.plan_cap, (unsigned long long)mask_q, (uint32_t)BL.items /* the spare record: store sink */,
+                               counters, (uint32_t)M, maxc_cap, vs);
         }
         LAUNCH_CHECK(view, stream, "render_fwd");
         return 0;

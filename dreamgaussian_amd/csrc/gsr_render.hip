@@ -307,7 +307,7 @@ gsr_render_fwd_serial(const uint32_t* __restrict__ tile_off, const SplatRec* __r
                       float* __restrict__ rec_base, const uint32_t* __restrict__ tile_seg,
                       const uint32_t* __restrict__ order, int seg_shift,
                       uint32_t* __restrict__ plan_off, uint4* __restrict__ plan_items,
-                      unsigned long long* __restrict__ plan_total, uint32_t plan_cap, unsigned long long qmask_views,
+                      unsigned long long* __restrict__ plan_total, uint32_t plan_cap, unsigned long long qmask_views, uint32_t sink_rec,
                       const unsigned long long* __restrict__ counters, uint32_t capacity, uint32_t maxc_cap, ViewSplit vs) {
     if (counters[2] > (unsigned long long)capacity || counters[3] > (unsigned long long)maxc_cap) return;
     __shared__ float4 stage[4][3][GSR_RB + 2];
@@ -351,107 +351,124 @@ gsr_render_fwd_serial(const uint32_t* __restrict__ tile_off, const SplatRec* __r
     float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, A = 0.f;
     uint32_t last = 0;
     bool done = !inside;
-    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra, na = ra, nb = ra, nc = ra;
-    uint32_t id_next = 0;                                  // list entry of round r+2 (r+3 after the loads below)
-    if ((uint32_t)lane < n) {
-        const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + ids[start + lane]);
-        ra = p[0]; rb = p[1]; rc = p[2];
-    }
-    if (GSR_RB + (uint32_t)lane < n) {
-        const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + ids[start + GSR_RB + lane]);
-        na = p[0]; nb = p[1]; nc = p[2];
-    }
-    if (2 * GSR_RB + (uint32_t)lane < n) id_next = ids[start + 2 * GSR_RB + lane];
-    for (uint32_t rel = 0; rel < n; rel += GSR_RB) {
-        const unsigned long long alive = __ballot(!done);
-        if (alive == 0ull) break;
-        float4 ma = make_float4(0.f, 0.f, 0.f, 0.f), mb = ma, mc = ma;
-        uint32_t id_next2 = 0;
+    // The walk is a chain of dependent gathers (list entry -> record) in front of ~1 000 instructions per round, and in its last
+    // third the heaviest tiles run alone on their SIMDs: what a round costs then is what it WAITS for. Three register sets take
+    // turns (the loop is unrolled three times, no copies between them): round r composites set r % 3, requested two rounds ago,
+    // and requests round r + 2's records and round r + 3's list entries. Every load is branch-free (positions clamped into the
+    // list: a load inside a divergent `if` drags a register copy, i.e. a wait, right behind it) and so are the stores (a lane
+    // that has nothing to store writes into a spare record): the compiler's waits are static counts, the minimum over all
+    // paths, and with the same number of memory operations on every path they leave two rounds of requests outstanding.
+    float* const sinkf = rec_base + (size_t)sink_rec * GSR_CKPT_FLOATS + (wave * 64 + lane);
+    unsigned long long* const sink64 = reinterpret_cast<unsigned long long*>(rec_base + (size_t)sink_rec * GSR_CKPT_FLOATS + GSR_REC_HINT) + lane;
+    if (n > 0u) {                                         // (wave-uniform)
+        float4 r0a, r0b, r0c, r1a, r1b, r1c, r2a, r2b, r2c;
+        uint32_t idq;                                     // list entries of the round after the youngest requested records
         {
-            if (rel + 2 * GSR_RB + lane < n) {
-                const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + id_next);
-                ma = p[0]; mb = p[1]; mc = p[2];
-            }
-            if (rel + 3 * GSR_RB + lane < n) id_next2 = ids[start + rel + 3 * GSR_RB + lane];
-        }
-        if (rel != 0u && (rel & ((1u << seg_shift) - 1u)) == 0u && inside) {    // segment cut: checkpoint for the backward
-            float* c = rec0 + (size_t)((rel >> seg_shift) - 1u) * GSR_CKPT_FLOATS;
-            c[0] = T; c[256] = C0; c[512] = C1; c[768] = C2; c[1024] = D; c[1280] = A;
-        }
-        const uint32_t i = rel + lane;
-        if (!QUAD) {
-            bool hit = false;
-            if (i < n)      // can alpha reach 1/255 anywhere in this wave's 8x8 block?
-                hit = rect_max_power(ra.x, ra.y, ra.z, ra.w, rb.x, bx0, bx0 + 7.f, by0, by0 + 7.f) >= min_visible_power(rb.y);
-            const unsigned long long mask = __ballot(hit);
-            if (mask != 0ull) {
-                const int nhit = __popcll(mask);
-                if (hit) {
-                    const uint32_t pos = lanes_below(mask);
-                    rc.z = __uint_as_float(i + 1u);       // 1-based list position replaces the box
-                    sa[pos] = ra; sb[pos] = rb; sc[pos] = rc;
-                }
-                wave_lds_handoff();
-                float4 e0a = sa[0], e0b = sb[0], e0c = sc[0];
-                for (int j = 0; j < nhit; j += 2) {       // slots nhit, nhit+1 are padding: read, masked
-                    const float4 e1a = sa[j + 1], e1b = sb[j + 1], e1c = sc[j + 1];   // in flight during entry j
-                    GSR_COMPOSITE(e0a, e0b, e0c, __float_as_uint(e0c.z), true, 1.f, true)
-                    e0a = sa[j + 2]; e0b = sb[j + 2]; e0c = sc[j + 2];               // in flight during entry j+1
-                    GSR_COMPOSITE(e1a, e1b, e1c, __float_as_uint(e1c.z), j + 1 < nhit, 1.f, true)
-                }
-                wave_lds_handoff();                       // reads above precede the next round's writes
-            }
-        } else {
-            bool h0 = false, h1 = false, h2 = false, h3 = false;
-            if (i < n) {
-                const float thr = min_visible_power(rb.y);
-                float qp[4];
-                quad_max_powers(ra.x, ra.y, ra.z, ra.w, rb.x, bx0, by0, qp);
-                // a quad whose pixels have all stopped takes no more entries
-                h0 = ((alive & 0x000000000000ffffull) != 0ull) && qp[0] >= thr;
-                h1 = ((alive & 0x00000000ffff0000ull) != 0ull) && qp[1] >= thr;
-                h2 = ((alive & 0x0000ffff00000000ull) != 0ull) && qp[2] >= thr;
-                h3 = ((alive & 0xffff000000000000ull) != 0ull) && qp[3] >= thr;
-            }
-            const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
-            if (lane == 0) {   // the round's four hit masks: the backward's quad tests (GSR_CNT_QMASK)
-                unsigned long long* mp = reinterpret_cast<unsigned long long*>(recw + (size_t)(rel >> seg_shift) * GSR_CKPT_FLOATS + GSR_REC_HINT)
-                                         + (((rel >> 6) & ((1u << (seg_shift - 6)) - 1u)) * 16u + (uint32_t)wave * 4u);
-                mp[0] = m0; mp[1] = m1; mp[2] = m2; mp[3] = m3;
-            }
-            if ((m0 | m1 | m2 | m3) != 0ull) {
-                uint8_t (*qlw)[80] = qlist[QUAD ? wave : 0];
-                if (h0 | h1 | h2 | h3) { sa[lane] = ra; sb[lane] = rb; sc[lane] = rc; }
-                if (h0) qlw[0][lanes_below(m0)] = (uint8_t)lane;
-                if (h1) qlw[1][lanes_below(m1)] = (uint8_t)lane;
-                if (h2) qlw[2][lanes_below(m2)] = (uint8_t)lane;
-                if (h3) qlw[3][lanes_below(m3)] = (uint8_t)lane;
-                const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
-                const int nmax = max(max(n0, n1), max(n2, n3));
-                const int nmine = row == 0 ? n0 : (row == 1 ? n1 : (row == 2 ? n2 : n3));
-                const uint32_t pos1 = rel + 1u;           // 1-based list position of staged slot 0
-                const uint8_t* __restrict__ ql = qlw[row];
-                wave_lds_handoff();
-                for (int jb = 0; jb < nmax; jb += 8) {
-                    const uint2 sl = *reinterpret_cast<const uint2*>(ql + jb);
-                    uint32_t slot[8];
+            const uint32_t id0 = ids[start + min((uint32_t)lane, n - 1u)], id1 = ids[start + min(GSR_RB + (uint32_t)lane, n - 1u)];
+            idq = ids[start + min(2u * GSR_RB + (uint32_t)lane, n - 1u)];
+            const float4* __restrict__ p0 = reinterpret_cast<const float4*>(recs + id0);
+            const float4* __restrict__ p1 = reinterpret_cast<const float4*>(recs + id1);
+            r0a = p0[0]; r0b = p0[1]; r0c = p0[2];
+            r1a = p1[0]; r1b = p1[1]; r1c = p1[2];
+            // (the static counts again: the path from here into the loop must hold as many memory operations behind these
+            // requests as one trip around the loop does, or the first wait of every round shrinks to what THIS path allows)
 #pragma unroll
-                    for (int b = 0; b < 8; ++b) slot[b] = ((b < 4 ? sl.x : sl.y) >> (8 * (b & 3))) & 0xffu;
-                    float4 e0a = sa[slot[0]], e0b = sb[slot[0]], e0c = sc[slot[0]];
+            for (int d = 1; d <= 16; ++d) sinkf[256 * d] = 0.f;          // planes 1.. of the three spare records
+        }
+        auto walk_round = [&](const uint32_t rel, float4 ra, float4 rb, float4 rc, float4& da, float4& db, float4& dc) -> bool {
+            if (rel >= n) return false;
+            const unsigned long long alive = __ballot(!done);
+            if (alive == 0ull) return false;
+            {
+                const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + idq);
+                da = p[0]; db = p[1]; dc = p[2];
+                idq = ids[start + min(rel + 3u * GSR_RB + (uint32_t)lane, n - 1u)];
+            }
+            {   // segment cut: checkpoint for the backward
+                const bool cut = rel != 0u && (rel & ((1u << seg_shift) - 1u)) == 0u;
+                float* c = (cut && inside) ? rec0 + (size_t)((rel >> seg_shift) - 1u) * GSR_CKPT_FLOATS : sinkf;
+                c[0] = T; c[256] = C0; c[512] = C1; c[768] = C2; c[1024] = D; c[1280] = A;
+            }
+            const uint32_t i = rel + lane;
+            if (!QUAD) {
+                bool hit = false;
+                if (i < n)      // can alpha reach 1/255 anywhere in this wave's 8x8 block?
+                    hit = rect_max_power(ra.x, ra.y, ra.z, ra.w, rb.x, bx0, bx0 + 7.f, by0, by0 + 7.f) >= min_visible_power(rb.y);
+                const unsigned long long mask = __ballot(hit);
+                if (mask != 0ull) {
+                    const int nhit = __popcll(mask);
+                    if (hit) {
+                        const uint32_t pos = lanes_below(mask);
+                        rc.z = __uint_as_float(i + 1u);       // 1-based list position replaces the box
+                        sa[pos] = ra; sb[pos] = rb; sc[pos] = rc;
+                    }
+                    wave_lds_handoff();
+                    float4 e0a = sa[0], e0b = sb[0], e0c = sc[0];
+                    for (int j = 0; j < nhit; j += 2) {       // slots nhit, nhit+1 are padding: read, masked
+                        const float4 e1a = sa[j + 1], e1b = sb[j + 1], e1c = sc[j + 1];   // in flight during entry j
+                        GSR_COMPOSITE(e0a, e0b, e0c, __float_as_uint(e0c.z), true, 1.f, true)
+                        e0a = sa[j + 2]; e0b = sb[j + 2]; e0c = sc[j + 2];               // in flight during entry j+1
+                        GSR_COMPOSITE(e1a, e1b, e1c, __float_as_uint(e1c.z), j + 1 < nhit, 1.f, true)
+                    }
+                    wave_lds_handoff();                       // reads above precede the next round's writes
+                }
+            } else {
+                bool h0 = false, h1 = false, h2 = false, h3 = false;
+                if (i < n) {
+                    const float thr = min_visible_power(rb.y);
+                    float qp[4];
+                    quad_max_powers(ra.x, ra.y, ra.z, ra.w, rb.x, bx0, by0, qp);
+                    // a quad whose pixels have all stopped takes no more entries
+                    h0 = ((alive & 0x000000000000ffffull) != 0ull) && qp[0] >= thr;
+                    h1 = ((alive & 0x00000000ffff0000ull) != 0ull) && qp[1] >= thr;
+                    h2 = ((alive & 0x0000ffff00000000ull) != 0ull) && qp[2] >= thr;
+                    h3 = ((alive & 0xffff000000000000ull) != 0ull) && qp[3] >= thr;
+                }
+                const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
+                {   // the round's four hit masks: the backward's quad tests (GSR_CNT_QMASK). Lanes 0..3 store one each, the others into the sink
+                    unsigned long long* mp = reinterpret_cast<unsigned long long*>(recw + (size_t)(rel >> seg_shift) * GSR_CKPT_FLOATS + GSR_REC_HINT)
+                                             + (((rel >> 6) & ((1u << (seg_shift - 6)) - 1u)) * 16u + (uint32_t)wave * 4u);
+                    *(lane < 4 ? mp + lane : sink64) = lane == 0 ? m0 : (lane == 1 ? m1 : (lane == 2 ? m2 : m3));
+                }
+                if ((m0 | m1 | m2 | m3) != 0ull) {
+                    uint8_t (*qlw)[80] = qlist[QUAD ? wave : 0];
+                    if (h0 | h1 | h2 | h3) { sa[lane] = ra; sb[lane] = rb; sc[lane] = rc; }
+                    if (h0) qlw[0][lanes_below(m0)] = (uint8_t)lane;
+                    if (h1) qlw[1][lanes_below(m1)] = (uint8_t)lane;
+                    if (h2) qlw[2][lanes_below(m2)] = (uint8_t)lane;
+                    if (h3) qlw[3][lanes_below(m3)] = (uint8_t)lane;
+                    const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
+                    const int nmax = max(max(n0, n1), max(n2, n3));
+                    const int nmine = row == 0 ? n0 : (row == 1 ? n1 : (row == 2 ? n2 : n3));
+                    const uint32_t pos1 = rel + 1u;           // 1-based list position of staged slot 0
+                    const uint8_t* __restrict__ ql = qlw[row];
+                    wave_lds_handoff();
+                    for (int jb = 0; jb < nmax; jb += 8) {
+                        const uint2 sl = *reinterpret_cast<const uint2*>(ql + jb);
+                        uint32_t slot[8];
 #pragma unroll
-                    for (int b = 0; b < 8; b += 2) {
-                        if (jb + b < nmax) {              // wave-uniform
-                            const float4 e1a = sa[slot[b + 1]], e1b = sb[slot[b + 1]], e1c = sc[slot[b + 1]];   // in flight during entry b
-                            GSR_COMPOSITE(e0a, e0b, e0c, pos1 + slot[b], jb + b < nmine, 1.f, true)
-                            if (b + 2 < 8) { e0a = sa[slot[b + 2]]; e0b = sb[slot[b + 2]]; e0c = sc[slot[b + 2]]; }   // in flight during entry b+1
-                            GSR_COMPOSITE(e1a, e1b, e1c, pos1 + slot[b + 1], jb + b + 1 < nmine, 1.f, true)
+                        for (int b = 0; b < 8; ++b) slot[b] = ((b < 4 ? sl.x : sl.y) >> (8 * (b & 3))) & 0xffu;
+                        float4 e0a = sa[slot[0]], e0b = sb[slot[0]], e0c = sc[slot[0]];
+#pragma unroll
+                        for (int b = 0; b < 8; b += 2) {
+                            if (jb + b < nmax) {              // wave-uniform
+                                const float4 e1a = sa[slot[b + 1]], e1b = sb[slot[b + 1]], e1c = sc[slot[b + 1]];   // in flight during entry b
+                                GSR_COMPOSITE(e0a, e0b, e0c, pos1 + slot[b], jb + b < nmine, 1.f, true)
+                                if (b + 2 < 8) { e0a = sa[slot[b + 2]]; e0b = sb[slot[b + 2]]; e0c = sc[slot[b + 2]]; }   // in flight during entry b+1
+                                GSR_COMPOSITE(e1a, e1b, e1c, pos1 + slot[b + 1], jb + b + 1 < nmine, 1.f, true)
+                            }
                         }
                     }
+                    wave_lds_handoff();                       // reads above precede the next round's writes
                 }
-                wave_lds_handoff();                       // reads above precede the next round's writes
             }
+            return true;
+        };
+        for (uint32_t rel = 0;; rel += 3u * GSR_RB) {
+            if (!walk_round(rel, r0a, r0b, r0c, r2a, r2b, r2c)) break;
+            if (!walk_round(rel + GSR_RB, r1a, r1b, r1c, r0a, r0b, r0c)) break;
+            if (!walk_round(rel + 2u * GSR_RB, r2a, r2b, r2c, r1a, r1b, r1c)) break;
         }
-        ra = na; rb = nb; rc = nc; na = ma; nb = mb; nc = mc; id_next = id_next2;
     }
     if (inside) {
         const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
@@ -483,15 +500,16 @@ gsr_render_fwd_serial(const uint32_t* __restrict__ tile_off, const SplatRec* __r
     {
         const uint32_t segs = wl[0], base = plan_base;
         for (uint32_t q = threadIdx.x; q < segs; q += 256)
-            if (base + q < plan_cap) plan_items[base + q] = make_uint4((uint32_t)tg, q, start, tile_n);   // {tile, segment, list start, list length}
+            if (base + q < plan_cap)     // {tile, the segment's record, list start, segment | (entries in it - 1) << 24}: all the backward needs, in one load
+                plan_items[base + q] = make_uint4((uint32_t)tg, tile_seg[tg] + q, start, q | ((min(1u << seg_shift, tile_n - (q << seg_shift)) - 1u) << 24));
     }
 }
 template __global__ void gsr_render_fwd_serial<false>(const uint32_t*, const SplatRec*, const uint32_t*, int, int, int, float*, float*, float*, float*,
                                                       uint32_t*, float*, float*, const uint32_t*, const uint32_t*, int, uint32_t*, uint4*,
-                                                      unsigned long long*, uint32_t, unsigned long long, const unsigned long long*, uint32_t, uint32_t, ViewSplit);
+                                                      unsigned long long*, uint32_t, unsigned long long, uint32_t, const unsigned long long*, uint32_t, uint32_t, ViewSplit);
 template __global__ void gsr_render_fwd_serial<true>(const uint32_t*, const SplatRec*, const uint32_t*, int, int, int, float*, float*, float*, float*,
                                                      uint32_t*, float*, float*, const uint32_t*, const uint32_t*, int, uint32_t*, uint4*,
-                                                     unsigned long long*, uint32_t, unsigned long long, const unsigned long long*, uint32_t, uint32_t, ViewSplit);
+                                                     unsigned long long*, uint32_t, unsigned long long, uint32_t, const unsigned long long*, uint32_t, uint32_t, ViewSplit);
 
 // The exact walk of list positions [lo, hi) of a tile for the lanes with done == false (lane = pixel, row-major 8x8 block at
 // (bx0, by0)), `gate` = their transmittance in front of the segment. Updates T, C0, C1, C2, D, A, last, done: the segment's own
@@ -692,7 +710,8 @@ gsr_render_fwd_combine(const uint32_t* __restrict__ tile_off, const SplatRec* __
     {
         const uint32_t segs = wl[0], base = plan_base;
         for (uint32_t q = threadIdx.x; q < segs; q += 256)
-            if (base + q < plan_cap) plan_items[base + q] = make_uint4((uint32_t)tg, q, start, tile_n);   // {tile, segment, list start, list length}
+            if (base + q < plan_cap)     // {tile, the segment's record, list start, segment | (entries in it - 1) << 24}: all the backward needs, in one load
+                plan_items[base + q] = make_uint4((uint32_t)tg, tile_seg[tg] + q, start, q | ((min(1u << seg_shift, tile_n - (q << seg_shift)) - 1u) << 24));
         uint32_t wb = walk_base;
         for (int w = 0; w < wave; ++w) wb += wcnt[w];
         if ((uint32_t)lane < nwalk) walk_items[wb + lane] = make_uint2((uint32_t)tg * 4u + (uint32_t)wave, (uint32_t)wseg[wave][lane]);
@@ -880,11 +899,14 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
     __shared__ uint32_t gmax_w[4];                                           // per wave: max of gsum over its pixels (bits of a non-negative float)
     extern __shared__ __attribute__((aligned(16))) unsigned long long acc64[];   // [(1 << seg_shift) * GSR_Q2_ROW]
     if (blockIdx.x >= (uint32_t)plan_total[0]) return;
-    const uint4 item = plan_items[blockIdx.x];            // {tile among all views' tiles, segment, list start, list length}: ONE load, then list -> records
+    // {tile among all views' tiles, the segment's record, list start, segment | (entries - 1) << 24}: ONE scalar load, and every
+    // vector load of the set-up below depends on nothing else (only the records hang off the list entries).
+    const uint4 item = plan_items[blockIdx.x];
     const int tg = (int)item.x;
-    const uint32_t seg = item.y;
+    const uint32_t rec_idx = item.y;
     const uint32_t start = item.z;
-    const uint32_t n = item.w;
+    const uint32_t seg = item.w & 0xffffffu;
+    const uint32_t len = (item.w >> 24) + 1u;             // entries of this segment
     const int view = tg / vs.tiles_per_view;
     const int tile = tg - view * vs.tiles_per_view;
     const float* __restrict__ bg = vs.bg[view];
@@ -896,29 +918,13 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
         final_T += view * vs.img_stride; n_contrib += view * vs.img_stride; totals += view * vs.img_stride;
     }
     const uint32_t seg_lo = seg << seg_shift;
-    if (seg_lo >= n) return;                              // (block-uniform)
+    const uint32_t seg_end = seg_lo + len;
     const bool have_masks = ((plan_total[GSR_CNT_QMASK - GSR_CNT_PLAN] >> view) & 1ull) != 0ull;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int row = lane >> 4, l15 = lane & 15;
-    // records of the first round: requested before anything else so that the two dependent loads
-    // (index, record) overlap the per-pixel set-up below; entries past this wave's own end are masked later
-    const uint32_t seg_end = min(seg_lo + (1u << seg_shift), n);
-    float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa, pc = pa;
-    uint32_t id_first = 0;
-    if (seg_lo + lane < seg_end) {
-        id_first = ids[start + seg_lo + lane];
-        const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + id_first);
-        pa = p[0]; pb = p[1]; pc = p[2];
-    }
-    // wave 0 keeps what the flush needs of its first-round records (index, x, y, qa, qb, qc, opacity): table row r of the flush
-    // is list entry seg_lo + r, i.e. exactly lane r's record here -- no second trip list -> record at the end of the chain
-    const float4 keep_a = pa;
-    const float keep_qc = pb.x, keep_op = pb.y;
     const int tx0 = (tile % gx) * GSR_TILE, ty0 = (tile / gx) * GSR_TILE;
     const int bx = tx0 + (wave & 1) * 8, by = ty0 + (wave >> 1) * 8;
-    for (int q = threadIdx.x; q < (GSR_Q2_ROW << seg_shift); q += 256) acc64[q] = 0ull;
-    for (int q = threadIdx.x; q < 4 * 4 * GSR_QL_PITCH / 4; q += 256) reinterpret_cast<uint32_t*>(&qlist[0][0][0])[q] = 0u;   // stale reads stay inside the stage
     bool active = (bx < W) && (by < H);                   // wave-uniform; no early return: barriers below
     const int qx = bx + (row & 1) * 4, qy = by + (row >> 1) * 4;         // this row's quad
     const int lx = (row & 1) * 4 + (l15 & 3), ly = (row >> 1) * 4 + (l15 >> 2);
@@ -926,35 +932,49 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
     const bool inside = (px < W) && (py < H);
     const float pxf = (float)px, pyf = (float)py;
     const int cidx = wave * 64 + ly * 8 + lx;             // the forward's checkpoint slot of this pixel (row-major 8x8)
+    // ---- every load of the set-up, issued back to back and BRANCH-FREE (indices clamped into range, the values of lanes that
+    // must not see them replaced further down): a load inside a divergent `if` is followed by a register copy, i.e. by a wait
+    // for memory right behind it, and a workgroup is a latency chain of which only four fit a CU.
+    // (1) list entry of the first round -> record (the only dependent pair); entries past the segment's end repeat its last one
+    //     and are masked where they are used
+    const uint32_t id_first = ids[start + min(seg_lo + (uint32_t)lane, seg_end - 1u)];
+    // (2) the pixel: clamped into the image
+    const size_t HW = (size_t)H * W;
+    const size_t pix = (size_t)min(py, H - 1) * W + min(px, W - 1);
+    const float l_T = final_T[pix];
+    const uint32_t l_last = n_contrib[pix];
+    const float l_g0 = dL_dcolor[pix], l_g1 = dL_dcolor[HW + pix], l_g2 = dL_dcolor[2 * HW + pix];
+    const float l_gD = dL_ddepth[pix], l_gA = dL_dalpha[pix];
+    const float l_t0 = totals[pix], l_t1 = totals[HW + pix], l_t2 = totals[2 * HW + pix], l_t3 = totals[3 * HW + pix], l_t4 = totals[4 * HW + pix];
+    // (3) the segment's checkpoint = the state the forward left after the segment in front (segment 0: its own record, unused)
+    const float* __restrict__ ckp = ckpt + (size_t)(rec_idx - (seg > 0u ? 1u : 0u)) * GSR_CKPT_FLOATS + cidx;
+    const float l_c0 = ckp[0], l_c1 = ckp[256], l_c2 = ckp[512], l_c3 = ckp[768], l_c4 = ckp[1024], l_c5 = ckp[1280];
+    // (4) the first round's quad masks (written by the serial forward; garbage without them: unused)
+    const unsigned long long* __restrict__ mp0 = reinterpret_cast<const unsigned long long*>(ckpt + (size_t)rec_idx * GSR_CKPT_FLOATS + GSR_REC_HINT) + (uint32_t)wave * 4u;
+    const unsigned long long km0 = mp0[0], km1 = mp0[1], km2 = mp0[2], km3 = mp0[3];
+    // (5) the records of the first round
+    float4 pa, pb, pc;
+    {
+        const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + id_first);
+        pa = p[0]; pb = p[1]; pc = p[2];
+    }
+    // wave 0 keeps what the flush needs of its first-round records (index, x, y, qa, qb, qc, opacity): table row r of the flush
+    // is list entry seg_lo + r, i.e. exactly lane r's record here -- no second trip list -> record at the end of the chain
+    const float4 keep_a = pa;
+    const float keep_qc = pb.x, keep_op = pb.y;
+    for (int q = threadIdx.x; q < (GSR_Q2_ROW << seg_shift); q += 256) acc64[q] = 0ull;
+    for (int q = threadIdx.x; q < 4 * 4 * GSR_QL_PITCH / 4; q += 256) reinterpret_cast<uint32_t*>(&qlist[0][0][0])[q] = 0u;   // stale reads stay inside the stage
     float4* __restrict__ sa = stage[wave][0];
     float4* __restrict__ sb = stage[wave][1];
     float4* __restrict__ sc = stage[wave][2];
     const uint8_t* __restrict__ ql = qlist[wave][row];
 
-    float T_final = 1.f, gC0 = 0.f, gC1 = 0.f, gC2 = 0.f, gD = 0.f, gA = 0.f, Cg_total = 0.f;
-    uint32_t last_contrib = 0;
-    // the segment's checkpoint: requested here, with the other per-pixel loads, not behind the two barriers below (a workgroup is a
-    // latency chain and only four of them fit a CU: every dependent load taken out of the chain is kernel time)
-    float ck0 = 1.f, ck1 = 0.f, ck2 = 0.f, ck3 = 0.f, ck4 = 0.f, ck5 = 0.f;
-    if (seg > 0) {
-        const float* c = ckpt + (size_t)(tile_seg[tg] + seg - 1u) * GSR_CKPT_FLOATS + cidx;
-        ck0 = c[0]; ck1 = c[256]; ck2 = c[512]; ck3 = c[768]; ck4 = c[1024]; ck5 = c[1280];
-    }
-    unsigned long long km0 = 0ull, km1 = 0ull, km2 = 0ull, km3 = 0ull;     // ... and the first round's quad masks
-    if (have_masks) {
-        const unsigned long long* __restrict__ mp = reinterpret_cast<const unsigned long long*>(ckpt + ((size_t)tile_seg[tg] + seg) * GSR_CKPT_FLOATS + GSR_REC_HINT)
-                                                    + (uint32_t)wave * 4u;
-        km0 = mp[0]; km1 = mp[1]; km2 = mp[2]; km3 = mp[3];
-    }
-    if (inside) {
-        const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
-        T_final = final_T[pix];
-        last_contrib = n_contrib[pix];
-        gC0 = dL_dcolor[pix]; gC1 = dL_dcolor[HW + pix]; gC2 = dL_dcolor[2 * HW + pix];
-        gD = dL_ddepth[pix]; gA = dL_dalpha[pix];
-        Cg_total = totals[pix] * gC0 + totals[HW + pix] * gC1 + totals[2 * HW + pix] * gC2
-                 + totals[3 * HW + pix] * gD + totals[4 * HW + pix] * gA;
-    }
+    // a pixel outside the image: transmittance 1, no contributor, zero incoming gradients
+    const float T_final = inside ? l_T : 1.f;
+    const uint32_t last_contrib = inside ? l_last : 0u;
+    const float gC0 = inside ? l_g0 : 0.f, gC1 = inside ? l_g1 : 0.f, gC2 = inside ? l_g2 : 0.f, gD = inside ? l_gD : 0.f, gA = inside ? l_gA : 0.f;
+    const float Cg_total = inside ? l_t0 * gC0 + l_t1 * gC1 + l_t2 * gC2 + l_t3 * gD + l_t4 * gA : 0.f;
+    const float ck0 = seg > 0u ? l_c0 : 1.f, ck1 = l_c1, ck2 = l_c2, ck3 = l_c3, ck4 = l_c4, ck5 = l_c5;    // (ck1..5 only read when seg > 0)
     float4* __restrict__ gtab = reinterpret_cast<float4*>(&mw[wave][0][0]);   // per-wave, read once below, then the space is pass 1's
     gtab[lane] = make_float4(gC0, gC1, gC2, gD);          // pass 2 reads other lanes' pixels
     {
@@ -1020,12 +1040,12 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
         const uint32_t i = pos0 + lane;
         bool h0 = false, h1 = false, h2q = false, h3 = false;
         const float4 ra = pa, rb = pb, rc = pc;
-        if (i + GSR_RB < seg_hi) {                        // next round's records: in flight during this round
-            const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + ids[start + i + GSR_RB]);
+        if (pos0 + GSR_RB < seg_hi) {                     // (wave-uniform) next round's records: in flight during this round; entries past the end repeat the last one
+            const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + ids[start + min(i + GSR_RB, seg_end - 1u)]);
             pa = p[0]; pb = p[1]; pc = p[2];
         }
         if (have_masks) {   // the forward's serial walk left the round's four quad masks: the same tests, already made
-            const unsigned long long* __restrict__ mp = reinterpret_cast<const unsigned long long*>(ckpt + ((size_t)tile_seg[tg] + seg) * GSR_CKPT_FLOATS + GSR_REC_HINT)
+            const unsigned long long* __restrict__ mp = reinterpret_cast<const unsigned long long*>(ckpt + (size_t)rec_idx * GSR_CKPT_FLOATS + GSR_REC_HINT)
                                                         + (((pos0 >> 6) & ((1u << (seg_shift - 6)) - 1u)) * 16u + (uint32_t)wave * 4u);
             unsigned long long k0 = km0, k1 = km1, k2 = km2, k3 = km3;       // first round: requested at the top of the kernel
             if (pos0 != seg_lo) { k0 = mp[0]; k1 = mp[1]; k2 = mp[2]; k3 = mp[3]; }
@@ -1122,7 +1142,6 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
 #undef GSR_Q2_ENTRY
     // ---- flush: fixed point -> float, raw moments -> the accumulator layout K6 reads, coalesced global atomics
     __syncthreads();
-    const uint32_t len = min(1u << seg_shift, n - seg_lo);
     float out[GSR_G2D_STRIDE];
     uint32_t gid = 0;
     bool any = false;
