@@ -182,7 +182,7 @@ gsr_scatter(int N, const EmitRec* __restrict__ emit, const uint32_t* __restrict_
         // learns everything about its item from ONE scalar load instead of a chain of five dependent ones.
         __shared__ uint32_t lev[GSR_NLEV + 1];
         for (int i = threadIdx.x; i <= GSR_NLEV; i += 256) lev[i] = level_off[i];
-        __syncthreads();
+        lds_barrier();
         const uint32_t total = min(lev[GSR_NLEV], items_cap);
         const uint32_t nthreads = gridDim.x * gridDim.y * 256u, gid = (blockIdx.y * gridDim.x + blockIdx.x) * 256u + threadIdx.x;
         for (uint32_t k = gid; k < total; k += nthreads) {
@@ -229,7 +229,7 @@ gsr_scatter(int N, const EmitRec* __restrict__ emit, const uint32_t* __restrict_
             em[r] = idx < N ? reinterpret_cast<const uint4*>(emit)[idx] : make_uint4(0u, 0u, 0u, 0u);     // all-zero = empty rectangle
         }
         for (int t = threadIdx.x; t < nTiles; t += 256) hist[t] = 0;
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int r = 0; r < GSR_SC_R; ++r) {
             const int x0 = em[r].x & 0xffff, x1 = em[r].x >> 16, y0 = em[r].y & 0xffff, y1 = em[r].y >> 16;
@@ -239,14 +239,14 @@ gsr_scatter(int N, const EmitRec* __restrict__ emit, const uint32_t* __restrict_
                 for (int tx = x0; tx < x1; ++tx, bit <<= 1)
                     if (!masked || (em[r].w & bit)) atomicAdd(&hist[ty * gx + tx], 1u);
         }
-        __syncthreads();
+        lds_barrier();
         const int t0 = (int)((blockIdx.x * 67u) % (unsigned)nTiles);   // staggered: see K1's flush
         for (int i = threadIdx.x; i < nTiles; i += 256) {
             int t = t0 + i; if (t >= nTiles) t -= nTiles;
             const uint32_t c = hist[t];
             hist[t] = c ? (tile_off[t] + atomicAdd(&cursor[t], c)) : 0u;
         }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int r = 0; r < GSR_SC_R; ++r) {
             const int x0 = em[r].x & 0xffff, x1 = em[r].x >> 16, y0 = em[r].y & 0xffff, y1 = em[r].y >> 16;
@@ -260,7 +260,7 @@ gsr_scatter(int N, const EmitRec* __restrict__ emit, const uint32_t* __restrict_
                     if (pos < capacity) entries[pos] = key;
                 }
         }
-        __syncthreads();                                  // the histogram is zeroed again by the next round
+        lds_barrier();                                  // the histogram is zeroed again by the next round
     }
 }
 

@@ -185,6 +185,15 @@ __device__ __forceinline__ void wave_lds_handoff() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Workgroup barrier for data exchanged through LDS ONLY: __syncthreads() is a fence over every address space, and the release half
+// makes a wave wait for its outstanding GLOBAL stores (s_waitcnt vmcnt(0)) in front of the barrier -- a memory round trip in the
+// chain wherever results have just been stored. This one orders LDS alone.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {

@@ -585,27 +585,31 @@ __device__ __forceinline__ const void* uniform_ptr(const void* p) {
     return (const void*)(((unsigned long long)hi << 32) | lo);
 }
 struct K6Out { float dm[3], dm2[2], dop, dsc[3], dq[4], dcov[6], dcol[3], dsh[3]; };
+// What k6_gaussian reads of a Gaussian, requested by the caller at the top of the batch (branch-free, in flight while the SH
+// rows are staged): the camera-independent inputs ...
+struct K6In { float mx, my, mz, op; float4 q; float sx, sy, sz; };
+// ... and the per-view ones: the 2D gradients render_bwd accumulated (three 16-byte loads) and K1's colour-clamp bits
+struct K6ViewIn { float4 g0, g1, g2; uint32_t flags; };
 template <bool RAW>
-__device__ __forceinline__ void k6_gaussian(const ViewConst& vc, int idx, int N, int K, bool live,
-                                            const float* __restrict__ means3D, const float* __restrict__ shs,
-                                            const float* __restrict__ opacities, const float* __restrict__ scales,
-                                            const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
-                                            const uint8_t* __restrict__ flags8, const float* __restrict__ g2d,
+__device__ __forceinline__ void k6_gaussian(const ViewConst& vc, const float* cam /* LDS: view[16] | proj[16] | campos[3] */, int idx, int N, int K, bool live,
+                                            const K6In& in, const K6ViewIn& vin, const float* __restrict__ shs,
+                                            const float* __restrict__ cov3D_precomp,
                                             float* __restrict__ dL_dshs, bool stage, float* myrow, int accumulate,
                                             bool sh_reg /* K == 1, several views per launch: dL/dSH of this view goes to out.dsh */, K6Out& out) {
     const int rowlen = 3 * K;
     const bool use_sh = (shs != nullptr);
-    const float* __restrict__ V = vc.view;
-    const float* __restrict__ P = vc.proj;
+    const float* V = cam;
+    const float* P = cam + 16;
+    const float* campos = cam + 32;
+    const float g[12] = {vin.g0.x, vin.g0.y, vin.g0.z, vin.g0.w, vin.g1.x, vin.g1.y, vin.g1.z, vin.g1.w, vin.g2.x, vin.g2.y, vin.g2.z, vin.g2.w};
     out.dm[0] = out.dm[1] = out.dm[2] = 0.f; out.dm2[0] = out.dm2[1] = 0.f; out.dop = 0.f; out.dsc[0] = out.dsc[1] = out.dsc[2] = 0.f; out.dq[0] = out.dq[1] = out.dq[2] = out.dq[3] = 0.f;
 #pragma unroll
     for (int e = 0; e < 6; ++e) out.dcov[e] = 0.f;
     out.dcol[0] = out.dcol[1] = out.dcol[2] = 0.f;
     out.dsh[0] = out.dsh[1] = out.dsh[2] = 0.f;
     if (live) {
-        const float* g = g2d + (size_t)idx * GSR_G2D_STRIDE;
-        const uint32_t flags = flags8[idx];
-        const float mx = means3D[3 * idx], my = means3D[3 * idx + 1], mz = means3D[3 * idx + 2];
+        const uint32_t flags = vin.flags;
+        const float mx = in.mx, my = in.my, mz = in.mz;
         float3 pv;
         pv.x = V[0] * mx + V[4] * my + V[8] * mz + V[12];
         pv.y = V[1] * mx + V[5] * my + V[9] * mz + V[13];
@@ -628,7 +632,7 @@ __device__ __forceinline__ void k6_gaussian(const ViewConst& vc, int idx, int N,
         out.dm[0] += V[2] * gdepth; out.dm[1] += V[6] * gdepth; out.dm[2] += V[10] * gdepth;
         // ---- opacity ----------------------------------------------------------------
         out.dop = g[5];
-        if (RAW) { const float o = act_sigmoid(opacities[idx]); out.dop *= o * (1.f - o); }   // d sigmoid
+        if (RAW) { const float o = act_sigmoid(in.op); out.dop *= o * (1.f - o); }   // d sigmoid
 
         // ---- colour -----------------------------------------------------------------
         float gr = g[6], gg = g[7], gb = g[8];
@@ -638,7 +642,7 @@ __device__ __forceinline__ void k6_gaussian(const ViewConst& vc, int idx, int N,
             if (flags & 1u) gr = 0.f;
             if (flags & 2u) gg = 0.f;
             if (flags & 4u) gb = 0.f;
-            float dx = mx - vc.campos[0], dy = my - vc.campos[1], dz = mz - vc.campos[2];
+            float dx = mx - campos[0], dy = my - campos[1], dz = mz - campos[2];
             const float len2 = dx * dx + dy * dy + dz * dz;
             const float inv = 1.f / sqrtf(len2);
             const float x = dx * inv, y = dy * inv, z = dz * inv;
@@ -702,8 +706,8 @@ __device__ __forceinline__ void k6_gaussian(const ViewConst& vc, int idx, int N,
             const float* c = cov3D_precomp + 6 * (size_t)idx;
             S.c0 = c[0]; S.c1 = c[1]; S.c2 = c[2]; S.c3 = c[3]; S.c4 = c[4]; S.c5 = c[5];
         } else {
-            q = reinterpret_cast<const float4*>(rotations)[idx];
-            s.x = scales[3 * idx]; s.y = scales[3 * idx + 1]; s.z = scales[3 * idx + 2];
+            q = in.q;
+            s.x = in.sx; s.y = in.sy; s.z = in.sz;
             if (RAW) { q = act_normalize(q, &q_inv_norm); s.x = __expf(s.x); s.y = __expf(s.y); s.z = __expf(s.z); }
             s_act = s;
             s.x *= vc.scale_modifier; s.y *= vc.scale_modifier; s.z *= vc.scale_modifier;
@@ -819,22 +823,51 @@ gsr_preprocess_bwd(ViewTab tab, int first_view, int B /* B == 1: the view tab.v[
     // accumulates B separate calls) in the same order, so the sums are bit-identical to them, without B - 1 read-modify-write
     // passes over the gradients. The cameras go from the by-value table to LDS (they are indexed with a run-time view number).
     __shared__ ViewConst sv[MULTI ? GSR_MAX_VIEWS : 1];
+    // The cameras' matrices sit in LDS (view[16] | proj[16] | campos[3] per view): read through their device pointers they come
+    // back as vector-memory loads, each with a wait for memory right behind it in the middle of the arithmetic.
+    __shared__ __attribute__((aligned(16))) float camf[MULTI ? GSR_MAX_VIEWS : 1][36];
     if (MULTI) {
         if (threadIdx.x == 0) {
 #pragma unroll
             for (int v = 0; v < GSR_MAX_VIEWS; ++v) sv[MULTI ? v : 0] = tab.v[v];
         }
-        __syncthreads();
     }
+    for (int e = threadIdx.x; e < 36 * (MULTI ? B : 1); e += blockDim.x) {
+        const int v = e / 36, c = e - v * 36;
+        const ViewConst& cv = tab.v[MULTI ? first_view + v : 0];
+        if (c < 35) camf[MULTI ? v : 0][c] = c < 16 ? cv.view[c] : (c < 32 ? cv.proj[c - 16] : cv.campos[c - 32]);
+    }
+    lds_barrier();
     for (int base = blockIdx.x * blockDim.x; base < N; base += gridDim.x * blockDim.x) {
         const int cnt = min((int)blockDim.x, N - base);
+        const int idx = base + threadIdx.x;
+        // this batch's per-Gaussian inputs: requested first, branch-free (index clamped), in flight while the SH rows are staged
+        const size_t ic = (size_t)min(idx, N - 1);
+        K6In in;
+        {
+            in.mx = means3D[3 * ic]; in.my = means3D[3 * ic + 1]; in.mz = means3D[3 * ic + 2];
+            in.op = opacities[ic];
+            in.q = make_float4(1.f, 0.f, 0.f, 0.f); in.sx = in.sy = in.sz = 0.f;
+            if (!cov3D_precomp) {                         // (uniform)
+                in.q = reinterpret_cast<const float4*>(rotations)[ic];
+                in.sx = scales[3 * ic]; in.sy = scales[3 * ic + 1]; in.sz = scales[3 * ic + 2];
+            }
+        }
+        K6ViewIn vin0;
+        int32_t radius0;
+        {
+            const size_t r0 = (size_t)(MULTI ? first_view + B - 1 : 0) * N + ic;     // the first view of the loop below
+            radius0 = radii[r0];
+            vin0.flags = flags8[r0];
+            const float4* gp = reinterpret_cast<const float4*>(g2d + r0 * GSR_G2D_STRIDE);
+            vin0.g0 = gp[0]; vin0.g1 = gp[1]; vin0.g2 = gp[2];
+        }
         if (stage) {
-            __syncthreads();
+            lds_barrier();
             if (shs_rest) stage_rows_in_split(shs + (size_t)base * 3, shs_rest + (size_t)base * (rowlen - 3), shbuf, cnt, rowlen);
             else stage_rows_in(shs + (size_t)base * rowlen, shbuf, cnt, rowlen);
-            __syncthreads();
+            lds_barrier();
         }
-        const int idx = base + threadIdx.x;
         K6Out out, cur;
         float tsh[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -847,19 +880,25 @@ gsr_preprocess_bwd(ViewTab tab, int first_view, int B /* B == 1: the view tab.v[
         float* myrow = shbuf + threadIdx.x * (rowlen + 1);
         const bool sh_in_regs = MULTI;                    // (then K == 1: three numbers per view)
         for (int v = MULTI ? first_view + B - 1 : 0; v >= (MULTI ? first_view : 0); --v) {
-            // one view per launch (the common case): the camera stays a kernel argument = scalar registers, its matrices are read
-            // with scalar loads; several: from LDS, made wave-uniform again lane 0's copy
+            // one view per launch (the common case): the camera stays a kernel argument = scalar registers; several: from LDS,
+            // made wave-uniform again from lane 0's copy
             ViewConst vc = tab.v[0];
+            K6ViewIn vin = vin0;
+            int32_t radius = radius0;
             if (MULTI) {
                 vc = sv[MULTI ? v : 0];
-                vc.view = reinterpret_cast<const float*>(uniform_ptr(vc.view)); vc.proj = reinterpret_cast<const float*>(uniform_ptr(vc.proj));
-                vc.campos = reinterpret_cast<const float*>(uniform_ptr(vc.campos));
                 vc.W = __builtin_amdgcn_readfirstlane(vc.W); vc.H = __builtin_amdgcn_readfirstlane(vc.H);
                 vc.sh_degree = __builtin_amdgcn_readfirstlane(vc.sh_degree);
+                if (v != first_view + B - 1) {            // (uniform) the views after the first of the loop
+                    const size_t r = (size_t)v * N + ic;
+                    radius = radii[r];
+                    vin.flags = flags8[r];
+                    const float4* gp = reinterpret_cast<const float4*>(g2d + r * GSR_G2D_STRIDE);
+                    vin.g0 = gp[0]; vin.g1 = gp[1]; vin.g2 = gp[2];
+                }
             }
-            const bool live = (idx < N) && (radii[(size_t)v * N + idx] > 0);
-            k6_gaussian<RAW>(vc, idx, N, K, live, means3D, shs, opacities, scales, rotations, cov3D_precomp, flags8 + (size_t)v * N,
-                             g2d + (size_t)v * N * GSR_G2D_STRIDE, dL_dshs, stage, myrow, accumulate, sh_in_regs, cur);
+            const bool live = (idx < N) && (radius > 0);
+            k6_gaussian<RAW>(vc, camf[MULTI ? v - first_view : 0], idx, N, K, live, in, vin, shs, cov3D_precomp, dL_dshs, stage, myrow, accumulate, sh_in_regs, cur);
             if (idx < N) { float* m2 = dL_dmeans2D + ((size_t)v * N + idx) * 3; m2[0] = cur.dm2[0]; m2[1] = cur.dm2[1]; m2[2] = 0.f; }
             // first pass (the last view): 0 + x = x exactly
 #pragma unroll
@@ -895,7 +934,7 @@ gsr_preprocess_bwd(ViewTab tab, int first_view, int B /* B == 1: the view tab.v[
             if (dL_drots) reinterpret_cast<float4*>(dL_drots)[idx] = make_float4(out.dq[0], out.dq[1], out.dq[2], out.dq[3]);
         }
         if (stage) {
-            __syncthreads();
+            lds_barrier();
             if (shs_rest) stage_rows_out_split(dL_dshs + (size_t)base * 3, dL_dshs_rest + (size_t)base * (rowlen - 3), shbuf, cnt, rowlen, accumulate);
             else stage_rows_out(dL_dshs + (size_t)base * rowlen, shbuf, cnt, rowlen, accumulate);
         }

@@ -487,7 +487,7 @@ gsr_render_fwd_serial(const uint32_t* __restrict__ tile_off, const SplatRec* __r
         const uint32_t wmax = wave_max_u32(inside ? last : 0u);
         if (lane == 0) wl[wave] = wmax;
     }
-    __syncthreads();
+    lds_barrier();
     if (threadIdx.x == 0) {
         const uint32_t tl = max(max(wl[0], wl[1]), max(wl[2], wl[3]));
         const uint32_t segs = (tl + (1u << seg_shift) - 1u) >> seg_shift;
@@ -496,7 +496,7 @@ gsr_render_fwd_serial(const uint32_t* __restrict__ tile_off, const SplatRec* __r
         plan_base = base;
         wl[0] = segs;
     }
-    __syncthreads();
+    lds_barrier();
     {
         const uint32_t segs = wl[0], base = plan_base;
         for (uint32_t q = threadIdx.x; q < segs; q += 256)
@@ -695,7 +695,7 @@ gsr_render_fwd_combine(const uint32_t* __restrict__ tile_off, const SplatRec* __
         const uint32_t wmax = wave_max_u32(inside ? last_abs : 0u);
         if (lane == 0) { wl[wave] = wmax; wcnt[wave] = nwalk; }
     }
-    __syncthreads();
+    lds_barrier();
     if (threadIdx.x == 0) {
         const uint32_t tl = max(max(wl[0], wl[1]), max(wl[2], wl[3]));
         const uint32_t segs = (tl + (1u << seg_shift) - 1u) >> seg_shift;
@@ -706,7 +706,7 @@ gsr_render_fwd_combine(const uint32_t* __restrict__ tile_off, const SplatRec* __
         const uint32_t nw = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
         walk_base = nw ? (uint32_t)atomicAdd(walk_total, (unsigned long long)nw) : 0u;
     }
-    __syncthreads();
+    lds_barrier();
     {
         const uint32_t segs = wl[0], base = plan_base;
         for (uint32_t q = threadIdx.x; q < segs; q += 256)
@@ -982,7 +982,7 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
         const uint32_t wm = wave_max_u32(__float_as_uint(gsum));          // non-negative floats order like their bits
         if (lane == 0) gmax_w[wave] = wm;
     }
-    __syncthreads();
+    lds_barrier();
     const uint32_t gmax_bits = max(max(gmax_w[0], gmax_w[1]), max(gmax_w[2], gmax_w[3]));   // (one barrier covers the zeroing above and these)
     const bool poisoned = gmax_bits >= 0x7f800000u;       // an infinite or NaN incoming gradient somewhere in the tile
     const float gmax = poisoned ? 1.f : __uint_as_float(gmax_bits);
@@ -1141,7 +1141,7 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
     }
 #undef GSR_Q2_ENTRY
     // ---- flush: fixed point -> float, raw moments -> the accumulator layout K6 reads, coalesced global atomics
-    __syncthreads();
+    lds_barrier();
     float out[GSR_G2D_STRIDE];
     uint32_t gid = 0;
     bool any = false;
@@ -1185,7 +1185,7 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
 #pragma unroll
         for (int q = 0; q < GSR_G2D_STRIDE; ++q) accf[threadIdx.x * GSR_G2D_STRIDE + q] = any ? out[q] : 0.f;
     }
-    __syncthreads();
+    lds_barrier();
     // consecutive threads = consecutive slots of consecutive list positions
     for (uint32_t e = threadIdx.x; e < len * GSR_G2D_STRIDE; e += 256) {
         const float v = accf[e];
