@@ -224,10 +224,11 @@ gsr_scatter(int N, const EmitRec* __restrict__ emit, const uint32_t* __restrict_
         const int base = round0 + blockIdx.x * 256 + threadIdx.x;
         uint4 em[GSR_SC_R];
 #pragma unroll
-        for (int r = 0; r < GSR_SC_R; ++r) {
-            const int idx = base + r * stride;
-            em[r] = idx < N ? reinterpret_cast<const uint4*>(emit)[idx] : make_uint4(0u, 0u, 0u, 0u);     // all-zero = empty rectangle
-        }
+        for (int r = 0; r < GSR_SC_R; ++r)     // branch-free (index clamped): a load inside a divergent `if` is waited for on the spot
+            em[r] = reinterpret_cast<const uint4*>(emit)[min(base + r * stride, N - 1)];
+#pragma unroll
+        for (int r = 0; r < GSR_SC_R; ++r)
+            if (base + r * stride >= N) em[r] = make_uint4(0u, 0u, 0u, 0u);                                // all-zero = empty rectangle
         for (int t = threadIdx.x; t < nTiles; t += 256) hist[t] = 0;
         lds_barrier();
 #pragma unroll
@@ -241,10 +242,21 @@ gsr_scatter(int N, const EmitRec* __restrict__ emit, const uint32_t* __restrict_
         }
         lds_barrier();
         const int t0 = (int)((blockIdx.x * 67u) % (unsigned)nTiles);   // staggered: see K1's flush
-        for (int i = threadIdx.x; i < nTiles; i += 256) {
-            int t = t0 + i; if (t >= nTiles) t -= nTiles;
-            const uint32_t c = hist[t];
-            hist[t] = c ? (tile_off[t] + atomicAdd(&cursor[t], c)) : 0u;
+        // one range per tile this workgroup emits into: four reservations (atomics WITH return) in flight per thread, not one
+        for (int i0 = threadIdx.x; i0 < nTiles; i0 += 256 * 4) {
+            int tt[4]; uint32_t cc[4], off4[4], got[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = min(i0 + 256 * u, nTiles - 1);
+                int t = t0 + i; if (t >= nTiles) t -= nTiles;
+                tt[u] = t;
+                cc[u] = i0 + 256 * u < nTiles ? hist[t] : 0u;
+                off4[u] = tile_off[t];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { got[u] = 0u; if (cc[u]) got[u] = atomicAdd(&cursor[tt[u]], cc[u]); }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (i0 + 256 * u < nTiles) hist[tt[u]] = cc[u] ? off4[u] + got[u] : 0u;
         }
         lds_barrier();
 #pragma unroll

@@ -975,6 +975,9 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
     const float gC0 = inside ? l_g0 : 0.f, gC1 = inside ? l_g1 : 0.f, gC2 = inside ? l_g2 : 0.f, gD = inside ? l_gD : 0.f, gA = inside ? l_gA : 0.f;
     const float Cg_total = inside ? l_t0 * gC0 + l_t1 * gC1 + l_t2 * gC2 + l_t3 * gD + l_t4 * gA : 0.f;
     const float ck0 = seg > 0u ? l_c0 : 1.f, ck1 = l_c1, ck2 = l_c2, ck3 = l_c3, ck4 = l_c4, ck5 = l_c5;    // (ck1..5 only read when seg > 0)
+    // (scalar loads: requested in front of the barrier, not behind it)
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+    const float cmax = fmaxf(fmaxf(__uint_as_float((uint32_t)plan_total[1]), 1.f), fmaxf(fabsf(bg0), fmaxf(fabsf(bg1), fabsf(bg2))));
     float4* __restrict__ gtab = reinterpret_cast<float4*>(&mw[wave][0][0]);   // per-wave, read once below, then the space is pass 1's
     gtab[lane] = make_float4(gC0, gC1, gC2, gD);          // pass 2 reads other lanes' pixels
     {
@@ -987,7 +990,6 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
     const bool poisoned = gmax_bits >= 0x7f800000u;       // an infinite or NaN incoming gradient somewhere in the tile
     const float gmax = poisoned ? 1.f : __uint_as_float(gmax_bits);
     if (!(gmax > 0.f)) return;                            // block-uniform: a zero incoming gradient adds nothing anywhere
-    const float cmax = fmaxf(fmaxf(__uint_as_float((uint32_t)plan_total[1]), 1.f), fmaxf(fabsf(bg[0]), fmaxf(fabsf(bg[1]), fabsf(bg[2]))));
     const int e0 = 60 - __builtin_amdgcn_frexp_expf(25856.f * cmax * gmax);     // 2^e0 * (256 * 101 * cmax * gmax) < 2^60
     const float tcx = (float)tx0 + 7.5f, tcy = (float)ty0 + 7.5f;
     // deepest contributor of each quad (list positions are < 2^24: exact as floats) and of the wave
@@ -997,7 +999,7 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
     const uint32_t wave_last = max(max(ql0, ql1), max(ql2, ql3));
     active = active && (wave_last > seg_lo);
     const uint32_t seg_hi = active ? min(seg_lo + (1u << seg_shift), wave_last) : seg_lo;
-    const float Cg_behind0 = Cg_total + T_final * (bg[0] * gC0 + bg[1] * gC1 + bg[2] * gC2);
+    const float Cg_behind0 = Cg_total + T_final * (bg0 * gC0 + bg1 * gC1 + bg2 * gC2);
 
     const float T_in = ck0;
     float T = T_in, Cgf = 0.f;
