@@ -440,3 +440,18 @@ def test_stage1_trained_gaussians_match_oracle(gpu, golden_dir, size, el, az):
     assert_forward_close(ho, oo, aux)
     _, og32, _ = run_oracle(sc, S, w, torch.float32)       # near-opaque Gaussians: see assert_grads_close(og32=)
     assert_grads_close(hg, og, aux, floors=grad_floors(sc, og), og32=og32)
+
+
+def test_scatter_with_several_rounds_per_workgroup(gpu):
+    """gsr_scatter keeps eight emission records per thread in registers and loops when a workgroup's share is larger
+    (more than 8 x 256 x grid Gaussians: beyond 1M at the default grid of 512). The grid is read once per process
+    (GSR_SCATTER_GRID), so the oracle comparisons with 3 000 - 20 000 Gaussians run again in a child process with a grid of
+    ONE workgroup: 2 - 10 rounds, the tile histogram re-zeroed and the list cursors carried from round to round."""
+    import subprocess
+    import sys
+    env = dict(os.environ, GSR_SCATTER_GRID="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "full_size_subsample or backward_without_forward_stats or speculative_forward"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-1000:]
