@@ -148,7 +148,7 @@ BinLayout bin_layout(size_t M, int nTiles, int shift) {
     L.ckpt = o; o += align_up((L.items + 3) * (size_t)GSR_CKPT_FLOATS * 4);   // + 3 spare records: the store sink of the serial walk (gsr_render.hip)
     // backward work list: sum over tiles of ceil(last_t / 2^shift) <= the same bound
     L.plan_cap = L.items + 1;
-    L.plan_tile = o; o += align_up(L.plan_cap * 16);      // 16-byte (tile, segment, list start, list length) items
+    L.plan_tile = o; o += align_up(L.plan_cap * 16);      // 16-byte work items of the backward: (tile, the segment's record, list start, segment | (entries - 1) << 24)
     L.item_recs = o; o += align_up(L.items * 16);        // the forward's work items (written by gsr_scatter)
     L.walk_items = o; o += align_up(L.items * 4 * 8);    // (tile, block, segment) items of the fix-up kernel: <= one per block and segment
     L.total = o < 256 ? 256 : o;
@@ -477,14 +477,14 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
             vs.view_mask = mask_q;
             hipLaunchKernelGGL(gsr_render_fwd_serial<true>, dim3(TA), dim3(256), 0, stream, tile_off, recs, sorted_ids, W, H, vc.gx,
                                out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, order, shift,
-                               plan_off, plan_tile, counters + 4, (uint32_t)BL.plan_cap, (unsigned long long)mask_q, (uint32_t)BL.items /* the spare record: store sink */,
+                               plan_off, plan_tile, counters + 4, (uint32_t)BL.plan_cap, (unsigned long long)mask_q, (uint32_t)BL.items /* the first of the three spare records: store sink */,
                                counters, (uint32_t)M, maxc_cap, vs);
         }
         if (mask_q != mask_all) {
             vs.view_mask = mask_all & ~mask_q;
             hipLaunchKernelGGL(gsr_render_fwd_serial<false>, dim3(TA), dim3(256), 0, stream, tile_off, recs, sorted_ids, W, H, vc.gx,
                                out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, order, shift,
-                               plan_off, plan_tile, counters + 4, (uint32_t)BL.plan_cap, (unsigned long long)mask_q, (uint32_t)BL.items /* the spare record: store sink */,
+                               plan_off, plan_tile, counters + 4, (uint32_t)BL.plan_cap, (unsigned long long)mask_q, (uint32_t)BL.items /* the first of the three spare records: store sink */,
                                counters, (uint32_t)M, maxc_cap, vs);
         }
         LAUNCH_CHECK(view, stream, "render_fwd");
