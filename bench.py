@@ -73,10 +73,21 @@ def kernel_family(name: str) -> str:
     return "render_fwd" if name in ("render_combine", "render_fix") else name
 
 
-def build_inputs(wl, kind, dev, azimuth):
+def apply_order(sc, order):
+    """`--order morton`: the scene's rows permuted along a Z-order curve (dreamgaussian_amd.morton_order) -- the same
+    Gaussians in another order. Used by BOTH step kinds (round 3 applied it in run_sds only and still stamped
+    "order": "morton" into the render line: those lines measured the given order)."""
+    if order != "morton":
+        return sc
+    import dreamgaussian_amd as D
+    perm = D.morton_order(sc["means3D"]).long()
+    return {k: v[perm].contiguous() for k, v in sc.items()}
+
+
+def build_inputs(wl, kind, dev, azimuth, order="given"):
     from dreamgaussian_amd import synthetic as syn
     import dreamgaussian_amd as D
-    sc = syn.make_scene(wl["N"], wl["deg"], 0, kind)
+    sc = apply_order(syn.make_scene(wl["N"], wl["deg"], 0, kind), order)
     rs_cpu = syn.make_settings(syn.orbit_pose(0.0, azimuth, 2.0), wl["W"], wl["H"], sh_degree=wl["deg"])
     rs = D.GaussianRasterizationSettings(*[x.to(dev) if torch.is_tensor(x) else x for x in rs_cpu])
     g = torch.Generator().manual_seed(1)
@@ -174,10 +185,7 @@ def run_sds(a, dev, rank, world):
     from dreamgaussian_amd import views
     wl = WORKLOADS["250k-512-sh0"]
     azimuth = 360.0 * rank / max(world, 1)
-    sc, _, rs, _ = build_inputs(wl, a.kind, dev, azimuth)
-    if a.order == "morton":
-        perm = D.morton_order(sc["means3D"]).long()
-        sc = {k: v[perm].contiguous() for k, v in sc.items()}
+    sc, _, rs, _ = build_inputs(wl, a.kind, dev, azimuth, a.order)
     t = {k: v.to(dev).requires_grad_(True) for k, v in sc.items()}
     m2d = torch.zeros(wl["N"], 3, device=dev, requires_grad=True)
     rast = D.GaussianRasterizer(raster_settings=rs)
@@ -302,7 +310,7 @@ def main():
     wl = WORKLOADS[a.workload]
     K = (wl["deg"] + 1) ** 2
     azimuth = 360.0 * rank / max(world, 1)          # rank r renders orbit view r
-    sc, rs_cpu, rs, grads_cpu = build_inputs(wl, a.kind, dev, azimuth)
+    sc, rs_cpu, rs, grads_cpu = build_inputs(wl, a.kind, dev, azimuth, a.order)
     t = {k: v.to(dev).requires_grad_(True) for k, v in sc.items()}
     m2d = torch.zeros(wl["N"], 3, device=dev, requires_grad=True)
     gout = [g.to(dev) for g in grads_cpu]

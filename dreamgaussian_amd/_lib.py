@@ -13,7 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSR_LIB") or os.path.join(_HERE, "libgsr.so")
 
 GSR_MAX_VIEWS = 16      # include/gsr.h
-GSR_ABI_VERSION = 3     # include/gsr.h
+GSR_ABI_VERSION = 4     # include/gsr.h
+GSR_VIEW_VIEWMATRIX_T, GSR_VIEW_PROJMATRIX_T, GSR_VIEW_NO_BACKWARD = 1, 2, 4   # GsrView.flags
 
 EXPORTS = ("gsr_forward", "gsr_backward", "gsr_forward_views", "gsr_backward_views", "gsr_mark_visible", "gsr_dist2", "gsr_extract_fields", "gsr_densify_stats",
            "gsr_adam_step", "gsr_mask_compact", "gsr_gather_rows", "gsr_concat_rows",
@@ -28,7 +29,7 @@ class GsrView(C.Structure):
                 ("prefiltered", C.c_int32), ("debug", C.c_int32),
                 ("bg", C.c_void_p), ("viewmatrix", C.c_void_p),
                 ("projmatrix", C.c_void_p), ("campos", C.c_void_p),
-                ("raw_activations", C.c_int32), ("reserved", C.c_int32),
+                ("raw_activations", C.c_int32), ("flags", C.c_int32),
                 ("shs_rest", C.c_void_p), ("dL_dshs_rest", C.c_void_p)]
 
 
@@ -55,7 +56,7 @@ class GsrConcatTensor(C.Structure):
 class GsrStats(C.Structure):
     _fields_ = [("num_instances", C.c_int64), ("num_instances_ref", C.c_int64),
                 ("num_visible", C.c_int64), ("max_tile_count", C.c_int64), ("bin_capacity", C.c_int64),
-                ("seg_shift", C.c_int64)]
+                ("seg_shift", C.c_int64), ("bwd_prepared", C.c_int64)]
 
 
 _lock = threading.Lock()
@@ -76,9 +77,13 @@ def load() -> C.CDLL:
                 "`python -m dreamgaussian_amd.build` (or __graft_entry__.build()); there is no "
                 "CPU fallback for the rasterizer.")
         lib = C.CDLL(LIB_PATH)
-        lib.gsr_abi_version.restype = C.c_int
-        if lib.gsr_abi_version() != GSR_ABI_VERSION:
-            raise RuntimeError(f"{LIB_PATH} reports ABI version {lib.gsr_abi_version()}, this binding is written for "
+        try:                                              # (a library older than the version check does not export the symbol)
+            lib.gsr_abi_version.restype = C.c_int
+            found = lib.gsr_abi_version()
+        except AttributeError:
+            found = None
+        if found != GSR_ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} reports ABI version {found}, this binding is written for "
                                f"{GSR_ABI_VERSION} (include/gsr.h): rebuild with `python -m dreamgaussian_amd.build`")
         p, i32, vp = C.c_void_p, C.c_int32, C.c_void_p
         lib.gsr_forward.restype = C.c_int

@@ -55,7 +55,7 @@ class _RasterizeViews(torch.autograd.Function):
         views = (_lib.GsrView * B)()
         keeps = []
         for v in range(B):
-            views[v], keep = _view_struct(settings[v], dev)
+            views[v], keep = _view_struct(settings[v], dev, no_backward=not any(ctx.needs_input_grad))
             keeps.append(keep)
         geom, binb, img, st = _lib.Scratch(dev), _lib.Scratch(dev), _lib.Scratch(dev), _lib.GsrStats()
         P = _lib.ptr
@@ -78,6 +78,9 @@ class _RasterizeViews(torch.autograd.Function):
                       None if scales is None else scales.shape, None if rotations is None else rotations.shape,
                       None if cov3Ds_precomp is None else cov3Ds_precomp.shape)
         ctx.mark_non_differentiable(radii)
+        # no zero tensors for outputs the loss does not use: autograd would otherwise fill an int32 [N] "gradient" of radii
+        # (a 4 MB memset per step at 1M Gaussians) before every backward; the backward below handles None
+        ctx.set_materialize_grads(False)
         return color, radii, depth, alpha
 
     @staticmethod
@@ -107,6 +110,7 @@ class _RasterizeViews(torch.autograd.Function):
                     P(radii), P(gc), P(gd), P(ga), P(geom), P(binb), P(img), C.byref(ctx.stats),
                     P(d_m3), P(d_m2), P(d_sh), P(d_col), P(d_op), P(d_sc), P(d_rot), P(d_cov), tmp.alloc, stream)
             tmp.release()
+            ctx.stats.bwd_prepared = 0         # one-shot (see rasterizer.py)
             _lib.check(rc, "gsr_backward_views")
         sh_ = ctx.shapes
         r = lambda g, shape: None if g is None or shape is None else g.reshape(shape)

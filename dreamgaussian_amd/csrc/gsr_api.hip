@@ -25,9 +25,10 @@ thread_local char g_err[512] = "";
 thread_local unsigned long long* g_pinned = nullptr;   // (kCounterWords + 1) x u64 host-pinned scratch: the counters, then the arrival flag
 constexpr int kCounterWords = 8 + 2 * GSR_MAX_VIEWS;  // device counters the host reads: 8 totals, then (M_ref, V) per view
 constexpr int kWalkCounter = kCounterWords;            // device only: walk items handed from the chaining kernel to the fix-up kernel
+constexpr int kZeroedFlag = kCounterWords + 4;          // device only: K1's "tile counts / cursors / counters are cleared" tag of the launch (gsr_preprocess.hip)
+constexpr int kCounterSlots = kCounterWords + 6;        // u64 words of the counter block
 struct FwdHint { bool valid = false; int N = 0, H = 0, W = 0, B = 0; unsigned long long M = 0, maxc = 0; unsigned long long per_view[2 * GSR_MAX_VIEWS] = {}; };
 thread_local FwdHint g_hint;                            // this thread's previous gsr_forward: predicts the next one's list sizes
-thread_local hipEvent_t g_copied = nullptr;            // this thread's "counters copied" event
 constexpr unsigned long long kFlagSentinel = 0xffffffffffffffffull;
 
 int fail(int code, const char* fmt, const char* a = "", long long b = 0) {
@@ -105,7 +106,7 @@ int once_per_device(F fn) {
 }
 
 struct GeomLayout {
-    size_t recs, emit, flags8, block_stats, tile_count, cursor, counters, tile_off, tile_seg, order, level_off, sat, plan_off, total;
+    size_t recs, emit, flags8, block_stats, tile_count, cursor, counters, tile_off, tile_seg, order, level_off, sat, plan_off, g2d, total;
     int nTiles;        // per view
     int allTiles;      // views * nTiles: the per-tile arrays hold every view's tiles, view-major
 };
@@ -125,13 +126,16 @@ GeomLayout geom_layout(int N, int H, int W, int B = 1) {
     // tile_count | cursor | counters are contiguous: one memset in front of K1
     L.tile_count = o; o += align_up(BT * 4);
     L.cursor = o; o += align_up(BT * 4);
-    L.counters = o; o += align_up((8 + 2 * GSR_MAX_VIEWS + 2) * 8);   // totals, (M_ref, V) per view, walk items
+    L.counters = o; o += align_up((size_t)kCounterSlots * 8);          // totals, (M_ref, V) per view, walk items, quad-mask word, K1's tag
     L.tile_off = o; o += align_up((BT + 1) * 4);
     L.tile_seg = o; o += align_up((BT + 1) * 4);
     L.order = o; o += align_up(BT * 4);
     L.level_off = o; o += align_up((GSR_NLEV + 1) * 4);
     L.sat = o; o += align_up(BT * 4 * 8);                         // hint word per (tile, wave) of the segment forward
     L.plan_off = o; o += align_up(BT * 4);
+    // the backward's screen-space gradient accumulators [B][N][12] f32: cleared by the FORWARD (forward_impl) so that the backward
+    // starts on its first kernel
+    L.g2d = o; o += align_up(BN * GSR_G2D_STRIDE * 4);
     L.total = o;
     return L;
 }
@@ -163,6 +167,7 @@ ViewConst make_view(const GsrView* v) {
     c.focal_x = c.W / (2.0f * v->tanfovx); c.focal_y = c.H / (2.0f * v->tanfovy);
     c.scale_modifier = v->scale_modifier; c.sh_degree = v->sh_degree;
     c.raw_act = v->raw_activations != 0;
+    c.mat_t = v->flags & (GSR_VIEW_VIEWMATRIX_T | GSR_VIEW_PROJMATRIX_T);
     c.bg = v->bg; c.view = v->viewmatrix; c.proj = v->projmatrix; c.campos = v->campos;
     return c;
 }
@@ -267,6 +272,8 @@ int fwd_hint_env() {
     return 0;
 }
 std::atomic<uint32_t> g_epoch{0x5eed};                  // launch tag of the segment forward's hints
+// launch tag of K1's "counters cleared" flag: process-wide and never repeated, so a stale word in recycled scratch is never it
+std::atomic<unsigned long long> g_k1_epoch{0x6b31000000000000ull ^ ((unsigned long long)(uintptr_t)&g_epoch << 8)};
 
 }  // namespace
 
@@ -302,7 +309,7 @@ extern "C" int gsr_profile_read(int cap, const char** names, float* total_ms, in
     }
     return n;
 }
-extern "C" const char* gsr_version(void) { return "gsr 0.3 (gfx950, wave64, 16x16 bins / 8x8 wave blocks, depth-segmented forward)"; }
+extern "C" const char* gsr_version(void) { return "gsr 0.4 (gfx950, wave64, 16x16 bins / 8x8 wave blocks, depth-segmented forward)"; }
 extern "C" int gsr_abi_version(void) { return GSR_ABI_VERSION; }
 
 extern "C" size_t gsr_geom_bytes(int32_t N, int32_t H, int32_t W) { return geom_layout(N, H, W).total; }
@@ -323,6 +330,10 @@ int begin_impl(const GsrView* views, int B, int32_t N, int32_t K,
                const float* cov3D_precomp, int32_t* radii, char* gbuf, int shift,
                unsigned long long* host_counters, int counter_words, hipStream_t stream) {
     const GsrView* view = views;
+    unsigned long long* host_counters_dev = nullptr;       // the pinned block as the device addresses it
+    HIP_TRY(hipHostGetDevicePointer((void**)&host_counters_dev, host_counters, 0));
+    host_counters[kCounterWords] = kFlagSentinel;          // overwritten by the scan kernel behind the counters (wait_counters polls it)
+    __sync_synchronize();
     ViewTab tab;
     memset(&tab, 0, sizeof(tab));
     for (int v = 0; v < B; ++v) tab.v[v] = make_view(views + v);
@@ -337,9 +348,16 @@ int begin_impl(const GsrView* views, int B, int32_t N, int32_t K,
     unsigned long long* counters = (unsigned long long*)(gbuf + GL.counters);
 
     const int hist_in_lds = T <= hist_lds_max_tiles();
-    prof_begin(stream);
-    HIP_TRY(hipMemsetAsync(gbuf + GL.tile_count, 0, GL.tile_off - GL.tile_count, stream));
-    prof_end(stream, "memset_fwd");
+    // tile_count | cursor | counters start from zero: cleared by K1's first workgroup (no launch of its own); without Gaussians
+    // there is no K1
+    if (N <= 0) {
+        prof_begin(stream);
+        HIP_TRY(hipMemsetAsync(gbuf + GL.tile_count, 0, GL.tile_off - GL.tile_count, stream));
+        prof_end(stream, "memset_fwd");
+    }
+    const uint32_t zero_words = (uint32_t)((GL.tile_off - GL.tile_count) / 4);
+    const uint32_t flag_word = (uint32_t)((GL.counters - GL.tile_count) / 4) + 2u * (uint32_t)kZeroedFlag;
+    const unsigned long long epoch = g_k1_epoch.fetch_add(1ull) + 1ull;
 
     // K1 is a persistent grid (per-workgroup tile histogram + statistics): four workgroups per CU (115 VGPRs), every wave walks
     // batches of 64 Gaussians. The grid is SHRUNK to ceil(batches / rounds) so that no workgroup walks one batch more than the
@@ -364,20 +382,17 @@ int begin_impl(const GsrView* views, int B, int32_t N, int32_t K,
             HIP_TRY(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         prof_begin(stream); hipLaunchKernelGGL(k1, dim3(grid_pre, B), dim3(256), lds, stream, tab, N, K, means3D, shs, view->shs_rest,
                            colors_precomp, opacities, scales, rotations, cov3D_precomp, recs, emit, radii,
-                           tile_count, (unsigned long long*)(gbuf + GL.block_stats), hist_in_lds, (uint8_t*)(gbuf + GL.flags8));
+                           tile_count, (unsigned long long*)(gbuf + GL.block_stats), hist_in_lds, (uint8_t*)(gbuf + GL.flags8),
+                           (uint32_t*)(gbuf + GL.tile_count), zero_words, flag_word, epoch);
         LAUNCH_CHECK(view, stream, "preprocess_fwd");
     }
     // one single-workgroup kernel: scan of the counts, K1's statistics, the segment forward's depth-major work list
     prof_begin(stream); hipLaunchKernelGGL(gsr_tile_scan, dim3(1), dim3(1024), 0, stream, tile_count, (uint32_t*)(gbuf + GL.tile_off), GL.allTiles, counters,
                        (uint32_t*)(gbuf + GL.tile_seg), shift, (const unsigned long long*)(gbuf + GL.block_stats), N > 0 ? grid_pre * B : 0, B,
-                       (uint32_t*)(gbuf + GL.order), (uint32_t*)(gbuf + GL.level_off));
+                       (uint32_t*)(gbuf + GL.order), (uint32_t*)(gbuf + GL.level_off), host_counters_dev, counter_words, kCounterWords);
     LAUNCH_CHECK(view, stream, "tile_scan");
-    HIP_TRY(hipMemcpyAsync(host_counters, counters, (size_t)counter_words * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-    // second, stream-ordered copy of a word that is zero here (counters[4], written only by the segment chaining, later in
-    // the stream): its arrival over the host's sentinel says the counters above have landed (forward_impl polls it)
-    host_counters[kCounterWords] = kFlagSentinel;
-    HIP_TRY(hipMemcpyAsync((void*)(host_counters + kCounterWords), counters + 4, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipEventRecord(g_copied, stream));
+    // (the scan kernel stores the counters and then the arrival flag into the pinned block itself: no copy kernels and no event
+    // marker in the stream -- the marker alone was a 5 us hole in front of the scatter)
     return 0;
 }
 
@@ -389,7 +404,7 @@ int sort_class(unsigned long long maxc) { return maxc <= 2048 ? 0 : (maxc <= 819
 int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float* out_depth, float* out_alpha,
                 char* gbuf, char* ibuf, GsrAlloc bin, int shift,
                 const unsigned long long* per_view /* (M_ref, V) of every view */,
-                unsigned long long cap, unsigned long long maxc, hipStream_t stream) {
+                unsigned long long cap, unsigned long long maxc, bool prepare_bwd, hipStream_t stream) {
     const GsrView* view = views;
     const ViewConst vc = make_view(view);
     const int H = vc.H, W = vc.W;
@@ -470,6 +485,10 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
     const uint32_t mask_all = B >= 32 ? ~0u : ((1u << B) - 1u);
     uint32_t* plan_off = (uint32_t*)(gbuf + GL.plan_off);
     uint4* plan_tile = (uint4*)(bbuf + BL.plan_tile);
+    // the backward's accumulators, cleared by the per-tile kernel's workgroups (the first launch of the two instantiations)
+    float4* zero4 = (float4*)(gbuf + GL.g2d);
+    uint32_t zero_n = prepare_bwd ? (uint32_t)((size_t)B * (size_t)N * GSR_G2D_STRIDE / 4) : 0u;
+    const uint32_t zero_per = (zero_n + (uint32_t)TA - 1u) / (uint32_t)TA;       // float4s per workgroup (grid = TA)
     if (sequential) {
         // ---- K5s: the serial walk, one workgroup per tile
         prof_begin(stream);
@@ -478,14 +497,15 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
             hipLaunchKernelGGL(gsr_render_fwd_serial<true>, dim3(TA), dim3(256), 0, stream, tile_off, recs, sorted_ids, W, H, vc.gx,
                                out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, order, shift,
                                plan_off, plan_tile, counters + 4, (uint32_t)BL.plan_cap, (unsigned long long)mask_q, (uint32_t)BL.items /* the first of the three spare records: store sink */,
-                               counters, (uint32_t)M, maxc_cap, vs);
+                               counters, (uint32_t)M, maxc_cap, vs, zero4, zero_n, zero_per);
+            zero_n = 0u;
         }
         if (mask_q != mask_all) {
             vs.view_mask = mask_all & ~mask_q;
             hipLaunchKernelGGL(gsr_render_fwd_serial<false>, dim3(TA), dim3(256), 0, stream, tile_off, recs, sorted_ids, W, H, vc.gx,
                                out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, order, shift,
                                plan_off, plan_tile, counters + 4, (uint32_t)BL.plan_cap, (unsigned long long)mask_q, (uint32_t)BL.items /* the first of the three spare records: store sink */,
-                               counters, (uint32_t)M, maxc_cap, vs);
+                               counters, (uint32_t)M, maxc_cap, vs, zero4, zero_n, zero_per);
         }
         LAUNCH_CHECK(view, stream, "render_fwd");
         return 0;
@@ -520,7 +540,7 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
     uint2* walk_items = (uint2*)(bbuf + BL.walk_items);
     hipLaunchKernelGGL(gsr_render_fwd_combine, dim3(TA), dim3(256), 0, stream, tile_off, recs, sorted_ids, W, H, vc.gx,
                        out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, order, shift,
-                       plan_off, plan_tile, counters + 4, (uint32_t)BL.plan_cap, walk_items, counters + kWalkCounter, counters, (uint32_t)M, maxc_cap, vs);
+                       plan_off, plan_tile, counters + 4, (uint32_t)BL.plan_cap, walk_items, counters + kWalkCounter, counters, (uint32_t)M, maxc_cap, vs, zero4, zero_n, zero_per);
     LAUNCH_CHECK(view, stream, "render_combine");
     if (M > 0) {   // ---- K5c: the pixels that stop inside a segment, one wave per (block, segment) item
         const unsigned grid_f = (unsigned)(TA < 2048 ? (TA < 64 ? 64 : TA) : 2048);
@@ -533,18 +553,16 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
     return 0;
 }
 
-// waits until the counter copy behind begin_impl has landed in the thread's pinned block
-int wait_counters(volatile unsigned long long* pinned) {
-    // GSR_WAIT=event: hipEventSynchronize only. Default: poll the pinned arrival flag (with work queued behind the
-    // event, hipEventSynchronize was seen to return only when that work had drained); bounded, then the event
-    const char* e = getenv("GSR_WAIT");
+// waits until the scan kernel's counters have landed in the thread's pinned block (it stores the arrival flag behind them)
+int wait_counters(volatile unsigned long long* pinned, hipStream_t stream) {
+    volatile unsigned long long* f = pinned + kCounterWords;
     bool arrived = false;
-    if (!(e && strcmp(e, "event") == 0)) {
-        volatile unsigned long long* f = pinned + kCounterWords;
-        for (long it = 0; it < 20000000L && !arrived; ++it) { arrived = (*f != kFlagSentinel); if (!arrived) __builtin_ia32_pause(); }
-        __sync_synchronize();
+    for (long it = 0; it < 20000000L && !arrived; ++it) { arrived = (*f != kFlagSentinel); if (!arrived) __builtin_ia32_pause(); }
+    __sync_synchronize();
+    if (!arrived) {                                       // (bounded poll: a stream that makes no progress surfaces as an error, not a hang)
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (*f == kFlagSentinel) return fail(-2, "the forward's counters did not arrive%s", "");
     }
-    if (!arrived) HIP_TRY(hipEventSynchronize(g_copied));
     return 0;
 }
 
@@ -562,17 +580,21 @@ int forward_impl(const GsrView* views, int B, int32_t N, int32_t K,
     if (!out_color || !out_depth || !out_alpha || (N > 0 && !radii)) return fail(-1, "output pointers are required%s", "");
     if (!geom.resize || !bin.resize || !img.resize) return fail(-1, "scratch allocators are required%s", "");
     // the one host round trip of the forward: how many (tile,Gaussian) instances to allocate
-    if (!g_pinned) HIP_TRY(hipHostMalloc((void**)&g_pinned, (kCounterWords + 1) * sizeof(unsigned long long), hipHostMallocDefault));
-    if (!g_copied) HIP_TRY(hipEventCreateWithFlags(&g_copied, hipEventDisableTiming));
+    if (!g_pinned) HIP_TRY(hipHostMalloc((void**)&g_pinned, (kCounterWords + 1) * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
     const ViewConst vcs = make_view(view);
     const GeomLayout GLs = geom_layout(N, vcs.H, vcs.W, B);
     const int shift = seg_shift_for(N, GLs.nTiles);
     char* gbuf = (char*)geom.resize(geom.ctx, GLs.total);
     char* ibuf = (char*)img.resize(img.ctx, gsr_img_bytes(vcs.H, vcs.W) * (size_t)B);
     if (!gbuf || !ibuf) return fail(-4, "scratch allocation failed%s", "");
+    // The backward accumulates its screen-space gradients with atomics into [B][N][12] floats that must start from zero -- 48 MB at
+    // 1M Gaussians, a 10 us fill in front of gsr_render_bwd_q2 in round 3. The forward's compositing leaves HBM idle: every workgroup
+    // of its per-tile kernel (gsr_render_fwd_serial / gsr_render_fwd_combine) clears a slice of them behind its own work. (A fill on
+    // a second stream was measured first: the two cross-stream waits cost 15 us of bubbles, more than the fill.)
+    const bool prepare = N > 0 && !(view->flags & GSR_VIEW_NO_BACKWARD);
     if (int rc = begin_impl(views, B, N, K, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                             radii, gbuf, shift, g_pinned, 8 + 2 * B, stream)) {
-        (void)hipEventSynchronize(g_copied);              // no copy into the pinned block may be pending when the next call re-arms it
+        (void)hipStreamSynchronize(stream);               // nothing may still write the pinned block when the next call re-arms it
         return rc;
     }
     // Speculation (default; GSR_SPECULATE=0 turns it off): the previous call of this thread on the same problem shape predicts
@@ -590,9 +612,9 @@ int forward_impl(const GsrView* views, int B, int32_t N, int32_t K,
         cap = g_hint.M + g_hint.M / 4 + 4096;
         const unsigned long long c = g_hint.maxc + g_hint.maxc / 4 + 64;
         capc = c <= 2048 ? 2048 : (c <= 8192 ? 8192 : (c <= 16384 ? 16384 : ~0ull));
-        rc = finish_impl(views, B, N, out_color, out_depth, out_alpha, gbuf, ibuf, bin, shift, g_hint.per_view, cap, capc, stream);
+        rc = finish_impl(views, B, N, out_color, out_depth, out_alpha, gbuf, ibuf, bin, shift, g_hint.per_view, cap, capc, prepare, stream);
     }
-    if (int rcw = wait_counters(g_pinned)) return rcw;    // also on a failed tail: nothing may stay pending on the pinned block
+    if (int rcw = wait_counters(g_pinned, stream)) return rcw;    // also on a failed tail: nothing may stay pending on the pinned block
     if (rc) return rc;
     const unsigned long long M_ref = g_pinned[0], V = g_pinned[1], M = g_pinned[2], maxc = g_pinned[3];
     if (spec && (M > cap || sort_class(maxc) > sort_class(capc))) {
@@ -602,10 +624,11 @@ int forward_impl(const GsrView* views, int B, int32_t N, int32_t K,
     }
     if (!spec || cap == 0) {
         cap = M;
-        rc = finish_impl(views, B, N, out_color, out_depth, out_alpha, gbuf, ibuf, bin, shift, g_pinned + 8, M, maxc, stream);
+        rc = finish_impl(views, B, N, out_color, out_depth, out_alpha, gbuf, ibuf, bin, shift, g_pinned + 8, M, maxc, prepare, stream);
     }
     if (stats) { stats->num_instances = (int64_t)M; stats->num_instances_ref = (int64_t)M_ref; stats->num_visible = (int64_t)V;
-                 stats->max_tile_count = (int64_t)maxc; stats->bin_capacity = (int64_t)cap; stats->seg_shift = shift; }
+                 stats->max_tile_count = (int64_t)maxc; stats->bin_capacity = (int64_t)cap; stats->seg_shift = shift;
+                 stats->bwd_prepared = (prepare && rc == 0) ? 1 : 0; }
     if (rc == 0) {
         g_hint.valid = true; g_hint.N = N; g_hint.H = vcs.H; g_hint.W = vcs.W; g_hint.B = B; g_hint.M = M; g_hint.maxc = maxc;
         for (int v = 0; v < 2 * B; ++v) g_hint.per_view[v] = g_pinned[8 + v];
@@ -633,7 +656,6 @@ int backward_impl(const GsrView* views, int B, int32_t N, int32_t K,
     if (!dL_dmeans3D || !dL_dmeans2D || !dL_dopacities) return fail(-1, "dL_dmeans3D/dL_dmeans2D/dL_dopacities are required%s", "");
     if (shs && !dL_dshs) return fail(-1, "dL_dshs is required with shs%s", "");
     if (view->shs_rest && (!shs || !view->dL_dshs_rest || K < 2)) return fail(-1, "split SH input needs shs (features_dc), K >= 2 and GsrView.dL_dshs_rest%s", "");
-    if (!tmp.resize) return fail(-1, "tmp allocator is required%s", "");
     const ViewConst vc = make_view(view);
     const int H = vc.H, W = vc.W;
     const GeomLayout GL = geom_layout(N, H, W, B);
@@ -667,11 +689,17 @@ int backward_impl(const GsrView* views, int B, int32_t N, int32_t K,
     const uint32_t* sorted_ids = (const uint32_t*)bin;    // BinLayout.ids == 0
 
     const size_t g2d_view = (size_t)N * GSR_G2D_STRIDE;
-    float* g2d = (float*)tmp.resize(tmp.ctx, align_up(g2d_view * 4 * (size_t)B));
-    if (!g2d) return fail(-4, "tmp scratch allocation failed%s", "");
-    prof_begin(stream);
-    HIP_TRY(hipMemsetAsync(g2d, 0, g2d_view * 4 * (size_t)B, stream));
-    prof_end(stream, "memset_bwd");
+    float* g2d = nullptr;
+    if (fwd_stats && fwd_stats->bwd_prepared == 1) {
+        g2d = (float*)(const_cast<char*>(gbuf) + GL.g2d);   // cleared by the forward (forward_impl)
+    } else {                                              // no GsrStats, GSR_VIEW_NO_BACKWARD, or a second backward of the same forward
+        if (!tmp.resize) return fail(-1, "tmp allocator is required%s", "");
+        g2d = (float*)tmp.resize(tmp.ctx, align_up(g2d_view * 4 * (size_t)B));
+        if (!g2d) return fail(-4, "tmp scratch allocation failed%s", "");
+        prof_begin(stream);
+        HIP_TRY(hipMemsetAsync(g2d, 0, g2d_view * 4 * (size_t)B, stream));
+        prof_end(stream, "memset_bwd");
+    }
 
     prof_begin(stream);
     if (M > 0) {
@@ -790,7 +818,7 @@ extern "C" int gsr_mark_visible(const GsrView* view, int32_t N, const float* mea
     if (N < 0) return fail(-1, "N must be >= 0%s", "");
     if (N == 0) return 0;
     if (!means3D || !visible) return fail(-1, "means3D and visible are required%s", "");
-    prof_begin(stream); hipLaunchKernelGGL(gsr_mark_visible_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, view->viewmatrix, N, means3D, visible);
+    prof_begin(stream); hipLaunchKernelGGL(gsr_mark_visible_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, view->viewmatrix, view->flags & GSR_VIEW_VIEWMATRIX_T, N, means3D, visible);
     LAUNCH_CHECK(view, stream, "mark_visible");
     return 0;
 }

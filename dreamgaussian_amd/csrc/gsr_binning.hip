@@ -49,7 +49,10 @@ extern "C" __global__ void __launch_bounds__(1024)
 gsr_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_off, int T,
               unsigned long long* __restrict__ counters, uint32_t* __restrict__ tile_seg, int seg_shift,
               const unsigned long long* __restrict__ block_stats, int nblocks /* all views */, int nviews,
-              uint32_t* __restrict__ order /* tiles by segment count, descending */, uint32_t* __restrict__ level_off /* [1024] */) {
+              uint32_t* __restrict__ order /* tiles by segment count, descending */, uint32_t* __restrict__ level_off /* [1024] */,
+              unsigned long long* __restrict__ host_out /* pinned host memory (device-mapped): the first `host_words` counters land in
+                                                           words 0.., the arrival flag in word `host_flag` */,
+              int host_words, int host_flag) {
     // tile_seg[t] = index of tile t's first segment record = exclusive scan of ceil(n_t / 2^seg_shift)
     __shared__ unsigned long long wsum[16];
     __shared__ uint32_t wsegs[16];
@@ -156,6 +159,18 @@ gsr_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ ti
             b = __builtin_amdgcn_readlane(b, leader);
             if (empty) order[b + (uint32_t)__popcll(em & ((1ull << lane) - 1ull))] = (uint32_t)t;
         }
+    }
+    // The host sizes the list scratch from the counters (gsr_forward's one round trip). They go straight into its pinned block --
+    // the two stream-ordered D2H copies behind this kernel were blit KERNELS of their own (5-8 us each) with an 11 us hole behind
+    // them in the rocprof trace of round 4: 23 us of every forward. Counters first, system-scope fence, then the flag the host polls.
+    if (host_out) {
+        __syncthreads();                                  // every counter above has been stored (by different threads)
+        if ((int)threadIdx.x < host_words) {
+            host_out[threadIdx.x] = __hip_atomic_load(counters + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence_system();
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(host_out + host_flag, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 

@@ -77,11 +77,15 @@ struct ViewConst {           // by-value kernel argument (scalar registers)
     float scale_modifier;
     int sh_degree;
     int raw_act;             // inputs are the raw parameters: opacity = sigmoid, scale = exp, rotation = normalise here
+    int mat_t;               // bit 0 / 1: `view` / `proj` point at the transposed matrix (GSR_VIEW_VIEWMATRIX_T / _PROJMATRIX_T)
     const float* bg;
     const float* view;
     const float* proj;
     const float* campos;
 };
+
+// element i (0..15) of a camera matrix in the layout the kernels compute with, from storage that may hold its transpose
+__device__ __forceinline__ int cam_index(int i, int transposed) { return transposed ? ((i & 3) << 2) | (i >> 2) : i; }
 
 // Several cameras in one launch chain (gsr_forward_views / gsr_backward_views): the per-Gaussian kernels take the
 // cameras as a by-value table and pick theirs with blockIdx.y; the per-tile kernels run over views * tiles_per_view

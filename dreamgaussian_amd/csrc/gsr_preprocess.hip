@@ -245,9 +245,34 @@ gsr_preprocess_fwd(ViewTab views /* camera of this workgroup: views.v[blockIdx.y
                    int32_t* __restrict__ radii, uint32_t* __restrict__ tile_count,
                    unsigned long long* __restrict__ block_stats /*[grid][3]: M_ref, V, max(colour, depth) bits per workgroup*/,
                    int hist_in_lds,
-                   uint8_t* __restrict__ flags8 /* colour-clamp bits for K6: 1 B instead of a 64-B record line */) {
+                   uint8_t* __restrict__ flags8 /* colour-clamp bits for K6: 1 B instead of a 64-B record line */,
+                   uint32_t* __restrict__ zero_base /* tile_count | cursor | counters of ALL views: zeroed here, by workgroup (0, 0) */,
+                   uint32_t zero_words, uint32_t flag_word /* (even) index in zero_base of the 64-bit "zeroed" flag */, unsigned long long epoch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_pp[];
     const ViewConst vc = views.v[blockIdx.y];
+    // The per-tile counts, the scatter's cursors and the counters start from zero: workgroup (0, 0) -- the first the dispatcher
+    // hands out -- clears them (20 KB at 2 500 tiles) and publishes a per-launch tag; every workgroup looks at the tag once, right
+    // before its first atomic on a tile count (~80 us later at 1M Gaussians): the hipMemsetAsync in front of K1 (a launch of its
+    // own, 6 us on the driver's box) is gone. Stale memory never holds this launch's tag (a process-wide counter).
+    unsigned long long* const zflag = reinterpret_cast<unsigned long long*>(zero_base + flag_word);
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        for (uint32_t i = threadIdx.x; i < zero_words; i += blockDim.x)
+            if ((i & ~1u) != flag_word) zero_base[i] = 0u;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(zflag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    auto wait_zeroed = [&]() {                            // (block-uniform call sites)
+        if (threadIdx.x == 0) {
+#pragma unroll 1
+            for (int spin = 0; spin < (1 << 22) && __hip_atomic_load(zflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch; ++spin)
+                __builtin_amdgcn_s_sleep(8);
+        }
+        __syncthreads();
+    };
     const int nTiles = vc.gx * vc.gy;
     // 256 bytes behind the statistics that nobody reads: where the lanes past the end of the array store (below)
     char* const sink = reinterpret_cast<char*>(block_stats) + (size_t)gridDim.y * 2048 * 3 * 8;
@@ -264,13 +289,13 @@ gsr_preprocess_fwd(ViewTab views /* camera of this workgroup: views.v[blockIdx.y
 
     if (hist_in_lds) {
         for (int t = threadIdx.x; t < nTiles; t += blockDim.x) hist[t] = 0;
-    }
+    } else wait_zeroed();                                 // tile grids beyond the LDS histogram: every emission is a global atomic
     // The camera sits in LDS: read through its device pointers it comes back as VECTOR-memory loads (the compiler cannot
     // prove the memory read-only), and waiting for one of those at the top of a batch also waits for the previous batch's
     // stores (one in-order counter for a wave's loads and stores).
     __shared__ __attribute__((aligned(16))) float cam[36];
-    if (threadIdx.x < 16) cam[threadIdx.x] = vc.view[threadIdx.x];
-    else if (threadIdx.x < 32) cam[threadIdx.x] = vc.proj[threadIdx.x - 16];
+    if (threadIdx.x < 16) cam[threadIdx.x] = vc.view[cam_index(threadIdx.x, vc.mat_t & 1)];
+    else if (threadIdx.x < 32) cam[threadIdx.x] = vc.proj[cam_index(threadIdx.x - 16, vc.mat_t & 2)];
     else if (threadIdx.x < 35) cam[threadIdx.x] = vc.campos[threadIdx.x - 32];
     __syncthreads();
 
@@ -561,6 +586,7 @@ gsr_preprocess_fwd(ViewTab views /* camera of this workgroup: views.v[blockIdx.y
         block_stats[3 * blockIdx.x + threadIdx.x] = sum;
     }
     if (hist_in_lds) {
+        wait_zeroed();
         // every workgroup starts its flush at a different tile: no burst of atomics on one address
         const int t0 = (int)((blockIdx.x * 67u) % (unsigned)nTiles);
         for (int i = threadIdx.x; i < nTiles; i += blockDim.x) {
@@ -835,7 +861,7 @@ gsr_preprocess_bwd(ViewTab tab, int first_view, int B /* B == 1: the view tab.v[
     for (int e = threadIdx.x; e < 36 * (MULTI ? B : 1); e += blockDim.x) {
         const int v = e / 36, c = e - v * 36;
         const ViewConst& cv = tab.v[MULTI ? first_view + v : 0];
-        if (c < 35) camf[MULTI ? v : 0][c] = c < 16 ? cv.view[c] : (c < 32 ? cv.proj[c - 16] : cv.campos[c - 32]);
+        if (c < 35) camf[MULTI ? v : 0][c] = c < 16 ? cv.view[cam_index(c, cv.mat_t & 1)] : (c < 32 ? cv.proj[cam_index(c - 16, cv.mat_t & 2)] : cv.campos[c - 32]);
     }
     lds_barrier();
     for (int base = blockIdx.x * blockDim.x; base < N; base += gridDim.x * blockDim.x) {
@@ -946,10 +972,13 @@ template __global__ void gsr_preprocess_bwd<true, false>(ViewTab, int, int, int,
 
 // visible[i] = view-space z > 0.2  (frustum rule of A.3)
 extern "C" __global__ void __launch_bounds__(256)
-gsr_mark_visible_kernel(const float* __restrict__ V, int N, const float* __restrict__ means3D,
+gsr_mark_visible_kernel(const float* __restrict__ Vg, int transposed, int N, const float* __restrict__ means3D,
                         uint8_t* __restrict__ visible) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= N) return;
+    float V[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) V[i] = (i == 2 || i == 6 || i == 10 || i == 14) ? Vg[cam_index(i, transposed)] : 0.f;
     const float z = view_depth(V, means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
     visible[idx] = z > 0.2f ? 1 : 0;
 }

@@ -287,6 +287,16 @@ template __global__ void gsr_render_fwd_seg<false>(const uint4*, const uint32_t*
 template __global__ void gsr_render_fwd_seg<true>(const uint4*, const uint32_t*, const uint32_t*, const SplatRec*, const uint32_t*, int, int, int,
                                                   float*, int, unsigned long long*, uint32_t, int, const unsigned long long*, uint32_t, uint32_t, ViewSplit);
 
+// The backward's per-Gaussian accumulators ([views][N][12] floats inside `geom`) start from zero. The forward's per-tile kernel
+// clears them: workgroup k of the launch stores zeros to slice k of `zero_n` float4s BEHIND its own work -- the compositing leaves
+// HBM idle, the workgroups finish spread over the kernel's length, and the 10 us fill in front of gsr_render_bwd_q2 (and its launch)
+// is gone. zero_n = 0: nothing to clear (GSR_VIEW_NO_BACKWARD, or the other instantiation's launch does it).
+__device__ __forceinline__ void clear_slice(float4* __restrict__ zero4, uint32_t zero_n, uint32_t per /* float4s per workgroup (host: ceil(zero_n / grid)) */) {
+    if (zero_n == 0u) return;
+    const uint32_t lo = blockIdx.x * per, hi = min(lo + per, zero_n);
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 256u) zero4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // =========================================================================================
 // K5s: forward, the serial walk -- for views that fill the chip on their own (fwd_sequential_for in gsr_api.hip).
 // One workgroup per tile (heaviest first), four independent waves = four 8x8 blocks. A wave fetches 64 list entries per
@@ -308,7 +318,8 @@ gsr_render_fwd_serial(const uint32_t* __restrict__ tile_off, const SplatRec* __r
                       const uint32_t* __restrict__ order, int seg_shift,
                       uint32_t* __restrict__ plan_off, uint4* __restrict__ plan_items,
                       unsigned long long* __restrict__ plan_total, uint32_t plan_cap, unsigned long long qmask_views, uint32_t sink_rec,
-                      const unsigned long long* __restrict__ counters, uint32_t capacity, uint32_t maxc_cap, ViewSplit vs) {
+                      const unsigned long long* __restrict__ counters, uint32_t capacity, uint32_t maxc_cap, ViewSplit vs,
+                      float4* __restrict__ zero4, uint32_t zero_n, uint32_t zero_per) {
     if (counters[2] > (unsigned long long)capacity || counters[3] > (unsigned long long)maxc_cap) return;
     __shared__ float4 stage[4][3][GSR_RB + 2];
     __shared__ __attribute__((aligned(8))) uint8_t qlist[QUAD ? 4 : 1][4][80];
@@ -317,7 +328,7 @@ gsr_render_fwd_serial(const uint32_t* __restrict__ tile_off, const SplatRec* __r
     if (blockIdx.x == 0 && threadIdx.x == 0) plan_total[GSR_CNT_QMASK - GSR_CNT_PLAN] = qmask_views;   // the views whose records carry quad masks
     const int tg = (int)order[blockIdx.x];                // heaviest tiles first
     const int view = tg / vs.tiles_per_view;
-    if (!((vs.view_mask >> view) & 1u)) return;           // (workgroup-uniform) this view composites with the other instantiation
+    if (!((vs.view_mask >> view) & 1u)) { clear_slice(zero4, zero_n, zero_per); return; }   // (workgroup-uniform) this view composites with the other instantiation
     const int tile = tg - view * vs.tiles_per_view;
     const float* __restrict__ bg = vs.bg[view];
     {
@@ -503,13 +514,14 @@ gsr_render_fwd_serial(const uint32_t* __restrict__ tile_off, const SplatRec* __r
             if (base + q < plan_cap)     // {tile, the segment's record, list start, segment | (entries in it - 1) << 24}: all the backward needs, in one load
                 plan_items[base + q] = make_uint4((uint32_t)tg, tile_seg[tg] + q, start, q | ((min(1u << seg_shift, tile_n - (q << seg_shift)) - 1u) << 24));
     }
+    clear_slice(zero4, zero_n, zero_per);
 }
 template __global__ void gsr_render_fwd_serial<false>(const uint32_t*, const SplatRec*, const uint32_t*, int, int, int, float*, float*, float*, float*,
                                                       uint32_t*, float*, float*, const uint32_t*, const uint32_t*, int, uint32_t*, uint4*,
-                                                      unsigned long long*, uint32_t, unsigned long long, uint32_t, const unsigned long long*, uint32_t, uint32_t, ViewSplit);
+                                                      unsigned long long*, uint32_t, unsigned long long, uint32_t, const unsigned long long*, uint32_t, uint32_t, ViewSplit, float4*, uint32_t, uint32_t);
 template __global__ void gsr_render_fwd_serial<true>(const uint32_t*, const SplatRec*, const uint32_t*, int, int, int, float*, float*, float*, float*,
                                                      uint32_t*, float*, float*, const uint32_t*, const uint32_t*, int, uint32_t*, uint4*,
-                                                     unsigned long long*, uint32_t, unsigned long long, uint32_t, const unsigned long long*, uint32_t, uint32_t, ViewSplit);
+                                                     unsigned long long*, uint32_t, unsigned long long, uint32_t, const unsigned long long*, uint32_t, uint32_t, ViewSplit, float4*, uint32_t, uint32_t);
 
 // The exact walk of list positions [lo, hi) of a tile for the lanes with done == false (lane = pixel, row-major 8x8 block at
 // (bx0, by0)), `gate` = their transmittance in front of the segment. Updates T, C0, C1, C2, D, A, last, done: the segment's own
@@ -573,7 +585,8 @@ gsr_render_fwd_combine(const uint32_t* __restrict__ tile_off, const SplatRec* __
                        uint32_t* __restrict__ plan_off, uint4* __restrict__ plan_items,
                        unsigned long long* __restrict__ plan_total, uint32_t plan_cap,
                        uint2* __restrict__ walk_items, unsigned long long* __restrict__ walk_total,
-                       const unsigned long long* __restrict__ counters, uint32_t capacity, uint32_t maxc_cap, ViewSplit vs) {
+                       const unsigned long long* __restrict__ counters, uint32_t capacity, uint32_t maxc_cap, ViewSplit vs,
+                       float4* __restrict__ zero4, uint32_t zero_n, uint32_t zero_per) {
     if (counters[2] > (unsigned long long)capacity || counters[3] > (unsigned long long)maxc_cap) return;
     __shared__ float4 stage[4][3][GSR_RB + 2];
     __shared__ uint32_t wl[4];
@@ -716,6 +729,7 @@ gsr_render_fwd_combine(const uint32_t* __restrict__ tile_off, const SplatRec* __
         for (int w = 0; w < wave; ++w) wb += wcnt[w];
         if ((uint32_t)lane < nwalk) walk_items[wb + lane] = make_uint2((uint32_t)tg * 4u + (uint32_t)wave, (uint32_t)wseg[wave][lane]);
     }
+    clear_slice(zero4, zero_n, zero_per);
 }
 
 // =========================================================================================

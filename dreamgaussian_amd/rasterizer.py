@@ -60,12 +60,19 @@ def _f32c(t: Optional[torch.Tensor], device) -> Optional[torch.Tensor]:
     return t.to(torch.float32).contiguous()
 
 
-def _view_struct(rs: GaussianRasterizationSettings, device, raw: bool = False):
+def _view_struct(rs: GaussianRasterizationSettings, device, raw: bool = False, no_backward: bool = False):
     keep = []
-    for x in (rs.bg, rs.viewmatrix, rs.projmatrix, rs.campos):
-        if type(x) is torch.Tensor and x.dtype is torch.float32 and x.device == device and x.is_contiguous():
+    flags = _lib.GSR_VIEW_NO_BACKWARD if no_backward else 0
+    for x, tbit in ((rs.bg, 0), (rs.viewmatrix, _lib.GSR_VIEW_VIEWMATRIX_T), (rs.projmatrix, _lib.GSR_VIEW_PROJMATRIX_T), (rs.campos, 0)):
+        ok = type(x) is torch.Tensor and x.dtype is torch.float32 and x.device == device
+        if ok and x.is_contiguous():
             keep.append(x)                                # already what the kernels read: no copy, no new tensor object
-        else:                                             # e.g. the reference's viewmatrix, a transposed (non-contiguous) view
+        elif ok and tbit and x.dim() == 2 and x.shape == (4, 4) and x.stride() == (1, 4):
+            # the reference's `world_view_transform`: a .transpose(0, 1) VIEW of the row-major w2c (gs_renderer.py:662-664). Its
+            # storage holds the transpose; the kernels read it as such (GSR_VIEW_*_T) -- no .contiguous() copy kernel per render
+            keep.append(x)
+            flags |= tbit
+        else:
             keep.append(torch.as_tensor(x).to(device=device, dtype=torch.float32).contiguous().reshape(-1))
     if keep[0].numel() != 3 or keep[1].numel() != 16 or keep[2].numel() != 16 or keep[3].numel() != 3:
         raise RuntimeError("bg/campos must have 3 elements and viewmatrix/projmatrix 16")
@@ -73,7 +80,7 @@ def _view_struct(rs: GaussianRasterizationSettings, device, raw: bool = False):
                      float(rs.tanfovy), float(rs.scale_modifier), int(rs.sh_degree),
                      int(bool(rs.prefiltered)), int(bool(rs.debug)),
                      keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(), keep[3].data_ptr(),
-                     1 if raw else 0, 0, None, None)
+                     1 if raw else 0, flags, None, None)
     return v, keep
 
 
@@ -120,7 +127,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         geom, binb, img = _lib.Scratch(dev), _lib.Scratch(dev), _lib.Scratch(dev)
         stats = _lib.GsrStats()
         with torch.cuda.device(dev):
-            view, keep = _view_struct(rs, dev, ctx.raw)
+            # (inference -- torch.no_grad(), or no input that requires a gradient: the backward's accumulators are not prepared)
+            view, keep = _view_struct(rs, dev, ctx.raw, no_backward=not any(ctx.needs_input_grad))
             if rest is not None:
                 view.shs_rest = rest.data_ptr()
                 keep.append(rest)
@@ -153,6 +161,9 @@ class _RasterizeGaussians(torch.autograd.Function):
                       None if rotations is None else rotations.shape,
                       None if cov3Ds_precomp is None else cov3Ds_precomp.shape)
         ctx.mark_non_differentiable(radii)
+        # no zero tensors for outputs the loss does not use: autograd would otherwise fill an int32 [N] "gradient" of radii
+        # (a 4 MB memset per step at 1M Gaussians) before every backward; the backward below handles None
+        ctx.set_materialize_grads(False)
         return color, radii, depth, alpha
 
     @staticmethod
@@ -203,6 +214,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                     P(geom), P(binb), P(img), C.byref(ctx.fwd_stats) if _pass_fwd_stats else None, P(d_m3), P(d_m2), P(d_sh), P(d_col), P(d_op),
                     P(d_sc), P(d_rot), P(d_cov), tmp.alloc, stream)
             tmp.release()
+            ctx.fwd_stats.bwd_prepared = 0     # one-shot: a second backward of this forward (retain_graph) clears its own accumulators
             _lib.check(rc, "gsr_backward")
         s = ctx.shapes
         rs_ = lambda g, shape: None if g is None or shape is None else g.reshape(shape)

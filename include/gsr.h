@@ -59,7 +59,7 @@ typedef struct GsrView {
     int32_t raw_activations; /* !=0: `opacities`, `scales`, `rotations` are DreamGaussian's RAW parameters
                               * (_opacity, _scaling, _rotation): sigmoid / exp / normalise (gs_renderer.py:134-142,
                               * 196-216) and their backward run inside the per-Gaussian kernels */
-    int32_t reserved;
+    int32_t flags;           /* GSR_VIEW_* bits below (0 = the drop-in behaviour) */
     /* Split SH input (the `cat`-free half): when shs_rest != NULL the `shs` argument of
      * gsr_forward / gsr_backward is DreamGaussian's `_features_dc` [N,1,3] and shs_rest its `_features_rest`
      * [N,K-1,3] (K still counts all coefficients): the kernels read the two tensors where they are instead of
@@ -68,6 +68,13 @@ typedef struct GsrView {
     const float* shs_rest;
     float* dL_dshs_rest;
 } GsrView;
+
+/* GsrView.flags */
+#define GSR_VIEW_VIEWMATRIX_T 1  /* viewmatrix points at the TRANSPOSE of the layout above (x' = m[0]*x + m[1]*y + m[2]*z + m[3]): what the
+                                  * storage of the reference's `world_view_transform` holds -- a `.transpose(0, 1)` VIEW of the row-major
+                                  * w2c (gs_renderer.py:662-664) -- so that binding needs no `.contiguous()` copy kernel per render */
+#define GSR_VIEW_PROJMATRIX_T 2  /* the same for projmatrix */
+#define GSR_VIEW_NO_BACKWARD 4   /* no gsr_backward will follow this forward (inference): the backward's accumulators are not prepared */
 
 /* Scratch allocator: resize(ctx, bytes) must return a device pointer, 256-byte aligned, to
  * at least `bytes` bytes that stay alive until the matching backward has run. */
@@ -87,11 +94,15 @@ typedef struct GsrStats {
                                  * from the previous call (+25 %) so that nothing waits for the host; the backward needs it */
     int64_t seg_shift;          /* log2 of the depth-segment length (6..8) the forward cut the tile lists with; the backward
                                  * walks the same segments */
+    int64_t bwd_prepared;       /* 1: the forward has cleared the backward's per-Gaussian accumulators inside `geom` (on a second
+                                 * stream, while its compositing runs) -- gsr_backward then neither allocates `tmp` nor clears
+                                 * anything. One-shot: a caller that runs a SECOND backward from the same forward state must pass
+                                 * 0 (the first one has accumulated into them); 0 also without GsrStats or under NO_BACKWARD */
 } GsrStats;
 
-/* Bumped whenever a struct of this header changes size or meaning (GsrStats grew in 3). A caller built against another
+/* Bumped whenever a struct of this header changes size or meaning (GsrStats grew in 3 and 4, GsrView.reserved became flags in 4). A caller built against another
  * value must not call the library: dreamgaussian_amd/_lib.py checks gsr_abi_version() at load. */
-#define GSR_ABI_VERSION 3
+#define GSR_ABI_VERSION 4
 int gsr_abi_version(void);
 
 /* Forward.

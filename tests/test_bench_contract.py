@@ -60,3 +60,22 @@ def test_committed_traffic_file_uses_the_calibrated_read_factors():
     assert rb["read_factor"] == 1.0 and abs(rb["hbm_bytes"] - (rb["read_bytes_raw"] + rb["write_bytes"])) < 1.0
     k6 = doc["1M-800-sh3/blob"]["preprocess_bwd<false, false>"]
     assert k6["read_factor"] == 2.0
+
+
+def test_order_morton_permutes_the_render_inputs():
+    """`bench.py --order morton` must hand the RENDER step a permuted scene (round 3 permuted it in run_sds only and the
+    render lines stamped "order": "morton" measured the given order). build_inputs is what both step kinds call."""
+    import torch
+    wl = dict(N=3000, deg=0, W=64, H=64)
+    dev = torch.device("cpu")
+    given, _, _, _ = bench.build_inputs(wl, "blob", dev, 0.0)
+    mort, _, _, _ = bench.build_inputs(wl, "blob", dev, 0.0, "morton")
+    assert not torch.equal(given["means3D"], mort["means3D"])
+    # the same Gaussians, rows moved together
+    from dreamgaussian_amd.densify import morton_order
+    perm = morton_order(given["means3D"]).long()
+    for k in given:
+        assert torch.equal(given[k][perm], mort[k])
+    # and main() routes a.order into it for the render step
+    src = open(bench.__file__).read()
+    assert src.count("build_inputs(wl, a.kind, dev, azimuth, a.order)") == 2
