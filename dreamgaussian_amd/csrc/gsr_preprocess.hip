@@ -126,9 +126,12 @@ __device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, flo
     }
 }
 
-// Stage `cnt` SH rows (each 3K floats, contiguous in HBM) into LDS with pitch 3K+1.
+// Stage `cnt` SH rows (each 3K floats, contiguous in HBM) into LDS with pitch 3K+1. `rowlive[r]` = 0: nobody will read row r
+// (a Gaussian no pixel gradient reached, three quarters of a dense scene) -- its 192 bytes are not fetched: the request goes to
+// the batch's first vector instead (one address for all such lanes, a cache hit; the loads stay branch-free and in flight
+// together) and nothing is written to LDS.
 __device__ __forceinline__ void stage_rows_in(const float* __restrict__ src, float* lds,
-                                              int cnt, int rowlen) {
+                                              int cnt, int rowlen, const uint8_t* rowlive) {
     const int total = cnt * rowlen;
     const int pitch = rowlen + 1;
     if ((rowlen & 3) == 0) {
@@ -139,15 +142,17 @@ __device__ __forceinline__ void stage_rows_in(const float* __restrict__ src, flo
         const int nvec = total / 4, stride = blockDim.x;
         for (int i0 = threadIdx.x; i0 < nvec; i0 += stride * STAGE_U) {
             float4 v[STAGE_U];
+            bool keep[STAGE_U];
 #pragma unroll
             for (int u = 0; u < STAGE_U; ++u) {
-                const int i = i0 + u * stride;
-                if (i < nvec) v[u] = s4[i];
+                const int i = min(i0 + u * stride, nvec - 1);
+                keep[u] = rowlive[(4 * i) / rowlen] != 0;
+                v[u] = s4[keep[u] ? i : 0];
             }
 #pragma unroll
             for (int u = 0; u < STAGE_U; ++u) {
                 const int i = i0 + u * stride;
-                if (i < nvec) {
+                if (i < nvec && keep[u]) {
                     const int e = 4 * i, row = e / rowlen, col = e - row * rowlen;  // rowlen%4==0: no row straddle
                     float* d = lds + row * pitch + col;
                     d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
@@ -157,25 +162,26 @@ __device__ __forceinline__ void stage_rows_in(const float* __restrict__ src, flo
     } else {
         for (int e = threadIdx.x; e < total; e += blockDim.x) {
             const int row = e / rowlen, col = e - row * rowlen;
-            lds[row * pitch + col] = src[e];
+            if (rowlive[row]) lds[row * pitch + col] = src[e];
         }
     }
 }
 
 // split rows: element e of a row lives in `dc` (e < 3) or in `rest` (e >= 3): DreamGaussian's two feature tensors
 __device__ __forceinline__ void stage_rows_in_split(const float* __restrict__ dc, const float* __restrict__ rest, float* lds,
-                                                    int cnt, int rowlen) {
+                                                    int cnt, int rowlen, const uint8_t* rowlive) {
     const int pitch = rowlen + 1, restlen = rowlen - 3;
     for (int e = threadIdx.x; e < cnt * rowlen; e += blockDim.x) {
         const int row = e / rowlen, col = e - row * rowlen;
-        lds[row * pitch + col] = col < 3 ? dc[row * 3 + col] : rest[(size_t)row * restlen + (col - 3)];
+        if (rowlive[row]) lds[row * pitch + col] = col < 3 ? dc[row * 3 + col] : rest[(size_t)row * restlen + (col - 3)];
     }
 }
 __device__ __forceinline__ void stage_rows_out_split(float* __restrict__ dc, float* __restrict__ rest, const float* lds,
-                                                     int cnt, int rowlen, int accumulate) {
+                                                     int cnt, int rowlen, int accumulate, const uint8_t* rowlive) {
     const int pitch = rowlen + 1, restlen = rowlen - 3;
     for (int e = threadIdx.x; e < cnt * rowlen; e += blockDim.x) {
         const int row = e / rowlen, col = e - row * rowlen;
+        if (accumulate && !rowlive[row]) continue;        // + 0: nothing to add
         const float v = lds[row * pitch + col];
         float* o = col < 3 ? dc + (row * 3 + col) : rest + ((size_t)row * restlen + (col - 3));
         *o = accumulate ? *o + v : v;
@@ -183,13 +189,14 @@ __device__ __forceinline__ void stage_rows_out_split(float* __restrict__ dc, flo
 }
 
 __device__ __forceinline__ void stage_rows_out(float* __restrict__ dst, const float* lds,
-                                               int cnt, int rowlen, int accumulate) {
+                                               int cnt, int rowlen, int accumulate, const uint8_t* rowlive) {
     const int total = cnt * rowlen;
     const int pitch = rowlen + 1;
     if ((rowlen & 3) == 0) {
         float4* d4 = reinterpret_cast<float4*>(dst);
         for (int i = threadIdx.x; i < total / 4; i += blockDim.x) {
             const int e = 4 * i, row = e / rowlen, col = e - row * rowlen;
+            if (accumulate && !rowlive[row]) continue;    // a later view of a batch adds nothing to this row: neither read nor written
             const float* s = lds + row * pitch + col;
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
             if (accumulate) o = d4[i];
@@ -198,6 +205,7 @@ __device__ __forceinline__ void stage_rows_out(float* __restrict__ dst, const fl
     } else {
         for (int e = threadIdx.x; e < total; e += blockDim.x) {
             const int row = e / rowlen, col = e - row * rowlen;
+            if (accumulate && !rowlive[row]) continue;
             const float v = lds[row * pitch + col];
             dst[e] = accumulate ? dst[e] + v : v;
         }
@@ -864,7 +872,10 @@ gsr_preprocess_bwd(ViewTab tab, int first_view, int B /* B == 1: the view tab.v[
         if (c < 35) camf[MULTI ? v : 0][c] = c < 16 ? cv.view[cam_index(c, cv.mat_t & 1)] : (c < 32 ? cv.proj[cam_index(c - 16, cv.mat_t & 2)] : cv.campos[c - 32]);
     }
     lds_barrier();
-    for (int base = blockIdx.x * blockDim.x; base < N; base += gridDim.x * blockDim.x) {
+    __shared__ uint8_t rowlive_buf[2][256];               // [batch parity][row]: a batch's stage_rows_out may still read while the next one writes
+    int parity = 0;
+    for (int base = blockIdx.x * blockDim.x; base < N; base += gridDim.x * blockDim.x, parity ^= 1) {
+        uint8_t* rowlive = rowlive_buf[parity];
         const int cnt = min((int)blockDim.x, N - base);
         const int idx = base + threadIdx.x;
         // this batch's per-Gaussian inputs: requested first, branch-free (index clamped), in flight while the SH rows are staged
@@ -888,10 +899,17 @@ gsr_preprocess_bwd(ViewTab tab, int first_view, int B /* B == 1: the view tab.v[
             const float4* gp = reinterpret_cast<const float4*>(g2d + r0 * GSR_G2D_STRIDE);
             vin0.g0 = gp[0]; vin0.g1 = gp[1]; vin0.g2 = gp[2];
         }
+        // A Gaussian no pixel gradient reached (hidden behind the stop, or outside every blended pixel's support: 73 % of the 1M blob,
+        // 94 % of the trained-like scene) has an all-zero row of 2D gradients: every output of this kernel is zero for it, and its SH
+        // row -- 192 of the 524 bytes the kernel moves per Gaussian at degree 3 -- is not read at all.
+        const bool touched = ((__float_as_uint(vin0.g0.x) | __float_as_uint(vin0.g0.y) | __float_as_uint(vin0.g0.z) | __float_as_uint(vin0.g0.w) |
+                               __float_as_uint(vin0.g1.x) | __float_as_uint(vin0.g1.y) | __float_as_uint(vin0.g1.z) | __float_as_uint(vin0.g1.w) |
+                               __float_as_uint(vin0.g2.x) | __float_as_uint(vin0.g2.y)) & 0x7fffffffu) != 0u;
         if (stage) {
+            rowlive[threadIdx.x] = (idx < N && radius0 > 0 && touched) ? 1 : 0;     // (the previous batch's stage_rows_out reads the other copy)
             lds_barrier();
-            if (shs_rest) stage_rows_in_split(shs + (size_t)base * 3, shs_rest + (size_t)base * (rowlen - 3), shbuf, cnt, rowlen);
-            else stage_rows_in(shs + (size_t)base * rowlen, shbuf, cnt, rowlen);
+            if (shs_rest) stage_rows_in_split(shs + (size_t)base * 3, shs_rest + (size_t)base * (rowlen - 3), shbuf, cnt, rowlen, rowlive);
+            else stage_rows_in(shs + (size_t)base * rowlen, shbuf, cnt, rowlen, rowlive);
             lds_barrier();
         }
         K6Out out, cur;
@@ -923,7 +941,7 @@ gsr_preprocess_bwd(ViewTab tab, int first_view, int B /* B == 1: the view tab.v[
                     vin.g0 = gp[0]; vin.g1 = gp[1]; vin.g2 = gp[2];
                 }
             }
-            const bool live = (idx < N) && (radius > 0);
+            const bool live = (idx < N) && (radius > 0) && (MULTI || touched);   // (MULTI: nothing is staged, the views differ)
             k6_gaussian<RAW>(vc, camf[MULTI ? v - first_view : 0], idx, N, K, live, in, vin, shs, cov3D_precomp, dL_dshs, stage, myrow, accumulate, sh_in_regs, cur);
             if (idx < N) { float* m2 = dL_dmeans2D + ((size_t)v * N + idx) * 3; m2[0] = cur.dm2[0]; m2[1] = cur.dm2[1]; m2[2] = 0.f; }
             // first pass (the last view): 0 + x = x exactly
@@ -961,8 +979,8 @@ gsr_preprocess_bwd(ViewTab tab, int first_view, int B /* B == 1: the view tab.v[
         }
         if (stage) {
             lds_barrier();
-            if (shs_rest) stage_rows_out_split(dL_dshs + (size_t)base * 3, dL_dshs_rest + (size_t)base * (rowlen - 3), shbuf, cnt, rowlen, accumulate);
-            else stage_rows_out(dL_dshs + (size_t)base * rowlen, shbuf, cnt, rowlen, accumulate);
+            if (shs_rest) stage_rows_out_split(dL_dshs + (size_t)base * 3, dL_dshs_rest + (size_t)base * (rowlen - 3), shbuf, cnt, rowlen, accumulate, rowlive);
+            else stage_rows_out(dL_dshs + (size_t)base * rowlen, shbuf, cnt, rowlen, accumulate, rowlive);
         }
     }
 }
