@@ -33,6 +33,13 @@ __device__ __forceinline__ float splat_power(float qa, float qb, float qc, float
 
 #define GSR_RB 64   // list entries fetched per wave per round
 
+// Two transcendentals of independent inputs in ADJACENT issue slots. Between plain VALU instructions a v_exp_f32 / v_rcp_f32 costs
+// ~16 cycles of a SIMD's issue, behind another transcendental ~8 (tools/valu_rates.hip, profiles/r04_valu_rates.txt), and the
+// scheduler spreads them out when left alone. The trailing s_nop covers the trans -> use wait state the hazard recognizer cannot
+// see inside the asm.
+#define GSR_TRANS_PAIR(op, d0, d1, s0, s1)                                                       \
+        asm(op " %0, %2\n\t" op " %1, %3\n\ts_nop 0" : "=&v"(d0), "=&v"(d1) : "v"(s0), "v"(s1));
+
 // agent-scope relaxed accesses (global_load / global_store ... sc1): the hint words other workgroups of the SAME launch
 // read; they carry no ordering and need none (every value ever stored at such an address is a valid hint or a tag mismatch)
 __device__ __forceinline__ uint32_t hint_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -46,11 +53,9 @@ __device__ __forceinline__ void hint_store64(unsigned long long* p, unsigned lon
 // is not blended. Both kernels run the SAME sequence of roundings on (T', C', ...) -- the combine's walk
 // reproduces the segment kernel's numbers bit for bit up to its own stopping point.
 //   ea = x y qa qb | eb = qc opac r g | ec = b depth - - ; kpos = 1-based list position
-#define GSR_COMPOSITE(ea, eb, ec, kpos, valid, gate, keepT)                                     \
+#define GSR_COMPOSITE_G(ea, eb, ec, power, Gv, kpos, valid, gate, keepT)                         \
     {                                                                                          \
-        const float dx = ea.x - pxf, dy = ea.y - pyf;                                          \
-        const float power = splat_power(ea.z, ea.w, eb.x, dx, dy);            /* log2 units */ \
-        const float alpha = fminf(0.99f, eb.y * fast_exp2(power));                             \
+        const float alpha = fminf(0.99f, eb.y * Gv);                                           \
         const bool ok = (valid) && !done && (power <= 0.f) && (alpha >= (1.0f / 255.0f));      \
         const float test_T = __fmul_rn(T, 1.f - alpha);                                        \
         const bool stop = ok && (__fmul_rn(gate, test_T) < 0.0001f);                           \
@@ -61,6 +66,19 @@ __device__ __forceinline__ void hint_store64(unsigned long long* p, unsigned lon
         T = (keepT ? acc : ok) ? test_T : T;                                                   \
         last = acc ? (kpos) : last;                                                            \
         done = done || stop;                                                                   \
+    }
+// Two consecutive list entries: both exponents first, their two v_exp_f32 in adjacent issue slots (GSR_TRANS_PAIR), then the two
+// dependent updates in list order; `between` runs after the first (the callers request the next records there). The arithmetic
+// per (pixel, entry) is the macro above in every kernel that blends.
+#define GSR_COMPOSITE2(e0a, e0b, e0c, k0, v0, e1a, e1b, e1c, k1, v1, gate, keepT, between)       \
+    {                                                                                          \
+        const float pw0_ = splat_power(e0a.z, e0a.w, e0b.x, e0a.x - pxf, e0a.y - pyf);         /* log2 units */ \
+        const float pw1_ = splat_power(e1a.z, e1a.w, e1b.x, e1a.x - pxf, e1a.y - pyf);         \
+        float G0_, G1_;                                                                        \
+        GSR_TRANS_PAIR("v_exp_f32", G0_, G1_, pw0_, pw1_)                                      \
+        GSR_COMPOSITE_G(e0a, e0b, e0c, pw0_, G0_, k0, v0, gate, keepT)                          \
+        between                                                                                \
+        GSR_COMPOSITE_G(e1a, e1b, e1c, pw1_, G1_, k1, v1, gate, keepT)                          \
     }
 
 // =========================================================================================
@@ -209,10 +227,10 @@ gsr_render_fwd_seg(const uint4* __restrict__ items, const uint32_t* __restrict__
                 // two entries per trip, both unconditional (the second is masked off on an odd tail) so
                 // that the body stays one basic block and the LDS reads are issued ahead of their use
                 for (int j = 0; j < nhit; j += 2) {       // slots nhit, nhit+1 are padding: read, masked
-                    const float4 e1a = sa[j + 1], e1b = sb[j + 1], e1c = sc[j + 1];   // in flight during entry j
-                    GSR_COMPOSITE(e0a, e0b, e0c, __float_as_uint(e0c.z), true, 1.f, false)
-                    e0a = sa[j + 2]; e0b = sb[j + 2]; e0c = sc[j + 2];               // in flight during entry j+1
-                    GSR_COMPOSITE(e1a, e1b, e1c, __float_as_uint(e1c.z), j + 1 < nhit, 1.f, false)
+                    const float4 e1a = sa[j + 1], e1b = sb[j + 1], e1c = sc[j + 1];
+                    const uint32_t k0 = __float_as_uint(e0c.z);
+                    GSR_COMPOSITE2(e0a, e0b, e0c, k0, true, e1a, e1b, e1c, __float_as_uint(e1c.z), j + 1 < nhit, 1.f, false,
+                                   e0a = sa[j + 2]; e0b = sb[j + 2]; e0c = sc[j + 2];)   // in flight during entry j+1
                 }
                 wave_lds_handoff();                       // reads above precede the next round's writes
             } else {
@@ -252,10 +270,9 @@ gsr_render_fwd_seg(const uint4* __restrict__ items, const uint32_t* __restrict__
 #pragma unroll
                     for (int b = 0; b < 8; b += 2) {
                         if (jb + b < nmax) {              // wave-uniform
-                            const float4 e1a = sa[slot[b + 1]], e1b = sb[slot[b + 1]], e1c = sc[slot[b + 1]];   // in flight during entry b
-                            GSR_COMPOSITE(e0a, e0b, e0c, pos1 + slot[b], jb + b < nmine, 1.f, false)
-                            if (b + 2 < 8) { e0a = sa[slot[b + 2]]; e0b = sb[slot[b + 2]]; e0c = sc[slot[b + 2]]; }   // in flight during entry b+1
-                            GSR_COMPOSITE(e1a, e1b, e1c, pos1 + slot[b + 1], jb + b + 1 < nmine, 1.f, false)
+                            const float4 e1a = sa[slot[b + 1]], e1b = sb[slot[b + 1]], e1c = sc[slot[b + 1]];
+                            GSR_COMPOSITE2(e0a, e0b, e0c, pos1 + slot[b], jb + b < nmine, e1a, e1b, e1c, pos1 + slot[b + 1], jb + b + 1 < nmine, 1.f, false,
+                                           if (b + 2 < 8) { e0a = sa[slot[b + 2]]; e0b = sb[slot[b + 2]]; e0c = sc[slot[b + 2]]; })   // in flight during entry b+1
                         }
                     }
                 }
@@ -416,10 +433,10 @@ gsr_render_fwd_serial(const uint32_t* __restrict__ tile_off, const SplatRec* __r
                     wave_lds_handoff();
                     float4 e0a = sa[0], e0b = sb[0], e0c = sc[0];
                     for (int j = 0; j < nhit; j += 2) {       // slots nhit, nhit+1 are padding: read, masked
-                        const float4 e1a = sa[j + 1], e1b = sb[j + 1], e1c = sc[j + 1];   // in flight during entry j
-                        GSR_COMPOSITE(e0a, e0b, e0c, __float_as_uint(e0c.z), true, 1.f, true)
-                        e0a = sa[j + 2]; e0b = sb[j + 2]; e0c = sc[j + 2];               // in flight during entry j+1
-                        GSR_COMPOSITE(e1a, e1b, e1c, __float_as_uint(e1c.z), j + 1 < nhit, 1.f, true)
+                        const float4 e1a = sa[j + 1], e1b = sb[j + 1], e1c = sc[j + 1];
+                        const uint32_t k0 = __float_as_uint(e0c.z);
+                        GSR_COMPOSITE2(e0a, e0b, e0c, k0, true, e1a, e1b, e1c, __float_as_uint(e1c.z), j + 1 < nhit, 1.f, true,
+                                       e0a = sa[j + 2]; e0b = sb[j + 2]; e0c = sc[j + 2];)   // in flight during entry j+1
                     }
                     wave_lds_handoff();                       // reads above precede the next round's writes
                 }
@@ -463,10 +480,9 @@ gsr_render_fwd_serial(const uint32_t* __restrict__ tile_off, const SplatRec* __r
 #pragma unroll
                         for (int b = 0; b < 8; b += 2) {
                             if (jb + b < nmax) {              // wave-uniform
-                                const float4 e1a = sa[slot[b + 1]], e1b = sb[slot[b + 1]], e1c = sc[slot[b + 1]];   // in flight during entry b
-                                GSR_COMPOSITE(e0a, e0b, e0c, pos1 + slot[b], jb + b < nmine, 1.f, true)
-                                if (b + 2 < 8) { e0a = sa[slot[b + 2]]; e0b = sb[slot[b + 2]]; e0c = sc[slot[b + 2]]; }   // in flight during entry b+1
-                                GSR_COMPOSITE(e1a, e1b, e1c, pos1 + slot[b + 1], jb + b + 1 < nmine, 1.f, true)
+                                const float4 e1a = sa[slot[b + 1]], e1b = sb[slot[b + 1]], e1c = sc[slot[b + 1]];
+                                GSR_COMPOSITE2(e0a, e0b, e0c, pos1 + slot[b], jb + b < nmine, e1a, e1b, e1c, pos1 + slot[b + 1], jb + b + 1 < nmine, 1.f, true,
+                                               if (b + 2 < 8) { e0a = sa[slot[b + 2]]; e0b = sb[slot[b + 2]]; e0c = sc[slot[b + 2]]; })   // in flight during entry b+1
                             }
                         }
                     }
@@ -549,9 +565,9 @@ template __global__ void gsr_render_fwd_serial<true>(const uint32_t*, const Spla
         float4 e0a = sa[0], e0b = sb[0], e0c = sc[0];                                                      \
         for (int j = 0; j < nhit; j += 2) {                                                                \
             const float4 e1a = sa[j + 1], e1b = sb[j + 1], e1c = sc[j + 1];                                \
-            GSR_COMPOSITE(e0a, e0b, e0c, __float_as_uint(e0c.z), true, gate, true)                         \
-            e0a = sa[j + 2]; e0b = sb[j + 2]; e0c = sc[j + 2];                                             \
-            GSR_COMPOSITE(e1a, e1b, e1c, __float_as_uint(e1c.z), j + 1 < nhit, gate, true)                 \
+            const uint32_t k0 = __float_as_uint(e0c.z);                                                    \
+            GSR_COMPOSITE2(e0a, e0b, e0c, k0, true, e1a, e1b, e1c, __float_as_uint(e1c.z), j + 1 < nhit, gate, true, \
+                           e0a = sa[j + 2]; e0b = sb[j + 2]; e0c = sc[j + 2];)                             \
         }                                                                                                  \
         wave_lds_handoff();                                                                                \
     }
@@ -806,7 +822,8 @@ gsr_render_fwd_fix(const uint2* __restrict__ walk_items, const unsigned long lon
     }
 }
 #undef GSR_WALK_SEGMENT
-#undef GSR_COMPOSITE
+#undef GSR_COMPOSITE2
+#undef GSR_COMPOSITE_G
 
 // =========================================================================================
 // Backward, FRONT TO BACK and depth-segmented.
@@ -886,7 +903,7 @@ __device__ __forceinline__ float row_max_f(float v) {       // every lane of a 1
 }
 // v + (v of the lane eight positions away inside the 16-lane row)
 __device__ __forceinline__ float add_other_half(float v) {
-    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_ROW_ROR(8), 0xf, 0xf, false));
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_ROW_ROR(8), 0xf, 0xf, true));
 }
 // v * 2^e as a two's-complement 64-bit integer (|v * 2^e| < 2^62; exact: the split is done on exactly representable floats)
 __device__ __forceinline__ unsigned long long to_fixed(float v, int e) {
@@ -978,6 +995,10 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
     const float keep_qc = pb.x, keep_op = pb.y;
     for (int q = threadIdx.x; q < (GSR_Q2_ROW << seg_shift); q += 256) acc64[q] = 0ull;
     for (int q = threadIdx.x; q < 4 * 4 * GSR_QL_PITCH / 4; q += 256) reinterpret_cast<uint32_t*>(&qlist[0][0][0])[q] = 0u;   // stale reads stay inside the stage
+    // ... and read FINITE numbers: pass 1 is branch-free, a lane past its quad's list runs the arithmetic on whatever its stale slot
+    // holds with alpha = 0 (0 * garbage must stay 0). A stale list byte is 0 (cleared above) or a slot an earlier round staged a
+    // real record in: slot 0 is the only one that can be read before it was ever written
+    if (lane < 3) stage[wave][lane][0] = make_float4(0.f, 0.f, 0.f, 0.f);
     float4* __restrict__ sa = stage[wave][0];
     float4* __restrict__ sb = stage[wave][1];
     float4* __restrict__ sc = stage[wave][2];
@@ -1031,26 +1052,35 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
     wave_lds_handoff();                                   // ... before pass 1 writes over the table
 
     // ea = x y qa qb | eb = qc opac r g | ec = b depth - - ; kpos = 1-based list position (row-uniform)
-#define GSR_Q2_ENTRY(ea, eb, ec, kpos, valid, kslot)                                             \
-    {                                                                                            \
-        const float dx = ea.x - pxf, dy = ea.y - pyf;                                            \
-        const float power = splat_power(ea.z, ea.w, eb.x, dx, dy);                               \
-        const float G = fast_exp2(power);                                                        \
-        const float alpha = fminf(0.99f, eb.y * G);                                              \
-        const bool ok = (valid) && ((kpos) <= last_contrib) && (power <= 0.f) && (alpha >= (1.0f / 255.0f)); \
-        float m = 0.f, w = 0.f;                           /* stay 0 in lanes that did not blend */ \
-        if (ok) {                                                                                \
-            const float cgi = eb.z * gC0 + eb.w * gC1 + ec.x * gC2 + ec.y * gD + gA;             \
-            const float oma = 1.f - alpha;                                                       \
-            w = alpha * T;                                                                       \
-            const float wc = w * cgi;                                                            \
-            const float dL_dal = T * cgi - (Cg_behind0 - Cgf - wc) * fast_rcp(oma);               \
-            m = (eb.y * dL_dal) * G;                                                             \
+    // Pass 1 is BRANCH-FREE and handles two list entries per trip: what does not depend on the running (T, Cgf) -- exponent, G,
+    // alpha, 1 / (1 - alpha), the colour dot product -- is computed for both first, so that the transcendentals issue back to back
+    // (v_exp_f32 / v_rcp_f32 cost ~16 cycles each between plain VALU instructions and ~8 behind one another: tools/valu_rates.hip),
+    // and a lane that does not blend an entry carries a_eff = 0 through the same arithmetic (alpha = 0, 1 - alpha = 1, w = m = 0
+    // exactly) instead of sitting out an exec-masked region with its s_and_saveexec / s_cbranch_execz pair.
+#define GSR_Q2_POWER(ea, eb, pw_)                                                                \
+        const float pw_ = splat_power(ea.z, ea.w, eb.x, ea.x - pxf, ea.y - pyf);
+#define GSR_Q2_HEAD(eb, ec, pw_, G_, kpos, valid, ae_, al_, om_, cgi_)                            \
+        float ae_, al_, om_, cgi_;                                                                    \
+        {                                                                                        \
+            const float araw = eb.y * G_;                                                        \
+            /* alpha = min(0.99, araw) >= 1/255  <=>  araw >= 1/255: the forward's decision, bit for bit */ \
+            /* (plain `&`: no short-circuit, or the compiler rebuilds the exec-masked regions around the exponential) */ \
+            const bool ok = (bool)((int)(valid) & (int)((kpos) <= last_contrib) & (int)(pw_ <= 0.f) & (int)(araw >= (1.0f / 255.0f))); \
+            ae_ = ok ? araw : 0.f;                                                               \
+            al_ = __builtin_amdgcn_fmed3f(ae_, 0.f, 0.99f);   /* min(0.99, a_eff), a_eff >= 0: one instruction, no canonicalising v_max in front */ \
+            om_ = 1.f - al_;                                                                     \
+            cgi_ = eb.z * gC0 + eb.w * gC1 + ec.x * gC2 + ec.y * gD + gA;                        \
+        }
+#define GSR_Q2_TAIL(ae_, al_, om_, rc_, cgi_, kslot)                                             \
+        {                                                                                        \
+            const float w = al_ * T;                                                             \
+            const float wc = w * cgi_;                                                           \
+            const float dL_dal = T * cgi_ - (Cg_behind0 - Cgf - wc) * rc_;                       \
+            const float m = dL_dal * ae_;                     /* (opacity * dL/dalpha) * G */     \
             Cgf += wc;                                                                           \
-            T *= oma;                                                                            \
-        }                                                                                        \
-        if (valid) *reinterpret_cast<float2*>(mw1 + (kslot) * GSR_Q2_KSTRIDE) = make_float2(m, w); \
-    }
+            T *= om_;                                                                            \
+            *reinterpret_cast<float2*>(mw1 + (kslot) * GSR_Q2_KSTRIDE) = make_float2(m, w);       \
+        }
 
     for (uint32_t pos0 = seg_lo; pos0 < seg_hi; pos0 += GSR_RB) {   // 0-based positions pos0 .. pos0+63
         const uint32_t i = pos0 + lane;
@@ -1099,14 +1129,26 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
             uint32_t slot[GSR_Q2_BATCH];
 #pragma unroll
             for (int b = 0; b < GSR_Q2_BATCH; ++b) slot[b] = ((b < 4 ? sl.x : sl.y) >> (8 * (b & 3))) & 0xffu;
+            // the records of a pair are dead once its heads are computed: the next pair's are requested into the same registers right
+            // there and travel during the pair's tails (no second register set: the kernel sits at 124 of 128 VGPRs)
             float4 ea = sa[slot[0]], eb = sb[slot[0]], ec = sc[slot[0]];
+            float4 fa = sa[slot[1]], fb = sb[slot[1]], fc = sc[slot[1]];
 #pragma unroll
-            for (int b = 0; b < GSR_Q2_BATCH; ++b) {
-                if (jb + b < nmax) {                      // wave-uniform
-                    float4 na = ea, nb = eb, nc = ec;
-                    if (b + 1 < GSR_Q2_BATCH) { na = sa[slot[b + 1]]; nb = sb[slot[b + 1]]; nc = sc[slot[b + 1]]; }   // in flight during entry b
-                    GSR_Q2_ENTRY(ea, eb, ec, pos0 + slot[b] + 1u, jb + b < nmine, b)
-                    ea = na; eb = nb; ec = nc;
+            for (int b = 0; b < GSR_Q2_BATCH; b += 2) {
+                if (jb + b < nmax) {                      // wave-uniform; the second entry of the pair may lie past every list: masked
+                    GSR_Q2_POWER(ea, eb, pw0)
+                    GSR_Q2_POWER(fa, fb, pw1)
+                    float G0, G1, rc0, rc1;
+                    GSR_TRANS_PAIR("v_exp_f32", G0, G1, pw0, pw1)
+                    GSR_Q2_HEAD(eb, ec, pw0, G0, pos0 + slot[b] + 1u, jb + b < nmine, ae0, al0, om0, cgi0)
+                    GSR_Q2_HEAD(fb, fc, pw1, G1, pos0 + slot[b + 1] + 1u, jb + b + 1 < nmine, ae1, al1, om1, cgi1)
+                    if (b + 2 < GSR_Q2_BATCH) {
+                        ea = sa[slot[b + 2]]; eb = sb[slot[b + 2]]; ec = sc[slot[b + 2]];
+                        fa = sa[slot[b + 3]]; fb = sb[slot[b + 3]]; fc = sc[slot[b + 3]];
+                    }
+                    GSR_TRANS_PAIR("v_rcp_f32", rc0, rc1, om0, om1)
+                    GSR_Q2_TAIL(ae0, al0, om0, rc0, cgi0, b)
+                    GSR_Q2_TAIL(ae1, al1, om1, rc1, cgi1, b + 1)
                 }
             }
             wave_lds_handoff();
@@ -1155,7 +1197,9 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
             wave_lds_handoff();                           // pass 2's reads precede the next batch's / round's writes
         }
     }
-#undef GSR_Q2_ENTRY
+#undef GSR_Q2_POWER
+#undef GSR_Q2_HEAD
+#undef GSR_Q2_TAIL
     // ---- flush: fixed point -> float, raw moments -> the accumulator layout K6 reads, coalesced global atomics
     lds_barrier();
     float out[GSR_G2D_STRIDE];
