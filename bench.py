@@ -494,6 +494,9 @@ def main():
         if sds is not None:
             out["sds_step"] = sds
         print(json.dumps(out), flush=True)
+    if views.gather_fallbacks:
+        raise SystemExit(f"bench.py: the gather of the rendered views fell back to all_gather {views.gather_fallbacks} times "
+                         f"(world x the bytes): the line above does not measure the intended exchange")
     if world > 1:
         dist.destroy_process_group()
 

@@ -19,7 +19,7 @@ GSR_VIEW_VIEWMATRIX_T, GSR_VIEW_PROJMATRIX_T, GSR_VIEW_NO_BACKWARD = 1, 2, 4   #
 EXPORTS = ("gsr_forward", "gsr_backward", "gsr_forward_views", "gsr_backward_views", "gsr_mark_visible", "gsr_dist2", "gsr_extract_fields", "gsr_densify_stats",
            "gsr_adam_step", "gsr_mask_compact", "gsr_gather_rows", "gsr_concat_rows",
            "gsr_profile_enable", "gsr_profile_read", "gsr_profile_reset",
-           "gsr_geom_bytes", "gsr_img_bytes", "gsr_last_error", "gsr_version", "gsr_abi_version")
+           "gsr_geom_bytes", "gsr_img_bytes", "gsr_last_error", "gsr_version", "gsr_abi_version", "gsr_testing_override")
 
 
 class GsrView(C.Structure):
@@ -126,6 +126,8 @@ def load() -> C.CDLL:
         lib.gsr_profile_read.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float),
                                          C.POINTER(C.c_int)]
         lib.gsr_last_error.restype = C.c_char_p
+        lib.gsr_testing_override.restype = C.c_int
+        lib.gsr_testing_override.argtypes = [C.c_char_p, i32]
         lib.gsr_version.restype = C.c_char_p
         _lib = lib
         return lib

@@ -219,18 +219,21 @@ int check_inputs(int N, int K, const GsrView* v, const float* means3D, const flo
     return 0;
 }
 
-// Largest tile grid whose per-tile counters a workgroup of K1 / the scatter keeps in LDS (64 KiB); GSR_HIST_MAX=<tiles> for A/B runs
+// ---- test hooks (gsr_testing_override, include/gsr.h): choices the library makes from the problem shape, forced by a TEST or an
+// A/B measurement through an explicit call. Nothing here is read from the process environment: two of them (forward mode, segment
+// length) decide where the per-pixel sums are cut, i.e. the rounding of the results, and that must not depend on who started the
+// process. -1 = the library decides.
+enum { OV_FWD_MODE, OV_SEG_SHIFT, OV_FWD_LISTS, OV_FWD_HINTS, OV_SPECULATE, OV_HIST_MAX, OV_K1_GRID, OV_SCATTER_GRID, OV_FWD_GRID, OV_K6_GRID, OV_COUNT };
+const char* const kOvNames[OV_COUNT] = {"fwd_mode", "seg_shift", "fwd_lists", "fwd_hints", "speculate", "hist_max", "k1_grid", "scatter_grid", "fwd_grid", "k6_grid"};
+std::atomic<int> g_ov[OV_COUNT] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
+inline int ov(int k) { return g_ov[k].load(std::memory_order_relaxed); }
+
+// Largest tile grid whose per-tile counters a workgroup of K1 / the scatter keeps in LDS (64 KiB)
 static int hist_lds_max_tiles() {
-    static const int v = [] { const char* e = getenv("GSR_HIST_MAX"); const int t = e ? atoi(e) : 16384; return t < 0 ? 0 : (t > 16384 ? 16384 : t); }();
-    return v;
+    const int t = ov(OV_HIST_MAX);
+    return t < 0 ? 16384 : (t > 16384 ? 16384 : t);
 }
 
-// Environment switches kept for same-box A/B measurements (defaults = the shipped path), read at every call:
-//   GSR_FWD=q|block       segment forward with quad lists / 8x8 block lists (default: chosen per view from its statistics)
-//   GSR_SEG_SHIFT=6..8    log2 of the segment length in list positions (default: from N and the tile count, below)
-//   GSR_SPECULATE=0       gsr_forward waits for the instance count before binning (default: speculative, see forward_impl)
-//   GSR_WAIT=event        that wait through hipEventSynchronize instead of the pinned arrival flag
-//   GSR_FWD_MODE=seg|seq  depth-segmented forward / serial walk (default: by the per-view tile count, below)
 // How the forward composites. Depth-segmented (K5a + K5b + K5c) where a view has few tiles: there the serial walk of a
 // tile's list leaves the chip empty (a 512^2 view has ~350 non-empty tiles = 1.4 waves per SIMD, a 256^2 view 0.6) and
 // the forward is a latency chain. The serial walk (K5b alone) where a view fills the chip: every vector instruction of the
@@ -243,7 +246,8 @@ static int hist_lds_max_tiles() {
 // call (a view of a batch renders bit-identically to its single-view call): the per-view tile count only.
 bool fwd_sequential_for(int N, int tiles_per_view) {
     (void)N;
-    if (const char* e = getenv("GSR_FWD_MODE")) { if (strcmp(e, "seq") == 0) return true; if (strcmp(e, "seg") == 0) return false; }
+    if (ov(OV_FWD_MODE) == 1) return true;                // test hook: 1 = serial walk, 2 = depth-segmented
+    if (ov(OV_FWD_MODE) == 2) return false;
     return tiles_per_view >= 1024;
 }
 // Segment length of one call: the backward's unit of work in both modes (it prefers 64 entries: 0.219 / 0.233 / 0.300 ms
@@ -251,26 +255,16 @@ bool fwd_sequential_for(int N, int tiles_per_view) {
 // entries (250k-512^2: K5a 97 -> 75 us) and short ones want the finest cut (5k-256^2: 16 / 21 / 32 us). From N and the
 // per-view tile count only, for the reason above.
 int seg_shift_for(int N, int tiles_per_view) {
-    if (const char* e = getenv("GSR_SEG_SHIFT")) { const int s = atoi(e); if (s >= 6 && s <= 8) return s; }
+    if (ov(OV_SEG_SHIFT) >= 6 && ov(OV_SEG_SHIFT) <= 8) return ov(OV_SEG_SHIFT);   // test hook
     if (fwd_sequential_for(N, tiles_per_view)) return 6;
     const double x = 4.0 * (double)N / (double)(tiles_per_view > 0 ? tiles_per_view : 1);   // ~ list length of an average tile
     return x <= 512.0 ? 6 : 7;
 }
-// forward compositing kernel: 0 = per view (finish_impl), 1 = 8x8 block lists, 2 = quad lists
-int fwd_kernel_env() {
-    const char* e = getenv("GSR_FWD");
-    if (e && strcmp(e, "q") == 0) return 2;
-    if (e && strcmp(e, "block") == 0) return 1;
-    return 0;
-}
-//   GSR_FWD_HINTS=off|skipall   segment forward: read no hints (every segment composited) / TEST: skip every segment behind the
-//                         first of a tile, so that the chaining kernel has to walk them all (same results, bit for bit)
-int fwd_hint_env() {
-    const char* e = getenv("GSR_FWD_HINTS");
-    if (e && strcmp(e, "off") == 0) return 1;
-    if (e && strcmp(e, "skipall") == 0) return 2;
-    return 0;
-}
+// forward compositing kernel: 0 = per view (finish_impl), 1 = 8x8 block lists, 2 = quad lists (test hook "fwd_lists")
+int fwd_kernel_env() { const int v = ov(OV_FWD_LISTS); return v == 1 || v == 2 ? v : 0; }
+// segment forward's hints: 0 = on, 1 = off (every segment composited), 2 = TEST: every segment behind a tile's first is skipped, so
+// that the chaining kernel has to walk them all (same results, bit for bit) (test hook "fwd_hints")
+int fwd_hint_env() { const int v = ov(OV_FWD_HINTS); return v == 1 || v == 2 ? v : 0; }
 std::atomic<uint32_t> g_epoch{0x5eed};                  // launch tag of the segment forward's hints
 // launch tag of K1's "counters cleared" flag: process-wide and never repeated, so a stale word in recycled scratch is never it
 std::atomic<unsigned long long> g_k1_epoch{0x6b31000000000000ull ^ ((unsigned long long)(uintptr_t)&g_epoch << 8)};
@@ -311,6 +305,12 @@ extern "C" int gsr_profile_read(int cap, const char** names, float* total_ms, in
 }
 extern "C" const char* gsr_version(void) { return "gsr 0.4 (gfx950, wave64, 16x16 bins / 8x8 wave blocks, depth-segmented forward)"; }
 extern "C" int gsr_abi_version(void) { return GSR_ABI_VERSION; }
+extern "C" int gsr_testing_override(const char* name, int32_t value) {
+    if (!name) return fail(-1, "override name is NULL%s", "");
+    for (int k = 0; k < OV_COUNT; ++k)
+        if (strcmp(name, kOvNames[k]) == 0) { g_ov[k].store(value, std::memory_order_relaxed); return 0; }
+    return fail(-1, "unknown override '%s'", name);
+}
 
 extern "C" size_t gsr_geom_bytes(int32_t N, int32_t H, int32_t W) { return geom_layout(N, H, W).total; }
 // final_T | n_contrib | totals[5] (the five per-pixel sums without background)
@@ -362,8 +362,8 @@ int begin_impl(const GsrView* views, int B, int32_t N, int32_t K,
     // K1 is a persistent grid (per-workgroup tile histogram + statistics): four workgroups per CU (115 VGPRs), every wave walks
     // batches of 64 Gaussians. The grid is SHRUNK to ceil(batches / rounds) so that no workgroup walks one batch more than the
     // others (at 1M Gaussians: 977 workgroups x 4 batches; 1280 workgroups gave 67 of them a fourth batch and every tile counter
-    // 1280 flush atomics instead of 977: 0.102 -> 0.096 ms by the grid alone). GSR_K1_GRID=<n> pins the grid (A/B runs).
-    static const int k1_grid_env = [] { const char* e = getenv("GSR_K1_GRID"); const int g = e ? atoi(e) : 0; return g < 0 ? 0 : (g > 2048 ? 2048 : g); }();
+    // 1280 flush atomics instead of 977: 0.102 -> 0.096 ms by the grid alone). Test hook "k1_grid" pins the grid (A/B runs).
+    const int k1_grid_env = ov(OV_K1_GRID) < 0 ? 0 : (ov(OV_K1_GRID) > 2048 ? 2048 : ov(OV_K1_GRID));
     const int k1_batches = (N + 255) / 256;
     int grid_pre = 0;
     if (N > 0) {
@@ -441,7 +441,7 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
         const size_t lds = hist_in_lds ? (size_t)T * 4 : 0;
         if (lds > 48 * 1024)
             HIP_TRY(hipFuncSetAttribute((const void*)gsr_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        static const int scatter_grid = [] { const char* e = getenv("GSR_SCATTER_GRID"); const int g = e ? atoi(e) : 512; return g < 1 ? 1 : (g > 4096 ? 4096 : g); }();
+        const int scatter_grid = ov(OV_SCATTER_GRID) < 1 ? 512 : (ov(OV_SCATTER_GRID) > 4096 ? 4096 : ov(OV_SCATTER_GRID));
         const int grid_sc = (int)fmin((double)((N + 255) / 256), (double)scatter_grid);
         const uint32_t* level_off = (const uint32_t*)(gbuf + GL.level_off);
         uint4* items = (uint4*)(bbuf + BL.item_recs);
@@ -517,10 +517,9 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
         unsigned long long* sat = (unsigned long long*)(gbuf + GL.sat);
         const uint32_t* level_off = (const uint32_t*)(gbuf + GL.level_off);
         uint4* items = (uint4*)(bbuf + BL.item_recs);
-        // one workgroup per item (GSR_FWD_GRID = n: n workgroups striding through the list, an A/B switch -- measured 2x slower,
+        // one workgroup per item (test hook "fwd_grid" = n: n workgroups striding through the list, an A/B switch -- measured 2x slower,
         // see the kernel)
-        const char* ge = getenv("GSR_FWD_GRID");
-        const size_t gmax = ge && atoi(ge) > 0 ? (size_t)atoi(ge) : ~(size_t)0;
+        const size_t gmax = ov(OV_FWD_GRID) > 0 ? (size_t)ov(OV_FWD_GRID) : ~(size_t)0;
         const unsigned grid_a = (unsigned)(BL.items < gmax ? BL.items : gmax);
         prof_begin(stream);
         if (mask_q) {
@@ -597,15 +596,14 @@ int forward_impl(const GsrView* views, int B, int32_t N, int32_t K,
         (void)hipStreamSynchronize(stream);               // nothing may still write the pinned block when the next call re-arms it
         return rc;
     }
-    // Speculation (default; GSR_SPECULATE=0 turns it off): the previous call of this thread on the same problem shape predicts
+    // Speculation (default; test hook "speculate" = 0 turns it off): the previous call of this thread on the same problem shape predicts
     // M (+25 %), the sort classes and each view's kernel; binning / sort / compositing are enqueued at once -- the GPU runs the
     // forward back to back -- and only then does the host wait for the counters, repeating the tail when the prediction was too
     // small (every kernel that touches the lists leaves when the true M or the true longest list exceeds what was launched for:
     // tests/test_parity_gpu.py::test_speculative_forward_recovers_from_mispredictions). Measured, ms per fwd+bwd, wait-first /
     // speculative with the event / speculative with the flag: 5k-256^2 0.402 / 0.396 / 0.313, 250k-512^2 0.366 / 0.352 / 0.354,
     // 100k-800^2 0.369 / 0.348 / 0.350, 1M-800^2 0.751 / 0.750 / 0.747 (round 2).
-    const char* se = getenv("GSR_SPECULATE");
-    const bool spec = !(se && se[0] == '0') && g_hint.valid && g_hint.N == N && g_hint.H == vcs.H && g_hint.W == vcs.W && g_hint.B == B && N > 0;
+    const bool spec = ov(OV_SPECULATE) != 0 && g_hint.valid && g_hint.N == N && g_hint.H == vcs.H && g_hint.W == vcs.W && g_hint.B == B && N > 0;
     unsigned long long cap = 0, capc = 0;
     int rc = 0;
     if (spec) {
@@ -722,7 +720,7 @@ int backward_impl(const GsrView* views, int B, int32_t N, int32_t K,
     }
     LAUNCH_CHECK(view, stream, "render_bwd");
 
-    static const int k6_grid = [] { const char* e = getenv("GSR_K6_GRID"); const int g = e ? atoi(e) : 2048; return g < 1 ? 1 : g; }();   // A/B runs
+    const int k6_grid = ov(OV_K6_GRID) < 1 ? 2048 : ov(OV_K6_GRID);   // (test hook: A/B runs)
     const int grid_n = (int)fmin((double)((N + 255) / 256), (double)k6_grid);
     const size_t lds = (shs && K > 1) ? (size_t)256 * (3 * K + 1) * 4 : 0;
     if (lds > 160 * 1024) return fail(-1, "preprocess_bwd needs more than 160 KiB of LDS%s", "");

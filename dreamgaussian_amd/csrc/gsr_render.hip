@@ -126,7 +126,7 @@ gsr_render_fwd_seg(const uint4* __restrict__ items, const uint32_t* __restrict__
     float4* __restrict__ sc = stage[wave][2];
     bool lds_ready = false;
     // One item per workgroup by default (the dispatcher then hands the items out in list order as slots free up, which is what
-    // keeps the hints flowing; a fixed stride per workgroup -- GSR_FWD_GRID -- lets the fast ones run ahead of the hints: 2x slower).
+    // keeps the hints flowing; a fixed stride per workgroup -- test hook "fwd_grid" -- lets the fast ones run ahead of the hints: 2x slower).
     const uint32_t total = level_off[GSR_NLEV];
   for (uint32_t k = blockIdx.x; k < total; k += gridDim.x) {
     const uint4 item = items[k];                          // {tile, list start, segment record, segment << 8 | entries - 1}

@@ -107,33 +107,11 @@ def prune_points(gaussians, mask: torch.Tensor) -> None:
     three accumulators -- one mask compaction (one synchronisation) and one gather launch instead of 21 boolean-mask
     indexings. Opt-in replacement; the reference's own method keeps working unchanged."""
     idx, _ = compact_mask(~mask)
-    groups = gaussians.optimizer.param_groups
-    tensors, slots = [], []
-    for g in groups:
-        p = g["params"][0]
-        st = gaussians.optimizer.state.get(p, None)
-        tensors.append(p.data)
-        slots.append((g, "param", st))
-        if st is not None:
-            tensors.append(st["exp_avg"]); slots.append((g, "exp_avg", st))
-            tensors.append(st["exp_avg_sq"]); slots.append((g, "exp_avg_sq", st))
+    slots = _optimizer_slots(gaussians)
     aux = [gaussians.xyz_gradient_accum, gaussians.denom, gaussians.max_radii2D]
-    outs = gather_rows(idx, tensors + aux)
-    new_params = {}
-    for (g, kind, st), t in zip(slots, outs[:len(slots)]):
-        if kind == "param":
-            old = g["params"][0]
-            newp = torch.nn.Parameter(t.requires_grad_(True))
-            if st is not None:
-                del gaussians.optimizer.state[old]
-                gaussians.optimizer.state[newp] = st
-            g["params"][0] = newp
-            new_params[g["name"]] = newp
-        else:
-            st[kind] = t
-    gaussians._xyz, gaussians._features_dc, gaussians._features_rest = new_params["xyz"], new_params["f_dc"], new_params["f_rest"]
-    gaussians._opacity, gaussians._scaling, gaussians._rotation = new_params["opacity"], new_params["scaling"], new_params["rotation"]
-    gaussians.xyz_gradient_accum, gaussians.denom, gaussians.max_radii2D = outs[len(slots)], outs[len(slots) + 1], outs[len(slots) + 2]
+    outs = gather_rows(idx, [t for t, _, _, _ in slots] + aux)
+    _rebind(gaussians, slots, outs[:len(slots)])
+    gaussians.xyz_gradient_accum, gaussians.denom, gaussians.max_radii2D = outs[len(slots):]
 
 
 def _optimizer_slots(gaussians):
@@ -179,8 +157,9 @@ def densification_postfix(gaussians, new_xyz, new_features_dc, new_features_rest
     outs, keep, arr = [], [], []
     for t, kind, g, _ in slots:
         ext = new[g["name"]].detach().to(torch.float32).contiguous() if kind == "param" else None
-        if kind == "param" and tuple(ext.shape[1:]) != tuple(t.shape[1:]):
-            raise RuntimeError(f"new rows of '{g['name']}' have shape {tuple(ext.shape)}, the model's {tuple(t.shape)}")
+        if kind == "param" and (tuple(ext.shape[1:]) != tuple(t.shape[1:]) or int(ext.shape[0]) != n_new):
+            # (rows as well as trailing dimensions: gsr_concat_rows reads n_new rows of every tensor)
+            raise RuntimeError(f"new rows of '{g['name']}' have shape {tuple(ext.shape)}, expected ({n_new}, {', '.join(str(int(d)) for d in t.shape[1:])})")
         o = torch.empty((n_old + n_new,) + tuple(t.shape[1:]), dtype=torch.float32, device=dev)
         outs.append(o)
         width = 1
@@ -218,10 +197,22 @@ def densify_and_clone(gaussians, grads: torch.Tensor, grad_threshold: float, sce
 
 
 @torch.no_grad()
+def quaternion_to_matrix(r: torch.Tensor) -> torch.Tensor:
+    """[n,4] quaternions (r, x, y, z), normalised here, -> [n,3,3]: the default `build_rotation` of densify_and_split (the
+    convention of gs_renderer.py:85-107; the reference's own function can be passed instead)."""
+    q = r / torch.norm(r, dim=1, keepdim=True)
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                     2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                     2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], dim=1)
+    return R.reshape(-1, 3, 3)
+
+
 def densify_and_split(gaussians, grads: torch.Tensor, grad_threshold: float, scene_extent: float, N: int = 2, build_rotation=None) -> None:
     """`GaussianModel.densify_and_split` (gs_renderer.py:554-580): selection and the random offsets as the reference computes
     them (same torch calls, same RNG stream), the rows through one compaction + one gather, then the one-launch postfix and
-    the one-gather prune of the split originals. `build_rotation` = gs_renderer.build_rotation (quaternion -> matrix)."""
+    the one-gather prune of the split originals. `build_rotation` = gs_renderer.build_rotation (quaternion -> matrix; default: the
+    same convention, `quaternion_to_matrix`)."""
     n_init = int(gaussians.get_xyz.shape[0])
     dev = gaussians._xyz.device
     padded = torch.zeros(n_init, device=dev)
@@ -234,7 +225,7 @@ def densify_and_split(gaussians, grads: torch.Tensor, grad_threshold: float, sce
     scaling = gaussians.scaling_activation(scaling_raw)
     stds = scaling.repeat(N, 1)
     samples = torch.normal(mean=torch.zeros((stds.size(0), 3), device=dev), std=stds)
-    rots = build_rotation(rot).repeat(N, 1, 1)
+    rots = (build_rotation or quaternion_to_matrix)(rot).repeat(N, 1, 1)
     new_xyz = torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + xyz.repeat(N, 1)
     new_scaling = gaussians.scaling_inverse_activation(scaling.repeat(N, 1) / (0.8 * N))
     densification_postfix(gaussians, new_xyz, f_dc.repeat(N, 1, 1), f_rest.repeat(N, 1, 1), opac.repeat(N, 1), new_scaling, rot.repeat(N, 1))

@@ -91,6 +91,18 @@ def _require_gpu(t: torch.Tensor):
             f"got a tensor on '{t.device}'. There is no CPU fallback.")
 
 
+def carve_gradients(N: int, widths, device):
+    """ONE allocation for all gradients of a backward, gradient i = N x widths[i] floats starting at a 64-element (256-byte) boundary
+    (offs[i]); K6 writes every element of every gradient, so nothing is cleared. views.allreduce_grads relies on this layout: the
+    parameter gradients tile one storage with gaps of at most 63 elements and are reduced in place over their span."""
+    offs, total = [], 0
+    for w_ in widths:
+        offs.append(total)
+        total += (N * w_ + 63) & ~63
+    flat = (torch.empty if N > 0 else torch.zeros)(max(total, 1), dtype=torch.float32, device=device)
+    return flat, offs
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
@@ -186,11 +198,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         # the parameter gradients in place and must not touch the screen-space one
         widths = [3, 1, 3 * k_sh if has_sh else 0, 3 if has_col else 0, 3 if has_sr else 0, 4 if has_sr else 0,
                   6 if has_cov else 0, 3 * k_rest, 3]
-        offs, total = [], 0
-        for w_ in widths:
-            offs.append(total)
-            total += (N * w_ + 63) & ~63
-        flat = (torch.empty if N > 0 else torch.zeros)(max(total, 1), dtype=torch.float32, device=dev)
+        flat, offs = carve_gradients(N, widths, dev)
         part = lambda i, *shape: flat[offs[i]:offs[i] + N * widths[i]].view(*shape)
         d_m3, d_op, d_m2 = part(0, N, 3), part(1, N, 1), part(8, N, 3)
         d_sh = part(2, N, k_sh, 3) if has_sh else None

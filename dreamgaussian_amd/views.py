@@ -19,6 +19,7 @@ import torch.distributed as dist
 
 
 _force = False
+gather_fallbacks = 0        # calls of gather_views_async that had to replace `gather` by `all_gather` (never under "nccl")
 
 
 def force_collectives(on: bool = True):
@@ -68,8 +69,17 @@ def gather_views_async(color: torch.Tensor, depth: torch.Tensor, alpha: torch.Te
     glist = [buf[i] for i in range(world)] if rank == dst else None
     try:
         return dist.gather(local, glist, dst=dst, group=group, async_op=True)
-    except (RuntimeError, NotImplementedError):
-        # a backend without gather: every rank receives every view (same bytes per link on xGMI)
+    except (RuntimeError, NotImplementedError) as e:
+        # A backend without gather: every rank receives every view -- world x the bytes. Never silently: counted, logged once per
+        # process, and refused outright under RCCL ("nccl" HAS gather: an exception there is a real failure, not a missing feature).
+        if dist.get_backend(group) == "nccl":
+            raise
+        global gather_fallbacks
+        gather_fallbacks += 1
+        if gather_fallbacks == 1:
+            import warnings
+            warnings.warn(f"dreamgaussian_amd.views: dist.gather failed on backend {dist.get_backend(group)!r} ({e}); falling back to "
+                          f"all_gather_into_tensor -- {world} x the bytes per step (views.gather_fallbacks counts the calls)")
         full = buf if rank == dst else torch.empty_like(buf)
         return dist.all_gather_into_tensor(full.view(-1), local.view(-1), group=group, async_op=True)
 
@@ -152,9 +162,17 @@ def allreduce_grads(params: Iterable[torch.Tensor], group=None, bucket_bytes: in
     rest = []
     for (_, dtype, dev), gs in by_storage.items():
         if len(gs) > 1 and all(g.is_contiguous() for g in gs):
-            lo = min(g.storage_offset() for g in gs)
-            hi = max(g.storage_offset() + g.numel() for g in gs)
-            if sum(g.numel() for g in gs) >= 0.95 * (hi - lo):      # only alignment gaps in between (never read)
+            # The span [lo, hi) is reduced as ONE buffer, gaps included: safe only if every gap is padding nobody reads -- the
+            # rasterizer carves its gradients at 64-element (256-byte) boundaries, so a gap of up to 63 elements is padding; a
+            # larger one may be a LIVE gradient that was not passed here (e.g. d_opacity between d_means3D and d_sh when a caller
+            # reduces parameter group by parameter group) and would be reduced twice. Then: the bucket path.
+            order = sorted(gs, key=lambda g: g.storage_offset())
+            lo, hi = order[0].storage_offset(), max(g.storage_offset() + g.numel() for g in gs)
+            end, tight = lo, True
+            for g in order:
+                tight = tight and 0 <= g.storage_offset() - end <= 63
+                end = max(end, g.storage_offset() + g.numel())
+            if tight:
                 span = torch.empty(0, dtype=dtype, device=dev).set_(gs[0].untyped_storage(), lo, (hi - lo,))
                 dist.all_reduce(span, op=dist.ReduceOp.SUM, group=group)
                 continue

@@ -105,6 +105,19 @@ typedef struct GsrStats {
 #define GSR_ABI_VERSION 4
 int gsr_abi_version(void);
 
+/* TEST HOOK -- not part of the drop-in surface. Forces one of the choices the library otherwise makes from the problem shape
+ * (process-wide; value -1 = the library decides again). Nothing is read from the process environment: "fwd_mode" and "seg_shift"
+ * decide where the per-pixel sums are cut, i.e. the rounding of the results.
+ *   "fwd_mode"     1 = serial walk (gsr_render_fwd_serial), 2 = depth-segmented forward (K5a/b/c)
+ *   "seg_shift"    6..8: log2 of the depth-segment length
+ *   "fwd_lists"    1 = 8x8 block lists, 2 = quad lists in the forward compositing
+ *   "fwd_hints"    1 = off, 2 = every segment behind a tile's first skipped (the chaining kernel walks them all)
+ *   "speculate"    0 = gsr_forward waits for the instance count before binning
+ *   "hist_max" "k1_grid" "scatter_grid" "fwd_grid" "k6_grid"   launch geometry (A/B measurements, multi-round paths)
+ * Returns 0, or -1 for an unknown name. dreamgaussian_amd/_testing.py wraps it. */
+int gsr_testing_override(const char* name, int32_t value);
+
+
 /* Forward.
  *   N                number of Gaussians; K = shs.shape[1] (max coefficients per Gaussian)
  *   means3D [N,3]    shs [N,K,3] or NULL    colors_precomp [N,3] or NULL (exactly one)
@@ -116,7 +129,7 @@ int gsr_abi_version(void);
  * the host: the list scratch is sized from the previous call of the thread on the same (N, H, W) (+25 %), binning / sort /
  * compositing are enqueued before the wait, and a prediction that turns out too small (instances, or the longest list against
  * the sort kernels that were launched) is detected on the device by every kernel that touches the lists and the tail repeated
- * (first call of a shape, GSR_SPECULATE=0: counters first, then the tail, like the reference ext's blocking read of num_rendered).
+ * (first call of a shape, or test hook "speculate" = 0: counters first, then the tail, like the reference ext's blocking read of num_rendered).
  * The result does not depend on the prediction: the depth-segment length (GsrStats.seg_shift) follows N and the image size only.
  * Returns 0, or a negative code with gsr_last_error() set. N==0 renders the background. */
 int gsr_forward(const GsrView* view, int32_t N, int32_t K,

@@ -205,6 +205,12 @@ def preprocess(means3D, means2D, opacities, shs, colors_precomp, scales, rotatio
         ry0, ry1 = tile(py - radius, gy), tile(py + radius + (BLOCK - 1), gy)
         tiles = (rx1 - rx0) * (ry1 - ry0)
         valid = valid & (tiles > 0)
+        # how far the two discontinuous integer decisions sit from flipping (for the tests: a radius / tile-count mismatch of an
+        # fp32 implementation must BE such a boundary case): 3 sqrt(lambda) against the next integer, the four rect edges against
+        # the next tile boundary (in tiles)
+        radius_raw = 3.0 * torch.sqrt(lam)
+        edges = torch.stack([px - radius, px + radius + (BLOCK - 1), py - radius, py + radius + (BLOCK - 1)], -1) / BLOCK
+        edge_margin = (edges - torch.round(edges)).abs().amin(-1)
 
     if colors_precomp is not None and colors_precomp.numel() > 0:
         color = colors_precomp
@@ -220,7 +226,7 @@ def preprocess(means3D, means2D, opacities, shs, colors_precomp, scales, rotatio
                 opacity=opacities.reshape(-1), color=color, clamped=clamped,
                 radius=torch.where(valid, radius, torch.zeros_like(radius)).to(torch.int32),
                 rect=torch.stack([rx0, ry0, rx1, ry1], -1), tiles=torch.where(valid, tiles, 0),
-                cov2d=torch.stack([a, b, c], -1), grid=(gx, gy))
+                cov2d=torch.stack([a, b, c], -1), grid=(gx, gy), radius_raw=radius_raw, edge_margin=edge_margin)
 
 
 # --------------------------------------------------------------------------------------

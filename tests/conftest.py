@@ -32,3 +32,12 @@ def gpu():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture
+def hooks():
+    """dreamgaussian_amd._testing (explicit test hooks of the library; nothing is read from the environment), reset afterwards."""
+    from dreamgaussian_amd import _testing
+    _testing.reset()
+    yield _testing
+    _testing.reset()

@@ -215,3 +215,92 @@ def test_forced_collectives_on_one_rank():
     res = q.get(timeout=60)
     p.join(timeout=30)
     assert p.exitcode == 0 and res == dict(fresh=True, same=True, back=True, grad=True)
+
+
+def _worker_span(rank, world, port, q):
+    """allreduce_grads on gradients laid out exactly as the rasterizer's backward lays them out for the split / raw-activation
+    entry at SH degree 3 (rasterizer.carve_gradients: means3D | opacity | features_dc | scales | rotations | features_rest | means2D)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dreamgaussian_amd import views
+        from dreamgaussian_amd.rasterizer import carve_gradients
+        N = 37                                             # not a multiple of 64: every gradient is followed by padding
+        widths = [3, 1, 3, 0, 3, 4, 0, 45, 3]              # k_sh = 1 (features_dc), k_rest = 15, no colours / covariances
+        names = ["means3D", "opacity", "features_dc", None, "scaling", "rotation", None, "features_rest", "means2D"]
+
+        def fresh():
+            flat, offs = carve_gradients(N, widths, "cpu")
+            flat.fill_(float("nan"))                       # padding must never be read into a result
+            params = {}
+            for i, nm in enumerate(names):
+                if nm is None:
+                    continue
+                p = torch.nn.Parameter(torch.zeros(N, widths[i]))
+                g = flat[offs[i]:offs[i] + N * widths[i]].view(N, widths[i])
+                g.copy_(torch.full((N, widths[i]), float(i + 1)) * (rank + 1))
+                p.grad = g
+                params[nm] = p
+            return flat, params
+
+        out = {}
+        # (a) every parameter gradient (means2D is the per-view one: not passed): ONE in-place all-reduce over the span
+        flat, params = fresh()
+        ptr = flat.data_ptr()
+        views.allreduce_grads([p for k, p in params.items() if k != "means2D"])
+        tot = sum(r + 1 for r in range(world))
+        out["span_ok"] = all(torch.equal(params[nm].grad, torch.full((N, widths[i]), float(i + 1) * tot))
+                             for i, nm in enumerate(names) if nm not in (None, "means2D"))
+        out["span_in_place"] = all(p.grad.untyped_storage().data_ptr() == ptr for p in params.values())
+        out["means2D_untouched"] = torch.equal(params["means2D"].grad, torch.full((N, 3), 9.0 * (rank + 1)))
+        # (b) the advisor's case: opacity left out of the first call (a live gradient sits in the hole between means3D and
+        # features_dc) -> no span reduction; opacity stays local, a second call reduces it exactly once
+        flat, params = fresh()
+        views.allreduce_grads([p for k, p in params.items() if k not in ("means2D", "opacity")])
+        out["hole_not_reduced"] = torch.equal(params["opacity"].grad, torch.full((N, 1), 2.0 * (rank + 1)))
+        out["others_reduced"] = torch.equal(params["features_rest"].grad, torch.full((N, 45), 8.0 * tot))
+        views.allreduce_grads([params["opacity"]])
+        out["hole_reduced_once"] = torch.equal(params["opacity"].grad, torch.full((N, 1), 2.0 * tot))
+        q.put(dict(rank=rank, **out))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_span_allreduce_on_the_split_entry_layout_and_its_hole_case():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_span, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in res:
+        assert all(v for k, v in r.items() if k != "rank"), r
+
+
+def test_gather_fallback_is_counted_and_refused_under_nccl(monkeypatch):
+    """views.gather_views_async may replace `gather` by `all_gather` (world x the bytes) only on a backend without gather, counts
+    and warns when it does, and re-raises under "nccl" (RCCL has gather: an exception there is a failure)."""
+    from dreamgaussian_amd import views
+    calls = {}
+    monkeypatch.setattr(views, "_world", lambda group=None: (0, 2))
+    monkeypatch.setattr(views.dist, "gather", lambda *a, **k: (_ for _ in ()).throw(RuntimeError("no gather")))
+    monkeypatch.setattr(views.dist, "all_gather_into_tensor", lambda *a, **k: calls.setdefault("all_gather", True))
+    c, d, a = torch.rand(3, 4, 4), torch.rand(1, 4, 4), torch.rand(1, 4, 4)
+    buf = views.make_gather_buffer(2, 5, 4, 4, "cpu")
+    monkeypatch.setattr(views.dist, "get_backend", lambda group=None: "gloo")
+    before = views.gather_fallbacks
+    with pytest.warns(UserWarning, match="all_gather"):
+        monkeypatch.setattr(views, "gather_fallbacks", 0)
+        views.gather_views_async(c, d, a, buf)
+    assert calls.get("all_gather") and views.gather_fallbacks == 1
+    monkeypatch.setattr(views.dist, "get_backend", lambda group=None: "nccl")
+    with pytest.raises(RuntimeError, match="no gather"):
+        views.gather_views_async(c, d, a, buf)
+    monkeypatch.setattr(views, "gather_fallbacks", before)

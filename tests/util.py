@@ -87,6 +87,16 @@ def assert_forward_close(ho, oo, aux=None, atol=FWD_ATOL):
         REPORT["radii_mismatch"] = nbad
         assert int(dr.max()) <= 1 and nbad <= max(1, dr.numel() // 5000), \
             f"radii mismatch on {nbad} Gaussians (max |diff| {int(dr.max())})"
+        if nbad and aux is not None and "pre" in aux and "radius_raw" in aux["pre"]:
+            # ... and every one of them IS a boundary case of ceil(): the oracle's own 3 sqrt(lambda) lies within fp32 rounding of
+            # the projection chain (a few 1e-6 relative) of an integer -- or the radius differs because the fp32 validity decision
+            # (culled <-> radius 0) sits on its own threshold, which the fragile set names
+            raw = aux["pre"]["radius_raw"].double()[dr != 0]
+            dist = (raw - torch.round(raw)).abs() / raw.clamp_min(1.0)
+            culled_flip = ((ho[1] == 0) != (oo[1] == 0))[dr != 0]
+            REPORT["radii_mismatch_worst_boundary_distance"] = float(dist[~culled_flip].max()) if (~culled_flip).any() else 0.0
+            assert bool(((dist <= 2e-5) | culled_flip).all()), \
+                f"a radius differs away from a ceil() boundary: relative distance to the next integer {dist.max().item():.2e}"
     frag = None if aux is None else torch.as_tensor(aux["fragile_pixels"]).bool()
     for name, i in (("color", 0), ("depth", 2), ("alpha", 3)):
         ref = oo[i].double()
@@ -96,6 +106,34 @@ def assert_forward_close(ho, oo, aux=None, atol=FWD_ATOL):
         assert strict.max().item() <= atol * scale, \
             f"{name}: max abs err {strict.max().item():.3e} > {atol * scale:.1e} on a pixel without ambiguous decisions"
         assert err.max().item() <= FRAGILE_ABS * scale, f"{name}: max abs err {err.max().item():.3e} on a fragile pixel"
+
+
+def assert_counts_explained(st, aux):
+    """V (visible Gaussians) equal; M_ref (tile instances under the reference's 3-sigma rect rule) equal up to the Gaussians whose
+    rect sits ON a discontinuity of an fp32 implementation: ceil(3 sqrt(lambda)) within 2e-5 (relative) of an integer, or a rect
+    edge within 2e-5 tiles of a tile boundary. Each such Gaussian can move the count by at most one row or column of its rect."""
+    assert st["V"] == aux["V"], (st["V"], aux["V"])
+    d = int(st["M_ref"]) - int(aux["M"])
+    REPORT["M_ref_mismatch"] = d
+    if d == 0:
+        return
+    pre = aux["pre"]
+    raw = pre["radius_raw"].double()
+    near = (((raw - torch.round(raw)).abs() / raw.clamp_min(1.0)) <= 2e-5) | (pre["edge_margin"].double() <= 2e-5)
+    near = near & pre["valid"]
+    rect = pre["rect"]
+    slack = int((torch.maximum(rect[:, 2] - rect[:, 0], rect[:, 3] - rect[:, 1]) + 1)[near].sum())
+    REPORT["M_ref_boundary_gaussians"] = int(near.sum())
+    assert abs(d) <= slack, f"M_ref differs by {d} but the {int(near.sum())} Gaussians on a rect discontinuity explain at most {slack}"
+
+
+def og32_if_near_opaque(sc, S, w):
+    """The fp32 oracle's gradients for assert_grads_close(og32=) -- ONLY for scenes that hold near-opaque Gaussians (opacity >= 0.99:
+    two of them in a row sit exactly on the 1e-4 stop, see assert_grads_close). Every other scene is held to the fp64 oracle alone."""
+    if float(sc["opacities"].max()) < 0.99:
+        return None
+    _, og32, _ = run_oracle(sc, S, w, torch.float32)
+    return og32
 
 
 def grad_floors(sc, og):
@@ -131,6 +169,8 @@ def assert_grads_close(hg, og, aux=None, rtol=GRAD_RTOL, floors=None, row_rel_p9
             if fg is not None:
                 miss = miss & ~fg
             REPORT[f"fp32_decided_{k}"] = int(miss.sum())
+            if int(miss.sum()):
+                print(f"[fp32-decided] d{k}: {int(miss.sum())} of {ref.shape[0]} rows miss the fp64 oracle and are held to the fp32 oracle")
             assert int(miss.sum()) <= max(3, int(og32_cap * ref.shape[0])), f"d{k}: {int(miss.sum())} rows miss the fp64 oracle"
             if miss.any():
                 assert err32[miss].max().item() <= rtol * scale + 1e-9, \

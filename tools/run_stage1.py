@@ -163,8 +163,8 @@ def check_against_oracle(sc, sizes=((256, 0.0, 0.0), (512, -15.0, 130.0)), label
         oo, og, aux = util.run_oracle(sc, S, w, torch.float64)
         util.REPORT.clear()
         util.assert_forward_close(ho, oo, aux)
-        _, og32, _ = util.run_oracle(sc, S, w, torch.float32)     # near-opaque Gaussians: see tests/util.py assert_grads_close(og32=)
-        util.assert_grads_close(hg, og, aux, floors=util.grad_floors(sc, og), og32=og32)
+        # (the fp32-oracle arbitration only if the trained model holds near-opaque Gaussians -- it does: tests/util.py)
+        util.assert_grads_close(hg, og, aux, floors=util.grad_floors(sc, og), og32=util.og32_if_near_opaque(sc, S, w))
         rep[f"{size}x{size}"] = dict(N=int(sc["means3D"].shape[0]), M=int(aux["M"]), V=int(aux["V"]), max_tile=int(st["max_tile"]),
                                      max_abs_color_err=float((ho[0].double() - oo[0].double()).abs().max()),
                                      fragile_pixels=int(torch.as_tensor(aux["fragile_pixels"]).sum()), observed=dict(util.REPORT))
@@ -218,8 +218,8 @@ def run(ref, iters, input_path, profiled, optin=False, keep=None):
                                           (("128", 0, int(0.3 * iters) - 1), ("256", int(0.3 * iters), int(0.6 * iters) - 1),
                                            ("512", int(0.6 * iters), iters)) if b > a})
     if profiled:
-        fwd = sum(ms for k, (ms, n) in kern.items() if k in ("memset_fwd", "preprocess_fwd", "tile_scan", "scatter", "render_fwd", "render_combine", "render_fix") or k.startswith("tile_sort"))
-        bwd = sum(ms for k, (ms, n) in kern.items() if k in ("memset_bwd", "bwd_plan", "render_bwd", "preprocess_bwd"))
+        fwd = sum(ms for k, (ms, n) in kern.items() if k in ("memset_fwd", "zero_g2d", "preprocess_fwd", "tile_scan", "scatter", "render_fwd", "render_combine", "render_fix") or k.startswith("tile_sort"))
+        bwd = sum(ms for k, (ms, n) in kern.items() if k in ("memset_bwd", "render_bwd", "preprocess_bwd"))
         other = sum(ms for k, (ms, n) in kern.items()) - fwd - bwd
         res["rasterizer_kernel_ms_per_iter"] = dict(forward=round(fwd / iters, 4), backward=round(bwd / iters, 4),
                                                     other_libgsr=round(other / iters, 4),
