@@ -105,8 +105,28 @@ int once_per_device(F fn) {
     return 0;
 }
 
+// ---- test hooks (gsr_testing_override, include/gsr.h): choices the library makes from the problem shape, forced by a TEST or an
+// A/B measurement through an explicit call. Nothing here is read from the process environment: two of them (forward mode, segment
+// length) decide where the per-pixel sums are cut, i.e. the rounding of the results, and that must not depend on who started the
+// process. -1 = the library decides.
+enum { OV_FWD_MODE, OV_SEG_SHIFT, OV_FWD_LISTS, OV_FWD_HINTS, OV_SPECULATE, OV_HIST_MAX, OV_K1_GRID, OV_FWD_GRID, OV_K6_GRID, OV_COUNT };
+const char* const kOvNames[OV_COUNT] = {"fwd_mode", "seg_shift", "fwd_lists", "fwd_hints", "speculate", "hist_max", "k1_grid", "fwd_grid", "k6_grid"};
+std::atomic<int> g_ov[OV_COUNT] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
+inline int ov(int k) { return g_ov[k].load(std::memory_order_relaxed); }
+
+// K1's grid (a persistent grid: every workgroup walks the same number of 256-Gaussian batches; test hook "k1_grid" pins it). The
+// scatter kernel runs on the SAME grid with the same Gaussian -> workgroup assignment (it continues K1's per-workgroup list ranges).
+int k1_grid_for(int N) {
+    if (N <= 0) return 0;
+    const int batches = (N + 255) / 256;
+    const int pin = ov(OV_K1_GRID) < 0 ? 0 : (ov(OV_K1_GRID) > 2048 ? 2048 : ov(OV_K1_GRID));
+    if (pin) return batches < pin ? batches : pin;
+    const int cap = 1024, rounds = (batches + cap - 1) / cap;      // block_stats holds 2048 workgroups per view
+    return (batches + rounds - 1) / rounds;
+}
+
 struct GeomLayout {
-    size_t recs, emit, flags8, block_stats, tile_count, cursor, counters, tile_off, tile_seg, order, level_off, sat, plan_off, g2d, total;
+    size_t recs, emit, flags8, block_stats, tile_count, cursor, counters, tile_off, tile_seg, order, level_off, sat, plan_off, g2d, wg_base, total;
     int nTiles;        // per view
     int allTiles;      // views * nTiles: the per-tile arrays hold every view's tiles, view-major
 };
@@ -136,6 +156,9 @@ GeomLayout geom_layout(int N, int H, int W, int B = 1) {
     // the backward's screen-space gradient accumulators [B][N][12] f32: cleared by the FORWARD (forward_impl) so that the backward
     // starts on its first kernel
     L.g2d = o; o += align_up(BN * GSR_G2D_STRIDE * 4);
+    // where each of K1's workgroups starts inside every tile's list ([view][workgroup][tile] u32, written by K1's histogram flush,
+    // read by the scatter): last, so that nothing else moves with K1's grid
+    L.wg_base = o; o += align_up((size_t)B * (size_t)k1_grid_for(N) * (size_t)L.nTiles * 4);
     L.total = o;
     return L;
 }
@@ -218,15 +241,6 @@ int check_inputs(int N, int K, const GsrView* v, const float* means3D, const flo
     if (v->shs_rest && (!shs || K < 2)) return fail(-1, "split SH input (GsrView.shs_rest) needs shs = features_dc and K >= 2%s", "");
     return 0;
 }
-
-// ---- test hooks (gsr_testing_override, include/gsr.h): choices the library makes from the problem shape, forced by a TEST or an
-// A/B measurement through an explicit call. Nothing here is read from the process environment: two of them (forward mode, segment
-// length) decide where the per-pixel sums are cut, i.e. the rounding of the results, and that must not depend on who started the
-// process. -1 = the library decides.
-enum { OV_FWD_MODE, OV_SEG_SHIFT, OV_FWD_LISTS, OV_FWD_HINTS, OV_SPECULATE, OV_HIST_MAX, OV_K1_GRID, OV_SCATTER_GRID, OV_FWD_GRID, OV_K6_GRID, OV_COUNT };
-const char* const kOvNames[OV_COUNT] = {"fwd_mode", "seg_shift", "fwd_lists", "fwd_hints", "speculate", "hist_max", "k1_grid", "scatter_grid", "fwd_grid", "k6_grid"};
-std::atomic<int> g_ov[OV_COUNT] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
-inline int ov(int k) { return g_ov[k].load(std::memory_order_relaxed); }
 
 // Largest tile grid whose per-tile counters a workgroup of K1 / the scatter keeps in LDS (64 KiB)
 static int hist_lds_max_tiles() {
@@ -363,16 +377,7 @@ int begin_impl(const GsrView* views, int B, int32_t N, int32_t K,
     // batches of 64 Gaussians. The grid is SHRUNK to ceil(batches / rounds) so that no workgroup walks one batch more than the
     // others (at 1M Gaussians: 977 workgroups x 4 batches; 1280 workgroups gave 67 of them a fourth batch and every tile counter
     // 1280 flush atomics instead of 977: 0.102 -> 0.096 ms by the grid alone). Test hook "k1_grid" pins the grid (A/B runs).
-    const int k1_grid_env = ov(OV_K1_GRID) < 0 ? 0 : (ov(OV_K1_GRID) > 2048 ? 2048 : ov(OV_K1_GRID));
-    const int k1_batches = (N + 255) / 256;
-    int grid_pre = 0;
-    if (N > 0) {
-        if (k1_grid_env) grid_pre = k1_batches < k1_grid_env ? k1_batches : k1_grid_env;
-        else {
-            const int cap = 1024, rounds = (k1_batches + cap - 1) / cap;      // block_stats holds 2048 workgroups per view
-            grid_pre = (k1_batches + rounds - 1) / rounds;
-        }
-    }
+    const int grid_pre = k1_grid_for(N);
     if (N > 0) {
         const size_t hist_bytes = hist_in_lds ? (((size_t)T * 4 + 15) & ~(size_t)15) : 0;
         const size_t lds = hist_bytes + (size_t)4 * GSR_K1_WSLICE * 4;      // + each wave's slice: SH staging rows, then its records on their way out
@@ -383,7 +388,7 @@ int begin_impl(const GsrView* views, int B, int32_t N, int32_t K,
         prof_begin(stream); hipLaunchKernelGGL(k1, dim3(grid_pre, B), dim3(256), lds, stream, tab, N, K, means3D, shs, view->shs_rest,
                            colors_precomp, opacities, scales, rotations, cov3D_precomp, recs, emit, radii,
                            tile_count, (unsigned long long*)(gbuf + GL.block_stats), hist_in_lds, (uint8_t*)(gbuf + GL.flags8),
-                           (uint32_t*)(gbuf + GL.tile_count), zero_words, flag_word, epoch);
+                           (uint32_t*)(gbuf + GL.tile_count), zero_words, flag_word, epoch, (uint32_t*)(gbuf + GL.wg_base));
         LAUNCH_CHECK(view, stream, "preprocess_fwd");
     }
     // one single-workgroup kernel: scan of the counts, K1's statistics, the segment forward's depth-major work list
@@ -441,13 +446,19 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
         const size_t lds = hist_in_lds ? (size_t)T * 4 : 0;
         if (lds > 48 * 1024)
             HIP_TRY(hipFuncSetAttribute((const void*)gsr_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        const int scatter_grid = ov(OV_SCATTER_GRID) < 1 ? 512 : (ov(OV_SCATTER_GRID) > 4096 ? 4096 : ov(OV_SCATTER_GRID));
-        const int grid_sc = (int)fmin((double)((N + 255) / 256), (double)scatter_grid);
         const uint32_t* level_off = (const uint32_t*)(gbuf + GL.level_off);
         uint4* items = (uint4*)(bbuf + BL.item_recs);
-        prof_begin(stream); hipLaunchKernelGGL(gsr_scatter, dim3(grid_sc, B), dim3(256), lds, stream, N, emit, tile_off, cursor, entries,
-                           vc.gx, T, hist_in_lds, (uint32_t)M, counters, level_off, order, tile_seg, shift, items,
-                           sequential ? 0u : (uint32_t)BL.items /* the serial walk takes its tiles from `order`: no work items */);
+        const uint32_t items_cap = sequential ? 0u : (uint32_t)BL.items;   // the serial walk takes its tiles from `order`: no work items
+        prof_begin(stream);
+        if (hist_in_lds) {
+            // K1's grid and Gaussian -> workgroup assignment: every workgroup continues the list ranges its K1 twin reserved
+            hipLaunchKernelGGL(gsr_scatter, dim3(k1_grid_for(N), B), dim3(256), lds, stream, N, emit, tile_off, (const uint32_t*)(gbuf + GL.wg_base), entries,
+                               vc.gx, T, (uint32_t)M, counters, level_off, order, tile_seg, shift, items, items_cap);
+        } else {
+            const int grid_sc = (int)fmin((double)((N + 255) / 256), 512.0);
+            hipLaunchKernelGGL(gsr_scatter_global, dim3(grid_sc, B), dim3(256), 0, stream, N, emit, tile_off, cursor, entries,
+                               vc.gx, T, (uint32_t)M, counters, level_off, order, tile_seg, shift, items, items_cap);
+        }
         LAUNCH_CHECK(view, stream, "scatter");
         // per-tile sort, size classes by list length
         constexpr size_t lds_s = 2048 * 8 + (512 + 1 + 512 + 40) * 4;
@@ -458,10 +469,14 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
                 if (e != hipSuccess) return e;
                 return hipFuncSetAttribute((const void*)gsr_tile_sort_bucket<16384, 1024, 2048>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l);
             })) return rc;
-        prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<2048, 256, 512>), dim3(TA), dim3(256), lds_s, stream, tile_off, entries, sorted_ids, 0u, 2048u, counters, (uint32_t)M);
-        LAUNCH_CHECK(view, stream, "tile_sort_small");
-        if (maxc > 2048) {
-            prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<8192, 1024, 2048>), dim3(TA), dim3(1024), lds_m, stream, tile_off, entries, sorted_ids, 2048u, 8192u, counters, (uint32_t)M);
+        // Lists of up to 2 048 entries sort on 256 threads; when longer ones exist ONE launch of the 1 024-thread kernel takes every
+        // list up to 8 192 (a short list then runs on its first waves): the two launches were latency chains of their own, one
+        // behind the other -- 12 + 32 us at 1M Gaussians against 32 for the merged one (44 -> 33 us with the third class).
+        if (maxc <= 2048) {
+            prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<2048, 256, 512>), dim3(TA), dim3(256), lds_s, stream, tile_off, entries, sorted_ids, 0u, 2048u, counters, (uint32_t)M);
+            LAUNCH_CHECK(view, stream, "tile_sort_small");
+        } else {
+            prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<8192, 1024, 2048>), dim3(TA), dim3(1024), lds_m, stream, tile_off, entries, sorted_ids, 0u, 8192u, counters, (uint32_t)M);
             LAUNCH_CHECK(view, stream, "tile_sort_medium");
         }
         if (maxc > 8192) {
@@ -721,8 +736,12 @@ int backward_impl(const GsrView* views, int B, int32_t N, int32_t K,
     LAUNCH_CHECK(view, stream, "render_bwd");
 
     const int k6_grid = ov(OV_K6_GRID) < 1 ? 2048 : ov(OV_K6_GRID);   // (test hook: A/B runs)
-    const int grid_n = (int)fmin((double)((N + 255) / 256), (double)k6_grid);
-    const size_t lds = (shs && K > 1) ? (size_t)256 * (3 * K + 1) * 4 : 0;
+    // K6 runs on 128-thread workgroups when it stages SH rows (25 KiB of LDS each, six per CU): a batch is a chain -- inputs, staged
+    // rows, arithmetic, per-Gaussian stores, row stores -- and more, smaller workgroups spread the chains' phases over the CU
+    // (0.091 -> 0.088 ms at 1M; 256 threads when nothing is staged)
+    const int k6_threads = (shs && K > 1) ? 128 : 256;
+    const int grid_n = (int)fmin((double)((N + k6_threads - 1) / k6_threads), (double)k6_grid * (256 / k6_threads));
+    const size_t lds = (shs && K > 1) ? (size_t)k6_threads * (3 * K + 1) * 4 : 0;
     if (lds > 160 * 1024) return fail(-1, "preprocess_bwd needs more than 160 KiB of LDS%s", "");
     auto k6 = vc.raw_act ? gsr_preprocess_bwd<true, false> : gsr_preprocess_bwd<false, false>;
     auto k6m = vc.raw_act ? gsr_preprocess_bwd<true, true> : gsr_preprocess_bwd<false, true>;
@@ -737,7 +756,7 @@ int backward_impl(const GsrView* views, int B, int32_t N, int32_t K,
     if (lds == 0 && B > 1) {
         for (int v = 0; v < B; ++v) tab.v[v] = make_view(views + v);
         prof_begin(stream);
-        hipLaunchKernelGGL(k6m, dim3(grid_n), dim3(256), lds, stream, tab, 0, B, N, K, means3D, shs, view->shs_rest, view->dL_dshs_rest,
+        hipLaunchKernelGGL(k6m, dim3(grid_n), dim3(k6_threads), lds, stream, tab, 0, B, N, K, means3D, shs, view->shs_rest, view->dL_dshs_rest,
                            colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, flags8, g2d,
                            dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacities, dL_dscales, dL_drotations, dL_dcov3D, 0);
         LAUNCH_CHECK(view, stream, "preprocess_bwd");
@@ -745,7 +764,7 @@ int backward_impl(const GsrView* views, int B, int32_t N, int32_t K,
         for (int v = B - 1; v >= 0; --v) {
             tab.v[0] = make_view(views + v);
             prof_begin(stream);
-            hipLaunchKernelGGL(k6, dim3(grid_n), dim3(256), lds, stream, tab, 0, 1, N, K, means3D, shs, view->shs_rest, view->dL_dshs_rest,
+            hipLaunchKernelGGL(k6, dim3(grid_n), dim3(k6_threads), lds, stream, tab, 0, 1, N, K, means3D, shs, view->shs_rest, view->dL_dshs_rest,
                                colors_precomp, opacities, scales, rotations, cov3D_precomp, radii + (size_t)v * N, flags8 + (size_t)v * N,
                                g2d + (size_t)v * g2d_view, dL_dmeans3D, dL_dmeans2D + (size_t)v * N * 3, dL_dshs, dL_dcolors, dL_dopacities,
                                dL_dscales, dL_drotations, dL_dcov3D, v == B - 1 ? 0 : 1);

@@ -176,118 +176,117 @@ gsr_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ ti
 
 // ---------------------------------------------------------------------------------------
 // K3: scatter (depth bits, id) keys into the tile segments.
-// dynamic LDS: nTiles uint32 when hist_in_lds.
+//
+// The forward's work items ride along in both kernels (they wait on scattered stores most of their time): one 16-byte record per
+// (tile, segment) of the segment forward -- {tile, list start, segment record, segment << 8 | entries - 1} -- in the depth-major
+// order gsr_tile_scan defined (item k = level c, tile order[k - level_off[c]]), so that a workgroup of gsr_render_fwd_seg learns
+// everything about its item from ONE scalar load instead of a chain of five dependent ones.
 // ---------------------------------------------------------------------------------------
-#define GSR_SC_R 8      // emission records a thread of gsr_scatter holds in registers per round
+__device__ __forceinline__ void write_forward_items(const uint32_t* __restrict__ level_off, const uint32_t* __restrict__ order,
+                                                    const uint32_t* __restrict__ tile_off, const uint32_t* __restrict__ tile_seg,
+                                                    int seg_shift, uint4* __restrict__ items, uint32_t items_cap, uint32_t* lev /* LDS [GSR_NLEV + 1] */) {
+    for (int i = threadIdx.x; i <= GSR_NLEV; i += 256) lev[i] = level_off[i];
+    lds_barrier();
+    const uint32_t total = min(lev[GSR_NLEV], items_cap);
+    const uint32_t nthreads = gridDim.x * gridDim.y * 256u, gid = (blockIdx.y * gridDim.x + blockIdx.x) * 256u + threadIdx.x;
+    for (uint32_t k = gid; k < total; k += nthreads) {
+        uint32_t lo = 0, hi = GSR_NLEV;               // lev[lo] <= k < lev[hi]
+        while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (lev[mid] <= k) lo = mid; else hi = mid; }
+        const uint32_t t = order[k - lev[lo]];
+        const uint32_t s0 = tile_off[t], n = tile_off[t + 1] - s0, first = lo << seg_shift;
+        const uint32_t len = min(1u << seg_shift, n - first);
+        items[k] = make_uint4(t, s0, tile_seg[t] + lo, (lo << 8) | (len - 1u));
+    }
+}
+
+// LDS-histogram mode (tile grids of up to 16 384 tiles): K1's twin. Same grid, same Gaussians per workgroup (batches blockIdx.x,
+// blockIdx.x + gridDim.x, ... of 256): K1's histogram flush has reserved, per tile, the range of this workgroup's entries
+// (wg_base); the positions inside it are handed out from LDS. ONE pass, no global atomics.
+// dynamic LDS: nTiles uint32.
+#define GSR_SC_R 4      // emission records a thread requests at once (K1's default grid: four batches per workgroup)
 extern "C" __global__ void __launch_bounds__(256)
 gsr_scatter(int N, const EmitRec* __restrict__ emit, const uint32_t* __restrict__ tile_off,
-            uint32_t* __restrict__ cursor, unsigned long long* __restrict__ entries,
-            int gx, int nTiles, int hist_in_lds, uint32_t capacity, unsigned long long* __restrict__ counters,
+            const uint32_t* __restrict__ wg_base, unsigned long long* __restrict__ entries,
+            int gx, int nTiles, uint32_t capacity, unsigned long long* __restrict__ counters,
             const uint32_t* __restrict__ level_off, const uint32_t* __restrict__ order, const uint32_t* __restrict__ tile_seg,
             int seg_shift, uint4* __restrict__ items, uint32_t items_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    uint32_t* hist = reinterpret_cast<uint32_t*>(smem_raw);
+    uint32_t* next = reinterpret_cast<uint32_t*>(smem_raw);      // [nTiles]: the next free position of this workgroup's range in the tile's list
     // The scratch may have been sized BEFORE the host knew M (gsr_forward: previous call + 25 %). M is on the
     // device: every consumer of the lists leaves at once when they do not fit, and the host repeats the tail.
     if (counters[2] > (unsigned long long)capacity) return;
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) counters[6] = capacity;    // for a backward called without GsrStats
-    {   // Riding along (this kernel waits on scattered stores most of its time): the segment forward's work items, one 16-byte
-        // record each -- {tile, list start, segment record, segment << 8 | entries - 1} -- in the depth-major order
-        // gsr_tile_scan defined (item k = level c, tile order[k - level_off[c]]), so that a workgroup of gsr_render_fwd_seg
-        // learns everything about its item from ONE scalar load instead of a chain of five dependent ones.
-        __shared__ uint32_t lev[GSR_NLEV + 1];
-        for (int i = threadIdx.x; i <= GSR_NLEV; i += 256) lev[i] = level_off[i];
-        lds_barrier();
-        const uint32_t total = min(lev[GSR_NLEV], items_cap);
-        const uint32_t nthreads = gridDim.x * gridDim.y * 256u, gid = (blockIdx.y * gridDim.x + blockIdx.x) * 256u + threadIdx.x;
-        for (uint32_t k = gid; k < total; k += nthreads) {
-            uint32_t lo = 0, hi = GSR_NLEV;               // lev[lo] <= k < lev[hi]
-            while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (lev[mid] <= k) lo = mid; else hi = mid; }
-            const uint32_t t = order[k - lev[lo]];
-            const uint32_t s0 = tile_off[t], n = tile_off[t + 1] - s0, first = lo << seg_shift;
-            const uint32_t len = min(1u << seg_shift, n - first);
-            items[k] = make_uint4(t, s0, tile_seg[t] + lo, (lo << 8) | (len - 1u));
-        }
-    }
+    __shared__ uint32_t lev[GSR_NLEV + 1];
+    if (items_cap) write_forward_items(level_off, order, tile_off, tile_seg, seg_shift, items, items_cap, lev);
     // blockIdx.y = view: its records and its tiles (tile_off holds positions in the one list array of all views)
     emit += (size_t)blockIdx.y * (size_t)N;
     tile_off += (size_t)blockIdx.y * nTiles;
-    cursor += (size_t)blockIdx.y * nTiles;
-    if (!hist_in_lds) {       // grids beyond the LDS histogram: one pass, a global cursor per tile
-        for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < N; idx += gridDim.x * blockDim.x) {
-            const uint4 em = reinterpret_cast<const uint4*>(emit)[idx];
-            const int x0 = em.x & 0xffff, x1 = em.x >> 16, y0 = em.y & 0xffff, y1 = em.y >> 16;
-            const unsigned long long key = ((unsigned long long)em.z << 32) | (uint32_t)idx;
-            const bool masked = (x1 - x0) * (y1 - y0) <= GSR_EMIT_MASK_TILES;
-            uint32_t bit = 1u;
-            for (int ty = y0; ty < y1; ++ty)
-                for (int tx = x0; tx < x1; ++tx, bit <<= 1) {
-                    if (masked && !(em.w & bit)) continue;
-                    const int t = ty * gx + tx;
-                    const uint32_t pos = tile_off[t] + atomicAdd(&cursor[t], 1u);
-                    if (pos < capacity) entries[pos] = key;
-                }
-        }
-        return;
-    }
-    // The workgroup counts its Gaussians' emissions per tile in LDS, reserves one range per tile it touches (one global atomic
-    // each), and hands the positions out from LDS. Both passes need the emission records: a thread keeps its GSR_SC_R records in
-    // REGISTERS -- all loads of a pass in flight at once and no second trip to memory (the kernel is a latency chain on two
-    // workgroups per CU: with the records re-read per pass and per iteration it spent 2 x 8 dependent load latencies).
+    const uint32_t* __restrict__ base_row = wg_base + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * nTiles;
     const int stride = gridDim.x * 256;
-    for (int round0 = 0; round0 < N; round0 += GSR_SC_R * stride) {          // (block-uniform trip count: barriers inside)
-        const int base = round0 + blockIdx.x * 256 + threadIdx.x;
-        uint4 em[GSR_SC_R];
+    const int first = blockIdx.x * 256 + threadIdx.x;
+    // a thread's first records travel while the ranges are loaded
+    uint4 em[GSR_SC_R];
 #pragma unroll
-        for (int r = 0; r < GSR_SC_R; ++r)     // branch-free (index clamped): a load inside a divergent `if` is waited for on the spot
-            em[r] = reinterpret_cast<const uint4*>(emit)[min(base + r * stride, N - 1)];
+    for (int r = 0; r < GSR_SC_R; ++r) em[r] = reinterpret_cast<const uint4*>(emit)[min(first + r * stride, N - 1)];   // branch-free (index clamped)
+    for (int t0 = threadIdx.x; t0 < nTiles; t0 += 256 * 4) {      // (eight loads in flight per thread; entries of tiles nobody here emits into: never used)
+        uint32_t a[4], b[4];
 #pragma unroll
-        for (int r = 0; r < GSR_SC_R; ++r)
-            if (base + r * stride >= N) em[r] = make_uint4(0u, 0u, 0u, 0u);                                // all-zero = empty rectangle
-        for (int t = threadIdx.x; t < nTiles; t += 256) hist[t] = 0;
-        lds_barrier();
+        for (int u = 0; u < 4; ++u) { const int t = min(t0 + 256 * u, nTiles - 1); a[u] = tile_off[t]; b[u] = base_row[t]; }
 #pragma unroll
-        for (int r = 0; r < GSR_SC_R; ++r) {
-            const int x0 = em[r].x & 0xffff, x1 = em[r].x >> 16, y0 = em[r].y & 0xffff, y1 = em[r].y >> 16;
-            const bool masked = (x1 - x0) * (y1 - y0) <= GSR_EMIT_MASK_TILES;
-            uint32_t bit = 1u;
-            for (int ty = y0; ty < y1; ++ty)
-                for (int tx = x0; tx < x1; ++tx, bit <<= 1)
-                    if (!masked || (em[r].w & bit)) atomicAdd(&hist[ty * gx + tx], 1u);
-        }
-        lds_barrier();
-        const int t0 = (int)((blockIdx.x * 67u) % (unsigned)nTiles);   // staggered: see K1's flush
-        // one range per tile this workgroup emits into: four reservations (atomics WITH return) in flight per thread, not one
-        for (int i0 = threadIdx.x; i0 < nTiles; i0 += 256 * 4) {
-            int tt[4]; uint32_t cc[4], off4[4], got[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = min(i0 + 256 * u, nTiles - 1);
-                int t = t0 + i; if (t >= nTiles) t -= nTiles;
-                tt[u] = t;
-                cc[u] = i0 + 256 * u < nTiles ? hist[t] : 0u;
-                off4[u] = tile_off[t];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { got[u] = 0u; if (cc[u]) got[u] = atomicAdd(&cursor[tt[u]], cc[u]); }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) if (i0 + 256 * u < nTiles) hist[tt[u]] = cc[u] ? off4[u] + got[u] : 0u;
-        }
-        lds_barrier();
+        for (int u = 0; u < 4; ++u) if (t0 + 256 * u < nTiles) next[t0 + 256 * u] = a[u] + b[u];
+    }
+    lds_barrier();
+    for (int base = first; base < N; base += GSR_SC_R * stride) {
 #pragma unroll
         for (int r = 0; r < GSR_SC_R; ++r) {
-            const int x0 = em[r].x & 0xffff, x1 = em[r].x >> 16, y0 = em[r].y & 0xffff, y1 = em[r].y >> 16;
-            const unsigned long long key = ((unsigned long long)em[r].z << 32) | (uint32_t)(base + r * stride);
+            const int idx = base + r * stride;
+            if (idx >= N) break;
+            const uint4 e = em[r];
+            const int x0 = e.x & 0xffff, x1 = e.x >> 16, y0 = e.y & 0xffff, y1 = e.y >> 16;
+            const unsigned long long key = ((unsigned long long)e.z << 32) | (uint32_t)idx;
             const bool masked = (x1 - x0) * (y1 - y0) <= GSR_EMIT_MASK_TILES;
             uint32_t bit = 1u;
             for (int ty = y0; ty < y1; ++ty)
                 for (int tx = x0; tx < x1; ++tx, bit <<= 1) {
-                    if (masked && !(em[r].w & bit)) continue;
-                    const uint32_t pos = atomicAdd(&hist[ty * gx + tx], 1u);
+                    if (masked && !(e.w & bit)) continue;
+                    const uint32_t pos = atomicAdd(&next[ty * gx + tx], 1u);
                     if (pos < capacity) entries[pos] = key;
                 }
         }
-        lds_barrier();                                  // the histogram is zeroed again by the next round
+        if (base + GSR_SC_R * stride < N) {           // grids pinned below K1's default: more than GSR_SC_R batches per workgroup
+#pragma unroll
+            for (int r = 0; r < GSR_SC_R; ++r) em[r] = reinterpret_cast<const uint4*>(emit)[min(base + (GSR_SC_R + r) * stride, N - 1)];
+        }
+    }
+}
+
+// Tile grids beyond the LDS histogram (more than 16 384 tiles): one pass, a global cursor per tile.
+extern "C" __global__ void __launch_bounds__(256)
+gsr_scatter_global(int N, const EmitRec* __restrict__ emit, const uint32_t* __restrict__ tile_off,
+                   uint32_t* __restrict__ cursor, unsigned long long* __restrict__ entries,
+                   int gx, int nTiles, uint32_t capacity, unsigned long long* __restrict__ counters,
+                   const uint32_t* __restrict__ level_off, const uint32_t* __restrict__ order, const uint32_t* __restrict__ tile_seg,
+                   int seg_shift, uint4* __restrict__ items, uint32_t items_cap) {
+    if (counters[2] > (unsigned long long)capacity) return;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) counters[6] = capacity;    // for a backward called without GsrStats
+    __shared__ uint32_t lev[GSR_NLEV + 1];
+    if (items_cap) write_forward_items(level_off, order, tile_off, tile_seg, seg_shift, items, items_cap, lev);
+    emit += (size_t)blockIdx.y * (size_t)N;
+    tile_off += (size_t)blockIdx.y * nTiles;
+    cursor += (size_t)blockIdx.y * nTiles;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < N; idx += gridDim.x * blockDim.x) {
+        const uint4 em = reinterpret_cast<const uint4*>(emit)[idx];
+        const int x0 = em.x & 0xffff, x1 = em.x >> 16, y0 = em.y & 0xffff, y1 = em.y >> 16;
+        const unsigned long long key = ((unsigned long long)em.z << 32) | (uint32_t)idx;
+        const bool masked = (x1 - x0) * (y1 - y0) <= GSR_EMIT_MASK_TILES;
+        uint32_t bit = 1u;
+        for (int ty = y0; ty < y1; ++ty)
+            for (int tx = x0; tx < x1; ++tx, bit <<= 1) {
+                if (masked && !(em.w & bit)) continue;
+                const int t = ty * gx + tx;
+                const uint32_t pos = tile_off[t] + atomicAdd(&cursor[t], 1u);
+                if (pos < capacity) entries[pos] = key;
+            }
     }
 }
 

@@ -255,7 +255,8 @@ gsr_preprocess_fwd(ViewTab views /* camera of this workgroup: views.v[blockIdx.y
                    int hist_in_lds,
                    uint8_t* __restrict__ flags8 /* colour-clamp bits for K6: 1 B instead of a 64-B record line */,
                    uint32_t* __restrict__ zero_base /* tile_count | cursor | counters of ALL views: zeroed here, by workgroup (0, 0) */,
-                   uint32_t zero_words, uint32_t flag_word /* (even) index in zero_base of the 64-bit "zeroed" flag */, unsigned long long epoch) {
+                   uint32_t zero_words, uint32_t flag_word /* (even) index in zero_base of the 64-bit "zeroed" flag */, unsigned long long epoch,
+                   uint32_t* __restrict__ wg_base /* [views][grid][nTiles]: where this workgroup's entries start inside each tile's list (LDS-histogram mode) */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_pp[];
     const ViewConst vc = views.v[blockIdx.y];
     // The per-tile counts, the scatter's cursors and the counters start from zero: workgroup (0, 0) -- the first the dispatcher
@@ -596,11 +597,25 @@ gsr_preprocess_fwd(ViewTab views /* camera of this workgroup: views.v[blockIdx.y
     if (hist_in_lds) {
         wait_zeroed();
         // every workgroup starts its flush at a different tile: no burst of atomics on one address
+        // The flush RESERVES: the value the atomic returns is the number of entries other workgroups have claimed in that tile's list so
+        // far = where this workgroup's entries start. It goes to wg_base; gsr_scatter, on the same grid with the same Gaussians, hands
+        // positions out from there -- no counting pass and no reservation atomics of its own (round 3: one returning atomic per
+        // (workgroup round, tile) in the scatter ON TOP of the ones here).
+        uint32_t* __restrict__ base_row = wg_base + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * nTiles;
         const int t0 = (int)((blockIdx.x * 67u) % (unsigned)nTiles);
-        for (int i = threadIdx.x; i < nTiles; i += blockDim.x) {
-            int t = t0 + i; if (t >= nTiles) t -= nTiles;
-            const uint32_t c = hist[t];
-            if (c) atomicAdd(&tile_count[t], c);
+        for (int i0 = threadIdx.x; i0 < nTiles; i0 += 256 * 4) {          // four returning atomics in flight per thread
+            int tt[4]; uint32_t cc[4], got[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = min(i0 + 256 * u, nTiles - 1);
+                int t = t0 + i; if (t >= nTiles) t -= nTiles;
+                tt[u] = t;
+                cc[u] = i0 + 256 * u < nTiles ? hist[t] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { got[u] = 0u; if (cc[u]) got[u] = atomicAdd(&tile_count[tt[u]], cc[u]); }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (cc[u]) base_row[tt[u]] = got[u];
         }
     }
 }

@@ -113,7 +113,8 @@ int gsr_abi_version(void);
  *   "fwd_lists"    1 = 8x8 block lists, 2 = quad lists in the forward compositing
  *   "fwd_hints"    1 = off, 2 = every segment behind a tile's first skipped (the chaining kernel walks them all)
  *   "speculate"    0 = gsr_forward waits for the instance count before binning
- *   "hist_max" "k1_grid" "scatter_grid" "fwd_grid" "k6_grid"   launch geometry (A/B measurements, multi-round paths)
+ *   "hist_max" "k1_grid" "fwd_grid" "k6_grid"   launch geometry (A/B measurements, multi-round paths; "k1_grid" is the grid of
+ *                  K1 AND of the scatter kernel, which continues K1's per-workgroup list ranges)
  * Returns 0, or -1 for an unknown name. dreamgaussian_amd/_testing.py wraps it. */
 int gsr_testing_override(const char* name, int32_t value);
 

@@ -33,9 +33,9 @@ def test_hot_kernels_have_no_loads_waited_for_on_the_spot(asm):
         "_Z21gsr_render_fwd_serialILb1E": 1,      # the work-list reservation (returning atomic) at the end
         "_Z21gsr_render_fwd_serialILb0E": 1,
         "_Z17gsr_render_bwd_q2": 4,               # later rounds of segments longer than 64 entries: list entry -> records
-        "gsr_scatter": 9,                         # the segment forward's work items, the non-LDS-histogram path, the reservations' use
-        "_Z18gsr_preprocess_fwdILb0E": 9,         # camera staging, cov3D_precomp / colors_precomp / degree-0 paths, the two polls of the "counters cleared" tag
-        "_Z18gsr_preprocess_fwdILb1E": 9,
+        "gsr_scatter": 11,                        # the segment forward's work items (rare path), the tail of the eight-deep fetch of the ranges, the refill of a pinned grid's later rounds
+        "_Z18gsr_preprocess_fwdILb0E": 10,        # camera staging, cov3D_precomp / colors_precomp / degree-0 paths, the two polls of the "counters cleared" tag,
+        "_Z18gsr_preprocess_fwdILb1E": 10,        # the last of the flush's four reserving atomics (their results are what is stored)
         "_Z18gsr_preprocess_bwdILb0ELb0E": 14,    # camera staging, the accumulate read-modify-write of views after the first, the
         "_Z18gsr_preprocess_bwdILb1ELb0E": 15,    # row-predicated element loads of the split / odd-row-length staging paths
     }

@@ -443,11 +443,11 @@ def test_stage1_trained_gaussians_match_oracle(gpu, golden_dir, size, el, az):
 
 @pytest.mark.parametrize("N,size", [(3_000, 96), (20_000, 200)])
 def test_scatter_with_several_rounds_per_workgroup(gpu, hooks, N, size):
-    """gsr_scatter keeps eight emission records per thread in registers and loops when a workgroup's share is larger
-    (more than 8 x 256 x grid Gaussians: beyond 1M at the default grid of 512). With a grid of ONE workgroup (test hook
-    scatter_grid) 3 000 - 20 000 Gaussians take 2 - 10 rounds: the tile histogram re-zeroed and the list cursors carried
-    from round to round. Against the fp64 oracle, twice (the second call speculates on the first one's counts)."""
-    hooks.set("scatter_grid", 1)
+    """gsr_scatter runs on K1's grid with K1's Gaussian -> workgroup assignment (it continues the list ranges K1's histogram flush
+    reserved) and holds four emission records per thread; a workgroup with more batches loops. With a grid of ONE workgroup (test
+    hook k1_grid) 3 000 - 20 000 Gaussians are 12 - 79 batches of K1 and 3 - 20 rounds of the scatter, every tile's list reserved
+    by that one workgroup. Against the fp64 oracle, twice (the second call speculates on the first one's counts)."""
+    hooks.set("k1_grid", 1)
     sc = O.make_scene(N, 1, 11, "trained")
     S = O.make_settings(O.orbit_pose(-12.0, 70.0, 2.0), size, size, sh_degree=1)
     w = weights_for(size, size)
@@ -457,6 +457,10 @@ def test_scatter_with_several_rounds_per_workgroup(gpu, hooks, N, size):
         assert st["V"] == aux["V"]
         assert_forward_close(ho, oo, aux)
         assert_grads_close(hg, og, aux, floors=grad_floors(sc, og))
+    hooks.set("k1_grid", 7)                                # an odd grid: ragged last round
+    ho, hg, st = run_hip(sc, S, gpu, w)
+    assert_forward_close(ho, oo, aux)
+    assert_grads_close(hg, og, aux, floors=grad_floors(sc, og))
 
 
 def test_debug_flag_synchronises_and_reports_the_failing_kernel(gpu):
