@@ -897,12 +897,15 @@ gsr_preprocess_bwd(ViewTab tab, int first_view, int B /* B == 1: the view tab.v[
         const size_t ic = (size_t)min(idx, N - 1);
         K6In in;
         {
-            in.mx = means3D[3 * ic]; in.my = means3D[3 * ic + 1]; in.mz = means3D[3 * ic + 2];
+            // (12-byte vector loads and stores throughout: one request per lane and array instead of three 4-byte ones 12 bytes apart)
+            const gsr_f3 m = *reinterpret_cast<const gsr_f3u*>(means3D + 3 * ic);
+            in.mx = m.x; in.my = m.y; in.mz = m.z;
             in.op = opacities[ic];
             in.q = make_float4(1.f, 0.f, 0.f, 0.f); in.sx = in.sy = in.sz = 0.f;
             if (!cov3D_precomp) {                         // (uniform)
                 in.q = reinterpret_cast<const float4*>(rotations)[ic];
-                in.sx = scales[3 * ic]; in.sy = scales[3 * ic + 1]; in.sz = scales[3 * ic + 2];
+                const gsr_f3 sc3 = *reinterpret_cast<const gsr_f3u*>(scales + 3 * ic);
+                in.sx = sc3.x; in.sy = sc3.y; in.sz = sc3.z;
             }
         }
         K6ViewIn vin0;
@@ -958,7 +961,7 @@ gsr_preprocess_bwd(ViewTab tab, int first_view, int B /* B == 1: the view tab.v[
             }
             const bool live = (idx < N) && (radius > 0) && (MULTI || touched);   // (MULTI: nothing is staged, the views differ)
             k6_gaussian<RAW>(vc, camf[MULTI ? v - first_view : 0], idx, N, K, live, in, vin, shs, cov3D_precomp, dL_dshs, stage, myrow, accumulate, sh_in_regs, cur);
-            if (idx < N) { float* m2 = dL_dmeans2D + ((size_t)v * N + idx) * 3; m2[0] = cur.dm2[0]; m2[1] = cur.dm2[1]; m2[2] = 0.f; }
+            if (idx < N) { const gsr_f3 m2 = {cur.dm2[0], cur.dm2[1], 0.f}; *reinterpret_cast<gsr_f3u*>(dL_dmeans2D + ((size_t)v * N + idx) * 3) = m2; }
             // first pass (the last view): 0 + x = x exactly
 #pragma unroll
             for (int e = 0; e < 3; ++e) { out.dm[e] = out.dm[e] + cur.dm[e]; out.dsc[e] = out.dsc[e] + cur.dsc[e]; out.dcol[e] = out.dcol[e] + cur.dcol[e]; tsh[e] = tsh[e] + cur.dsh[e]; }
@@ -972,24 +975,25 @@ gsr_preprocess_bwd(ViewTab tab, int first_view, int B /* B == 1: the view tab.v[
 
         if (idx < N) {
             if (accumulate) {   // old + new, the order autograd's AccumulateGrad adds a later view's gradient in
-                out.dm[0] = dL_dmeans3D[3 * idx] + out.dm[0]; out.dm[1] = dL_dmeans3D[3 * idx + 1] + out.dm[1]; out.dm[2] = dL_dmeans3D[3 * idx + 2] + out.dm[2];
+                const gsr_f3 om = *reinterpret_cast<const gsr_f3u*>(dL_dmeans3D + 3 * (size_t)idx);
+                out.dm[0] = om.x + out.dm[0]; out.dm[1] = om.y + out.dm[1]; out.dm[2] = om.z + out.dm[2];
                 out.dop = dL_dopac[idx] + out.dop;
                 if (dL_dcolors) { out.dcol[0] = dL_dcolors[3 * idx] + out.dcol[0]; out.dcol[1] = dL_dcolors[3 * idx + 1] + out.dcol[1]; out.dcol[2] = dL_dcolors[3 * idx + 2] + out.dcol[2]; }
                 if (dL_dcov3D) {
 #pragma unroll
                     for (int e = 0; e < 6; ++e) out.dcov[e] = dL_dcov3D[6 * (size_t)idx + e] + out.dcov[e];
                 }
-                if (dL_dscales) { out.dsc[0] = dL_dscales[3 * idx] + out.dsc[0]; out.dsc[1] = dL_dscales[3 * idx + 1] + out.dsc[1]; out.dsc[2] = dL_dscales[3 * idx + 2] + out.dsc[2]; }
+                if (dL_dscales) { const gsr_f3 os = *reinterpret_cast<const gsr_f3u*>(dL_dscales + 3 * (size_t)idx); out.dsc[0] = os.x + out.dsc[0]; out.dsc[1] = os.y + out.dsc[1]; out.dsc[2] = os.z + out.dsc[2]; }
                 if (dL_drots) { const float4 o = reinterpret_cast<const float4*>(dL_drots)[idx]; out.dq[0] = o.x + out.dq[0]; out.dq[1] = o.y + out.dq[1]; out.dq[2] = o.z + out.dq[2]; out.dq[3] = o.w + out.dq[3]; }
             }
-            dL_dmeans3D[3 * idx] = out.dm[0]; dL_dmeans3D[3 * idx + 1] = out.dm[1]; dL_dmeans3D[3 * idx + 2] = out.dm[2];
+            { const gsr_f3 o3 = {out.dm[0], out.dm[1], out.dm[2]}; *reinterpret_cast<gsr_f3u*>(dL_dmeans3D + 3 * (size_t)idx) = o3; }
             dL_dopac[idx] = out.dop;
-            if (dL_dcolors) { dL_dcolors[3 * idx] = out.dcol[0]; dL_dcolors[3 * idx + 1] = out.dcol[1]; dL_dcolors[3 * idx + 2] = out.dcol[2]; }
+            if (dL_dcolors) { const gsr_f3 o3 = {out.dcol[0], out.dcol[1], out.dcol[2]}; *reinterpret_cast<gsr_f3u*>(dL_dcolors + 3 * (size_t)idx) = o3; }
             if (dL_dcov3D) {
 #pragma unroll
                 for (int e = 0; e < 6; ++e) dL_dcov3D[6 * (size_t)idx + e] = out.dcov[e];
             }
-            if (dL_dscales) { dL_dscales[3 * idx] = out.dsc[0]; dL_dscales[3 * idx + 1] = out.dsc[1]; dL_dscales[3 * idx + 2] = out.dsc[2]; }
+            if (dL_dscales) { const gsr_f3 o3 = {out.dsc[0], out.dsc[1], out.dsc[2]}; *reinterpret_cast<gsr_f3u*>(dL_dscales + 3 * (size_t)idx) = o3; }
             if (dL_drots) reinterpret_cast<float4*>(dL_drots)[idx] = make_float4(out.dq[0], out.dq[1], out.dq[2], out.dq[3]);
         }
         if (stage) {
