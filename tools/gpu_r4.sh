@@ -77,6 +77,20 @@ views)
   for m in "--views 8" "--views 8 --views-serial"; do
     timeout 300 python bench.py --workload 250k-512-sh0 --cpu-budget 0 $m 2>gpurun_out/views_err.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['config']['views_mode'], d['value'], 'Mrays/s', d['ms_per_step'], 'ms per 8 views')"
   done;;
+sds)
+  echo "== bench --step sds (1 GPU, no collectives)"; timeout 300 python bench.py --step sds --cpu-budget 0 2>&1 | grep -a "^{" | tee gpurun_out/sds_plain.json | cut -c1-400
+  echo "== bench --step sds --force-collectives (1 GPU, 1-rank RCCL group)"; timeout 300 python bench.py --step sds --cpu-budget 0 --force-collectives 2>&1 | grep -a "^{" | tee gpurun_out/sds_rccl.json | cut -c1-400;;
+cpubase)
+  for wl in 5k-256-sh0 100k-800-sh3; do
+    echo "== bench $wl with the CPU oracle"; timeout 900 python bench.py --workload $wl --cpu-budget ${CPU_BUDGET:-10} 2> gpurun_out/benchcpu_$wl.err | tee gpurun_out/benchcpu_$wl.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['cpu_baseline'])"
+  done;;
+pmcmorton)
+  echo "== rocprofv3 PMC passes, --order morton (1M)"
+  mkdir -p gpurun_out/pmcm
+  for c in "FETCH_SIZE" "WRITE_SIZE"; do
+    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmcm/pmc_$c -o r04 -- python $R/bench.py --steps 3 --warmup 1 --cpu-budget 0 --no-roofline --order morton > $R/gpurun_out/pmcm/pmc_$c.log 2>&1)
+  done
+  python tools/pmc_summary.py gpurun_out/pmcm 2>&1 | tee gpurun_out/pmc_morton_summary.txt | cut -c1-300;;
 smoke)
   timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3;;
 *) echo "unknown section $sec";;
