@@ -126,7 +126,7 @@ int k1_grid_for(int N) {
 }
 
 struct GeomLayout {
-    size_t recs, emit, flags8, block_stats, tile_count, cursor, counters, tile_off, tile_seg, order, level_off, sat, plan_off, g2d, wg_base, total;
+    size_t recs, emit, flags8, block_stats, tile_count, cursor, counters, tile_off, tile_seg, order, order_span, level_off, sat, plan_off, g2d, wg_base, total;
     int nTiles;        // per view
     int allTiles;      // views * nTiles: the per-tile arrays hold every view's tiles, view-major
 };
@@ -150,6 +150,7 @@ GeomLayout geom_layout(int N, int H, int W, int B = 1) {
     L.tile_off = o; o += align_up((BT + 1) * 4);
     L.tile_seg = o; o += align_up((BT + 1) * 4);
     L.order = o; o += align_up(BT * 4);
+    L.order_span = o; o += align_up(BT * 8);                       // (list start, length) of order[k]: what a sort workgroup needs, in one load
     L.level_off = o; o += align_up((GSR_NLEV + 1) * 4);
     L.sat = o; o += align_up(BT * 4 * 8);                         // hint word per (tile, wave) of the segment forward
     L.plan_off = o; o += align_up(BT * 4);
@@ -394,7 +395,7 @@ int begin_impl(const GsrView* views, int B, int32_t N, int32_t K,
     // one single-workgroup kernel: scan of the counts, K1's statistics, the segment forward's depth-major work list
     prof_begin(stream); hipLaunchKernelGGL(gsr_tile_scan, dim3(1), dim3(1024), 0, stream, tile_count, (uint32_t*)(gbuf + GL.tile_off), GL.allTiles, counters,
                        (uint32_t*)(gbuf + GL.tile_seg), shift, (const unsigned long long*)(gbuf + GL.block_stats), N > 0 ? grid_pre * B : 0, B,
-                       (uint32_t*)(gbuf + GL.order), (uint32_t*)(gbuf + GL.level_off), host_counters_dev, counter_words, kCounterWords);
+                       (uint32_t*)(gbuf + GL.order), (uint2*)(gbuf + GL.order_span), (uint32_t*)(gbuf + GL.level_off), host_counters_dev, counter_words, kCounterWords);
     LAUNCH_CHECK(view, stream, "tile_scan");
     // (the scan kernel stores the counters and then the arrival flag into the pinned block itself: no copy kernels and no event
     // marker in the stream -- the marker alone was a 5 us hole in front of the scatter)
@@ -473,14 +474,14 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
         // list up to 8 192 (a short list then runs on its first waves): the two launches were latency chains of their own, one
         // behind the other -- 12 + 32 us at 1M Gaussians against 32 for the merged one (44 -> 33 us with the third class).
         if (maxc <= 2048) {
-            prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<2048, 256, 512>), dim3(TA), dim3(256), lds_s, stream, tile_off, entries, sorted_ids, 0u, 2048u, counters, (uint32_t)M);
+            prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<2048, 256, 512>), dim3(TA), dim3(256), lds_s, stream, tile_off, entries, sorted_ids, 0u, 2048u, counters, (uint32_t)M, (const uint2*)(gbuf + GL.order_span));
             LAUNCH_CHECK(view, stream, "tile_sort_small");
         } else {
-            prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<8192, 1024, 2048>), dim3(TA), dim3(1024), lds_m, stream, tile_off, entries, sorted_ids, 0u, 8192u, counters, (uint32_t)M);
+            prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<8192, 1024, 2048>), dim3(TA), dim3(1024), lds_m, stream, tile_off, entries, sorted_ids, 0u, 8192u, counters, (uint32_t)M, (const uint2*)(gbuf + GL.order_span));
             LAUNCH_CHECK(view, stream, "tile_sort_medium");
         }
         if (maxc > 8192) {
-            prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<16384, 1024, 2048>), dim3(TA), dim3(1024), lds_l, stream, tile_off, entries, sorted_ids, 8192u, 16384u, counters, (uint32_t)M);
+            prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<16384, 1024, 2048>), dim3(TA), dim3(1024), lds_l, stream, tile_off, entries, sorted_ids, 8192u, 16384u, counters, (uint32_t)M, (const uint2*)(gbuf + GL.order_span));
             LAUNCH_CHECK(view, stream, "tile_sort_large");
         }
         if (maxc > 16384) {

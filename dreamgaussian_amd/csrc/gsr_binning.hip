@@ -49,7 +49,8 @@ extern "C" __global__ void __launch_bounds__(1024)
 gsr_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_off, int T,
               unsigned long long* __restrict__ counters, uint32_t* __restrict__ tile_seg, int seg_shift,
               const unsigned long long* __restrict__ block_stats, int nblocks /* all views */, int nviews,
-              uint32_t* __restrict__ order /* tiles by segment count, descending */, uint32_t* __restrict__ level_off /* [1024] */,
+              uint32_t* __restrict__ order /* tiles by segment count, descending */, uint2* __restrict__ order_span /* (list start, length) of order[k] */,
+              uint32_t* __restrict__ level_off /* [1024] */,
               unsigned long long* __restrict__ host_out /* pinned host memory (device-mapped): the first `host_words` counters land in
                                                            words 0.., the arrival flag in word `host_flag` */,
               int host_words, int host_flag) {
@@ -151,13 +152,23 @@ gsr_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ ti
         const uint32_t n = t < T ? tile_count[t] : 0u;
         const bool empty = t < T && n == 0u;
         const unsigned long long em = __ballot(empty);
-        if (t < T && n != 0u) order[atomicAdd(&cls[min((n + round) >> seg_shift, (uint32_t)GSR_NLEV)], 1u)] = (uint32_t)t;
+        // (tile_off was stored by other threads of this workgroup in front of several barriers; the sort kernels take a tile's
+        // (start, length) from ONE load at its position in the order instead of order -> tile_off)
+        if (t < T && n != 0u) {
+            const uint32_t pos = atomicAdd(&cls[min((n + round) >> seg_shift, (uint32_t)GSR_NLEV)], 1u);
+            order[pos] = (uint32_t)t;
+            order_span[pos] = make_uint2(__hip_atomic_load(tile_off + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), n);
+        }
         if (em != 0ull) {
             const int leader = __builtin_ctzll(em);
             uint32_t b = 0;
             if (lane == leader) b = atomicAdd(&cls[0], (uint32_t)__popcll(em));
             b = __builtin_amdgcn_readlane(b, leader);
-            if (empty) order[b + (uint32_t)__popcll(em & ((1ull << lane) - 1ull))] = (uint32_t)t;
+            if (empty) {
+                const uint32_t pos = b + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
+                order[pos] = (uint32_t)t;
+                order_span[pos] = make_uint2(0u, 0u);
+            }
         }
     }
     // The host sizes the list scratch from the counters (gsr_forward's one round trip). They go straight into its pinned block --
@@ -361,15 +372,18 @@ template <int CAP, int NT, int NBMAX>
 __global__ void __launch_bounds__(NT)
 gsr_tile_sort_bucket(const uint32_t* __restrict__ tile_off, const unsigned long long* __restrict__ entries,
                      uint32_t* __restrict__ out_ids, uint32_t lo_excl, uint32_t hi_incl,
-                     const unsigned long long* __restrict__ counters, uint32_t capacity) {
+                     const unsigned long long* __restrict__ counters, uint32_t capacity,
+                     const uint2* __restrict__ order_span /* (list start, length) of the tiles, longest lists first (gsr_tile_scan) */) {
     if (counters[2] > (unsigned long long)capacity) return;            // lists do not fit the scratch (see gsr_scatter)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem_raw);
     uint32_t* off = reinterpret_cast<uint32_t*>(smem_raw + (size_t)CAP * 8);
     uint32_t* cur = off + (NBMAX + 1);
     uint32_t* red = cur + NBMAX;                       // [0..15] wave partials, [32] min, [33] max, [34] max bucket
-    const uint32_t s = tile_off[blockIdx.x];
-    const uint32_t n = tile_off[blockIdx.x + 1] - s;
+    // longest lists first: a tile is a latency chain of its own (eight barriers), and with two 80 KiB workgroups per CU the
+    // launch is two rounds deep -- the long chains start in the first, the short ones fill in behind them
+    const uint2 span = order_span[blockIdx.x];
+    const uint32_t s = span.x, n = span.y;
     if (n <= lo_excl || n > hi_incl) return;
     const unsigned long long* __restrict__ src = entries + s;
     const int lane = threadIdx.x & 63;
@@ -470,6 +484,6 @@ gsr_tile_sort_global_ids(const uint32_t* __restrict__ tile_off, unsigned long lo
     for (uint32_t i = threadIdx.x; i < n; i += 1024) out_ids[s + i] = (uint32_t)entries[s + i];
 }
 
-template __global__ void gsr_tile_sort_bucket<2048, 256, 512>(const uint32_t*, const unsigned long long*, uint32_t*, uint32_t, uint32_t, const unsigned long long*, uint32_t);
-template __global__ void gsr_tile_sort_bucket<8192, 1024, 2048>(const uint32_t*, const unsigned long long*, uint32_t*, uint32_t, uint32_t, const unsigned long long*, uint32_t);
-template __global__ void gsr_tile_sort_bucket<16384, 1024, 2048>(const uint32_t*, const unsigned long long*, uint32_t*, uint32_t, uint32_t, const unsigned long long*, uint32_t);
+template __global__ void gsr_tile_sort_bucket<2048, 256, 512>(const uint32_t*, const unsigned long long*, uint32_t*, uint32_t, uint32_t, const unsigned long long*, uint32_t, const uint2*);
+template __global__ void gsr_tile_sort_bucket<8192, 1024, 2048>(const uint32_t*, const unsigned long long*, uint32_t*, uint32_t, uint32_t, const unsigned long long*, uint32_t, const uint2*);
+template __global__ void gsr_tile_sort_bucket<16384, 1024, 2048>(const uint32_t*, const unsigned long long*, uint32_t*, uint32_t, uint32_t, const unsigned long long*, uint32_t, const uint2*);
