@@ -924,7 +924,7 @@ __device__ __forceinline__ int row_radius_exp(float gx, float gy, float tcx, flo
 
 __global__ void __launch_bounds__(256, 4)   // <= 128 VGPRs: four workgroups per CU (LDS: 34 KiB + 5 KiB table at 64-entry segments)
 gsr_render_bwd_q2(GSR_BWD_PARAMS) {
-    __shared__ float4 stage[4][3][GSR_RB];                                   // 12 KiB staged records, slot = fetching lane
+    __shared__ float4 stage[4][3][GSR_RB + 1];                               // 12 KiB staged records, slot = fetching lane; slot 64 = an all-zero record (opacity 0: never blends)
     __shared__ __attribute__((aligned(8))) uint8_t qlist[4][4][GSR_QL_PITCH]; // 1.25 KiB [wave][quad][k] = staged slot of the quad's k-th entry
     __shared__ __attribute__((aligned(16))) float mw[4][4][GSR_Q2_BATCH * GSR_Q2_KSTRIDE];   // 20 KiB
     __shared__ uint32_t gmax_w[4];                                           // per wave: max of gsum over its pixels (bits of a non-negative float)
@@ -998,7 +998,7 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
     // ... and read FINITE numbers: pass 1 is branch-free, a lane past its quad's list runs the arithmetic on whatever its stale slot
     // holds with alpha = 0 (0 * garbage must stay 0). A stale list byte is 0 (cleared above) or a slot an earlier round staged a
     // real record in: slot 0 is the only one that can be read before it was ever written
-    if (lane < 3) stage[wave][lane][0] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < 3) { stage[wave][lane][0] = make_float4(0.f, 0.f, 0.f, 0.f); stage[wave][lane][GSR_RB] = make_float4(0.f, 0.f, 0.f, 0.f); }
     float4* __restrict__ sa = stage[wave][0];
     float4* __restrict__ sb = stage[wave][1];
     float4* __restrict__ sc = stage[wave][2];
@@ -1039,6 +1039,9 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
     const float T_in = ck0;
     float T = T_in, Cgf = 0.f;
     if (seg > 0) Cgf = ck1 * gC0 + ck2 * gC1 + ck3 * gC2 + ck4 * gD + ck5 * gA;
+    // what is composited behind the entry at hand, its own share included: (everything) - (in front of it); every entry takes its
+    // share off (one fma) and what is left IS the numerator of its dL/dalpha
+    float Rb = Cg_behind0 - Cgf;
     const float bx0 = (float)bx, by0 = (float)by;
     // pass 1 writes (m, w) of pixel l15 of entry k to mw1[k * KSTRIDE]; pass 2 lane (h2, k2) reads mw2[0..15]
     float* __restrict__ mw1 = &mw[wave][row][(l15 >> 3) * GSR_Q2_HSTRIDE + (l15 & 7) * 2];
@@ -1059,25 +1062,25 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
     // exactly) instead of sitting out an exec-masked region with its s_and_saveexec / s_cbranch_execz pair.
 #define GSR_Q2_POWER(ea, eb, pw_)                                                                \
         const float pw_ = splat_power(ea.z, ea.w, eb.x, ea.x - pxf, ea.y - pyf);
-#define GSR_Q2_HEAD(eb, ec, pw_, G_, kpos, valid, ae_, al_, om_, cgi_)                            \
+#define GSR_Q2_HEAD(eb, ec, pw_, G_, slot_, ae_, al_, om_, cgi_)                                \
         float ae_, al_, om_, cgi_;                                                                    \
         {                                                                                        \
             const float araw = eb.y * G_;                                                        \
-            /* alpha = min(0.99, araw) >= 1/255  <=>  araw >= 1/255: the forward's decision, bit for bit */ \
+            /* alpha = min(0.99, araw) >= 1/255  <=>  araw >= 1/255: the forward's decision, bit for bit; the list position against */ \
+            /* the pixel's last contributor as (staged slot) <= (last - first position of the round - 1): one compare */ \
             /* (plain `&`: no short-circuit, or the compiler rebuilds the exec-masked regions around the exponential) */ \
-            const bool ok = (bool)((int)(valid) & (int)((kpos) <= last_contrib) & (int)(pw_ <= 0.f) & (int)(araw >= (1.0f / 255.0f))); \
+            const bool ok = (bool)((int)((int)(slot_) <= last_rel) & (int)(pw_ <= 0.f) & (int)(araw >= (1.0f / 255.0f))); \
             ae_ = ok ? araw : 0.f;                                                               \
             al_ = __builtin_amdgcn_fmed3f(ae_, 0.f, 0.99f);   /* min(0.99, a_eff), a_eff >= 0: one instruction, no canonicalising v_max in front */ \
             om_ = 1.f - al_;                                                                     \
-            cgi_ = eb.z * gC0 + eb.w * gC1 + ec.x * gC2 + ec.y * gD + gA;                        \
+            cgi_ = fmaf(eb.z, gC0, fmaf(eb.w, gC1, fmaf(ec.x, gC2, fmaf(ec.y, gD, gA))));        \
         }
 #define GSR_Q2_TAIL(ae_, al_, om_, rc_, cgi_, kslot)                                             \
         {                                                                                        \
             const float w = al_ * T;                                                             \
-            const float wc = w * cgi_;                                                           \
-            const float dL_dal = T * cgi_ - (Cg_behind0 - Cgf - wc) * rc_;                       \
+            Rb = fmaf(-w, cgi_, Rb);                          /* behind this entry, without it */ \
+            const float dL_dal = fmaf(T, cgi_, -(Rb * rc_));                                     \
             const float m = dL_dal * ae_;                     /* (opacity * dL/dalpha) * G */     \
-            Cgf += wc;                                                                           \
             T *= om_;                                                                            \
             *reinterpret_cast<float2*>(mw1 + (kslot) * GSR_Q2_KSTRIDE) = make_float2(m, w);       \
         }
@@ -1121,7 +1124,16 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
         const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
         const int nmax = max(max(n0, n1), max(n2, n3));
         const int nmine = row == 0 ? n0 : (row == 1 ? n1 : (row == 2 ? n2 : n3));
+        {   // a list shorter than the longest one is padded with the all-zero record up to the last batch the loop below reads: pass 1
+            // then needs no "is this entry inside my list" test per entry (opacity 0 fails the alpha test by itself)
+            const int nread = (nmax + GSR_Q2_BATCH - 1) & ~(GSR_Q2_BATCH - 1);
+            if (lane >= n0 && lane < nread) qlist[wave][0][lane] = (uint8_t)GSR_RB;
+            if (lane >= n1 && lane < nread) qlist[wave][1][lane] = (uint8_t)GSR_RB;
+            if (lane >= n2 && lane < nread) qlist[wave][2][lane] = (uint8_t)GSR_RB;
+            if (lane >= n3 && lane < nread) qlist[wave][3][lane] = (uint8_t)GSR_RB;
+        }
         const uint32_t accrow0 = pos0 - seg_lo;           // table row of staged slot 0
+        const int last_rel = (int)last_contrib - (int)pos0 - 1;   // staged slot s is list position pos0 + s + 1 (1-based)
         wave_lds_handoff();
         for (int jb = 0; jb < nmax; jb += GSR_Q2_BATCH) {
             // ---- pass 1: entries jb .. jb+7 of every quad list (stale slots beyond a list: in range, masked)
@@ -1140,8 +1152,8 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
                     GSR_Q2_POWER(fa, fb, pw1)
                     float G0, G1, rc0, rc1;
                     GSR_TRANS_PAIR("v_exp_f32", G0, G1, pw0, pw1)
-                    GSR_Q2_HEAD(eb, ec, pw0, G0, pos0 + slot[b] + 1u, jb + b < nmine, ae0, al0, om0, cgi0)
-                    GSR_Q2_HEAD(fb, fc, pw1, G1, pos0 + slot[b + 1] + 1u, jb + b + 1 < nmine, ae1, al1, om1, cgi1)
+                    GSR_Q2_HEAD(eb, ec, pw0, G0, slot[b], ae0, al0, om0, cgi0)
+                    GSR_Q2_HEAD(fb, fc, pw1, G1, slot[b + 1], ae1, al1, om1, cgi1)
                     if (b + 2 < GSR_Q2_BATCH) {
                         ea = sa[slot[b + 2]]; eb = sb[slot[b + 2]]; ec = sc[slot[b + 2]];
                         fa = sa[slot[b + 3]]; fb = sb[slot[b + 3]]; fc = sc[slot[b + 3]];
