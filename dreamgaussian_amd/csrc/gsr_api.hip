@@ -754,10 +754,14 @@ int backward_impl(const GsrView* views, int B, int32_t N, int32_t K,
     ViewTab tab;
     memset(&tab, 0, sizeof(tab));
     const uint8_t* flags8 = (const uint8_t*)(gbuf + GL.flags8);
-    if (lds == 0 && B > 1) {
+    // several views in ONE launch: always when nothing is staged; with staged SH rows when input + output rows of a workgroup fit
+    // the CU's LDS twice over (two workgroups per CU at least): 50 KiB at 16 coefficients
+    const size_t lds_multi = 2 * lds;
+    if (B > 1 && lds_multi <= 80 * 1024) {
         for (int v = 0; v < B; ++v) tab.v[v] = make_view(views + v);
+        if (lds_multi > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k6m, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi));
         prof_begin(stream);
-        hipLaunchKernelGGL(k6m, dim3(grid_n), dim3(k6_threads), lds, stream, tab, 0, B, N, K, means3D, shs, view->shs_rest, view->dL_dshs_rest,
+        hipLaunchKernelGGL(k6m, dim3(grid_n), dim3(k6_threads), lds_multi, stream, tab, 0, B, N, K, means3D, shs, view->shs_rest, view->dL_dshs_rest,
                            colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, flags8, g2d,
                            dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacities, dL_dscales, dL_drotations, dL_dcov3D, 0);
         LAUNCH_CHECK(view, stream, "preprocess_bwd");

@@ -643,7 +643,9 @@ template <bool RAW>
 __device__ __forceinline__ void k6_gaussian(const ViewConst& vc, const float* cam /* LDS: view[16] | proj[16] | campos[3] */, int idx, int N, int K, bool live,
                                             const K6In& in, const K6ViewIn& vin, const float* __restrict__ shs,
                                             const float* __restrict__ cov3D_precomp,
-                                            float* __restrict__ dL_dshs, bool stage, float* myrow, int accumulate,
+                                            float* __restrict__ dL_dshs, bool stage, const float* myrow /* staged SH row (input) */,
+                                            float* myrow_out /* LDS row of dL/dSH (the same row as the input for one view per launch) */,
+                                            bool lds_accum /* several views per launch: add to myrow_out instead of overwriting it */, int accumulate,
                                             bool sh_reg /* K == 1, several views per launch: dL/dSH of this view goes to out.dsh */, K6Out& out) {
     const int rowlen = 3 * K;
     const bool use_sh = (shs != nullptr);
@@ -732,16 +734,17 @@ __device__ __forceinline__ void k6_gaussian(const ViewConst& vc, const float* ca
             }
             // dL/dSH: write this lane's row (the staged input row is dead now)
             if (sh_reg) { out.dsh[0] = B[0] * gr; out.dsh[1] = B[0] * gg; out.dsh[2] = B[0] * gb; }
-            float* o = stage ? myrow : (dL_dshs + (size_t)idx * rowlen);
+            float* o = stage ? myrow_out : (dL_dshs + (size_t)idx * rowlen);
+            const bool add = stage ? lds_accum : (accumulate != 0);     // (K == 1 without staging: straight to HBM)
 #pragma unroll
             for (int k = 0; k < 16 && !sh_reg; ++k) {
                 if (k < K) {
                     const float bk = (k < nb) ? B[k] : 0.f;
-                    if (!stage && accumulate && !sh_reg) { o[3 * k] += bk * gr; o[3 * k + 1] += bk * gg; o[3 * k + 2] += bk * gb; }   // K == 1: straight to HBM
+                    if (add) { o[3 * k] = o[3 * k] + bk * gr; o[3 * k + 1] = o[3 * k + 1] + bk * gg; o[3 * k + 2] = o[3 * k + 2] + bk * gb; }   // old + new
                     else { o[3 * k] = bk * gr; o[3 * k + 1] = bk * gg; o[3 * k + 2] = bk * gb; }
                 }
             }
-            if (!sh_reg && (stage || !accumulate)) for (int e = 48; e < rowlen; ++e) o[e] = 0.f;   // K > 16: inactive coefficients
+            if (!sh_reg && !add) for (int e = 48; e < rowlen; ++e) o[e] = 0.f;   // K > 16: inactive coefficients
         }
 
         // ---- conic -> cov2D -> (Sigma, t) -------------------------------------------
@@ -838,7 +841,7 @@ __device__ __forceinline__ void k6_gaussian(const ViewConst& vc, const float* ca
 #pragma unroll
         for (int k = 0; k < 3; ++k) out.dm[k] += V[4 * k] * dtx + V[4 * k + 1] * dty + V[4 * k + 2] * dtz;
     } else if (idx < N && use_sh && !sh_reg) {
-        if (stage) { for (int e = 0; e < rowlen; ++e) myrow[e] = 0.f; }
+        if (stage) { if (!lds_accum) for (int e = 0; e < rowlen; ++e) myrow_out[e] = 0.f; }
         else if (!accumulate) { float* o = dL_dshs + (size_t)idx * rowlen; for (int e = 0; e < rowlen; ++e) o[e] = 0.f; }
     }
 
@@ -866,11 +869,13 @@ gsr_preprocess_bwd(ViewTab tab, int first_view, int B /* B == 1: the view tab.v[
     const int rowlen = 3 * K;
     const bool use_sh = (shs != nullptr);
     const bool stage = use_sh && (K > 1);
-    // Several views in one launch (B > 1; the host does this when nothing is staged through LDS: K == 1 -- DreamGaussian's
-    // sh_degree 0 -- or precomputed colours): every Gaussian is read ONCE and the cameras are run through in registers, last
+    // Several views in one launch (B > 1): every Gaussian is read ONCE and the cameras are run through in registers, last
     // view first and `earlier sum + this view` after that -- the additions of B separate launches (= the order autograd
-    // accumulates B separate calls) in the same order, so the sums are bit-identical to them, without B - 1 read-modify-write
-    // passes over the gradients. The cameras go from the by-value table to LDS (they are indexed with a run-time view number).
+    // accumulates B separate calls) in the same order, without B - 1 read-modify-write passes over the gradients. K == 1
+    // (DreamGaussian's sh_degree 0) or precomputed colours: nothing is staged, dL/dSH is three registers. K > 1 (round 4): the SH
+    // rows are staged ONCE into the first half of the LDS buffer and stay there for all views; dL/dSH accumulates in a second
+    // row per Gaussian (the input row can no longer double as the output row) and leaves through one stage_rows_out -- the
+    // 8-view chain at SH degree 3 used to be 8 launches x 524 MB. The cameras go from the by-value table to LDS.
     __shared__ ViewConst sv[MULTI ? GSR_MAX_VIEWS : 1];
     // The cameras' matrices sit in LDS (view[16] | proj[16] | campos[3] per view): read through their device pointers they come
     // back as vector-memory loads, each with a wait for memory right behind it in the middle of the arithmetic.
@@ -924,7 +929,8 @@ gsr_preprocess_bwd(ViewTab tab, int first_view, int B /* B == 1: the view tab.v[
                                __float_as_uint(vin0.g1.x) | __float_as_uint(vin0.g1.y) | __float_as_uint(vin0.g1.z) | __float_as_uint(vin0.g1.w) |
                                __float_as_uint(vin0.g2.x) | __float_as_uint(vin0.g2.y)) & 0x7fffffffu) != 0u;
         if (stage) {
-            rowlive[threadIdx.x] = (idx < N && radius0 > 0 && touched) ? 1 : 0;     // (the previous batch's stage_rows_out reads the other copy)
+            // (several views: a row is fetched if the Gaussian exists -- which views touch it is known view by view, below)
+            rowlive[threadIdx.x] = (idx < N && (MULTI || (radius0 > 0 && touched))) ? 1 : 0;     // (the previous batch's stage_rows_out reads the other copy)
             lds_barrier();
             if (shs_rest) stage_rows_in_split(shs + (size_t)base * 3, shs_rest + (size_t)base * (rowlen - 3), shbuf, cnt, rowlen, rowlive);
             else stage_rows_in(shs + (size_t)base * rowlen, shbuf, cnt, rowlen, rowlive);
@@ -940,7 +946,9 @@ gsr_preprocess_bwd(ViewTab tab, int first_view, int B /* B == 1: the view tab.v[
 #pragma unroll
         for (int e = 0; e < 6; ++e) out.dcov[e] = 0.f;
         float* myrow = shbuf + threadIdx.x * (rowlen + 1);
-        const bool sh_in_regs = MULTI;                    // (then K == 1: three numbers per view)
+        float* shbuf_out = (MULTI && stage) ? shbuf + blockDim.x * (rowlen + 1) : shbuf;     // several views: input rows stay, output rows apart
+        float* myrow_out = shbuf_out + threadIdx.x * (rowlen + 1);
+        const bool sh_in_regs = MULTI && !stage;          // (then K == 1: three numbers per view)
         for (int v = MULTI ? first_view + B - 1 : 0; v >= (MULTI ? first_view : 0); --v) {
             // one view per launch (the common case): the camera stays a kernel argument = scalar registers; several: from LDS,
             // made wave-uniform again from lane 0's copy
@@ -960,7 +968,8 @@ gsr_preprocess_bwd(ViewTab tab, int first_view, int B /* B == 1: the view tab.v[
                 }
             }
             const bool live = (idx < N) && (radius > 0) && (MULTI || touched);   // (MULTI: nothing is staged, the views differ)
-            k6_gaussian<RAW>(vc, camf[MULTI ? v - first_view : 0], idx, N, K, live, in, vin, shs, cov3D_precomp, dL_dshs, stage, myrow, accumulate, sh_in_regs, cur);
+            k6_gaussian<RAW>(vc, camf[MULTI ? v - first_view : 0], idx, N, K, live, in, vin, shs, cov3D_precomp, dL_dshs, stage, myrow, myrow_out,
+                             MULTI && v != first_view + B - 1, accumulate, sh_in_regs, cur);
             if (idx < N) { const gsr_f3 m2 = {cur.dm2[0], cur.dm2[1], 0.f}; *reinterpret_cast<gsr_f3u*>(dL_dmeans2D + ((size_t)v * N + idx) * 3) = m2; }
             // first pass (the last view): 0 + x = x exactly
 #pragma unroll
@@ -998,8 +1007,8 @@ gsr_preprocess_bwd(ViewTab tab, int first_view, int B /* B == 1: the view tab.v[
         }
         if (stage) {
             lds_barrier();
-            if (shs_rest) stage_rows_out_split(dL_dshs + (size_t)base * 3, dL_dshs_rest + (size_t)base * (rowlen - 3), shbuf, cnt, rowlen, accumulate, rowlive);
-            else stage_rows_out(dL_dshs + (size_t)base * rowlen, shbuf, cnt, rowlen, accumulate, rowlive);
+            if (shs_rest) stage_rows_out_split(dL_dshs + (size_t)base * 3, dL_dshs_rest + (size_t)base * (rowlen - 3), shbuf_out, cnt, rowlen, accumulate, rowlive);
+            else stage_rows_out(dL_dshs + (size_t)base * rowlen, shbuf_out, cnt, rowlen, accumulate, rowlive);
         }
     }
 }
