@@ -53,7 +53,7 @@ __device__ __forceinline__ void hint_store64(unsigned long long* p, unsigned lon
 // is not blended. Both kernels run the SAME sequence of roundings on (T', C', ...) -- the combine's walk
 // reproduces the segment kernel's numbers bit for bit up to its own stopping point.
 //   ea = x y qa qb | eb = qc opac r g | ec = b depth - - ; kpos = 1-based list position
-#define GSR_COMPOSITE_G(ea, eb, ec, power, Gv, kpos, valid, gate, keepT)                         \
+#define GSR_COMPOSITE_G(ea, eb, ec, power, Gv, kpos, valid, gate, keepT, LASTV)                  \
     {                                                                                          \
         const float alpha = fminf(0.99f, eb.y * Gv);                                           \
         const bool ok = (valid) && !done && (power <= 0.f) && (alpha >= (1.0f / 255.0f));      \
@@ -64,21 +64,21 @@ __device__ __forceinline__ void hint_store64(unsigned long long* p, unsigned lon
         C0 = fmaf(eb.z, w, C0); C1 = fmaf(eb.w, w, C1); C2 = fmaf(ec.x, w, C2);                \
         D = fmaf(ec.y, w, D); A += w;                                                          \
         T = (keepT ? acc : ok) ? test_T : T;                                                   \
-        last = acc ? (kpos) : last;                                                            \
+        LASTV = acc ? (kpos) : LASTV;                                                          \
         done = done || stop;                                                                   \
     }
 // Two consecutive list entries: both exponents first, their two v_exp_f32 in adjacent issue slots (GSR_TRANS_PAIR), then the two
 // dependent updates in list order; `between` runs after the first (the callers request the next records there). The arithmetic
 // per (pixel, entry) is the macro above in every kernel that blends.
-#define GSR_COMPOSITE2(e0a, e0b, e0c, k0, v0, e1a, e1b, e1c, k1, v1, gate, keepT, between)       \
+#define GSR_COMPOSITE2(e0a, e0b, e0c, k0, v0, e1a, e1b, e1c, k1, v1, gate, keepT, LASTV, between) \
     {                                                                                          \
         const float pw0_ = splat_power(e0a.z, e0a.w, e0b.x, e0a.x - pxf, e0a.y - pyf);         /* log2 units */ \
         const float pw1_ = splat_power(e1a.z, e1a.w, e1b.x, e1a.x - pxf, e1a.y - pyf);         \
         float G0_, G1_;                                                                        \
         GSR_TRANS_PAIR("v_exp_f32", G0_, G1_, pw0_, pw1_)                                      \
-        GSR_COMPOSITE_G(e0a, e0b, e0c, pw0_, G0_, k0, v0, gate, keepT)                          \
+        GSR_COMPOSITE_G(e0a, e0b, e0c, pw0_, G0_, k0, v0, gate, keepT, LASTV)                   \
         between                                                                                \
-        GSR_COMPOSITE_G(e1a, e1b, e1c, pw1_, G1_, k1, v1, gate, keepT)                          \
+        GSR_COMPOSITE_G(e1a, e1b, e1c, pw1_, G1_, k1, v1, gate, keepT, LASTV)                   \
     }
 
 // =========================================================================================
@@ -229,7 +229,7 @@ gsr_render_fwd_seg(const uint4* __restrict__ items, const uint32_t* __restrict__
                 for (int j = 0; j < nhit; j += 2) {       // slots nhit, nhit+1 are padding: read, masked
                     const float4 e1a = sa[j + 1], e1b = sb[j + 1], e1c = sc[j + 1];
                     const uint32_t k0 = __float_as_uint(e0c.z);
-                    GSR_COMPOSITE2(e0a, e0b, e0c, k0, true, e1a, e1b, e1c, __float_as_uint(e1c.z), j + 1 < nhit, 1.f, false,
+                    GSR_COMPOSITE2(e0a, e0b, e0c, k0, true, e1a, e1b, e1c, __float_as_uint(e1c.z), j + 1 < nhit, 1.f, false, last,
                                    e0a = sa[j + 2]; e0b = sb[j + 2]; e0c = sc[j + 2];)   // in flight during entry j+1
                 }
                 wave_lds_handoff();                       // reads above precede the next round's writes
@@ -255,9 +255,19 @@ gsr_render_fwd_seg(const uint4* __restrict__ items, const uint32_t* __restrict__
                 if (h3) qlw[3][lanes_below(m3)] = (uint8_t)lane;
                 const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
                 const int nmax = max(max(n0, n1), max(n2, n3));
-                const int nmine = row == 0 ? n0 : (row == 1 ? n1 : (row == 2 ? n2 : n3));
                 const uint32_t pos1 = pos0 + 1u;          // 1-based list position of staged slot 0
                 const uint8_t* __restrict__ ql = qlw[row];
+                // a list shorter than the longest is padded with slot 64 (an all-zero record: opacity 0 never passes the alpha test) up to the
+                // last batch that is read, so that an entry needs no 'inside my list' test; the last blended entry is tracked as a staged
+                // slot and turned into a list position once per round (one compare and one add per entry fewer on the longest tiles' path)
+                {
+                    const int nread = (nmax + 7) & ~7;
+                    if (lane >= n0 && lane < nread) qlw[0][lane] = (uint8_t)GSR_RB;
+                    if (lane >= n1 && lane < nread) qlw[1][lane] = (uint8_t)GSR_RB;
+                    if (lane >= n2 && lane < nread) qlw[2][lane] = (uint8_t)GSR_RB;
+                    if (lane >= n3 && lane < nread) qlw[3][lane] = (uint8_t)GSR_RB;
+                }
+                uint32_t lasts = 0xffffffffu;
                 wave_lds_handoff();
                 for (int jb = 0; jb < nmax; jb += 8) {
                     const uint2 sl = *reinterpret_cast<const uint2*>(ql + jb);
@@ -271,11 +281,12 @@ gsr_render_fwd_seg(const uint4* __restrict__ items, const uint32_t* __restrict__
                     for (int b = 0; b < 8; b += 2) {
                         if (jb + b < nmax) {              // wave-uniform
                             const float4 e1a = sa[slot[b + 1]], e1b = sb[slot[b + 1]], e1c = sc[slot[b + 1]];
-                            GSR_COMPOSITE2(e0a, e0b, e0c, pos1 + slot[b], jb + b < nmine, e1a, e1b, e1c, pos1 + slot[b + 1], jb + b + 1 < nmine, 1.f, false,
+                            GSR_COMPOSITE2(e0a, e0b, e0c, slot[b], true, e1a, e1b, e1c, slot[b + 1], true, 1.f, false, lasts,
                                            if (b + 2 < 8) { e0a = sa[slot[b + 2]]; e0b = sb[slot[b + 2]]; e0c = sc[slot[b + 2]]; })   // in flight during entry b+1
                         }
                     }
                 }
+                last = lasts != 0xffffffffu ? pos1 + lasts : last;
                 wave_lds_handoff();                       // reads above precede the next round's writes
             }
         }
@@ -435,7 +446,7 @@ gsr_render_fwd_serial(const uint32_t* __restrict__ tile_off, const SplatRec* __r
                     for (int j = 0; j < nhit; j += 2) {       // slots nhit, nhit+1 are padding: read, masked
                         const float4 e1a = sa[j + 1], e1b = sb[j + 1], e1c = sc[j + 1];
                         const uint32_t k0 = __float_as_uint(e0c.z);
-                        GSR_COMPOSITE2(e0a, e0b, e0c, k0, true, e1a, e1b, e1c, __float_as_uint(e1c.z), j + 1 < nhit, 1.f, true,
+                        GSR_COMPOSITE2(e0a, e0b, e0c, k0, true, e1a, e1b, e1c, __float_as_uint(e1c.z), j + 1 < nhit, 1.f, true, last,
                                        e0a = sa[j + 2]; e0b = sb[j + 2]; e0c = sc[j + 2];)   // in flight during entry j+1
                     }
                     wave_lds_handoff();                       // reads above precede the next round's writes
@@ -467,9 +478,19 @@ gsr_render_fwd_serial(const uint32_t* __restrict__ tile_off, const SplatRec* __r
                     if (h3) qlw[3][lanes_below(m3)] = (uint8_t)lane;
                     const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
                     const int nmax = max(max(n0, n1), max(n2, n3));
-                    const int nmine = row == 0 ? n0 : (row == 1 ? n1 : (row == 2 ? n2 : n3));
                     const uint32_t pos1 = rel + 1u;           // 1-based list position of staged slot 0
                     const uint8_t* __restrict__ ql = qlw[row];
+                    // a list shorter than the longest is padded with slot 64 (an all-zero record: opacity 0 never passes the alpha test) up to the
+                    // last batch that is read, so that an entry needs no 'inside my list' test; the last blended entry is tracked as a staged
+                    // slot and turned into a list position once per round (one compare and one add per entry fewer on the longest tiles' path)
+                    {
+                        const int nread = (nmax + 7) & ~7;
+                        if (lane >= n0 && lane < nread) qlw[0][lane] = (uint8_t)GSR_RB;
+                        if (lane >= n1 && lane < nread) qlw[1][lane] = (uint8_t)GSR_RB;
+                        if (lane >= n2 && lane < nread) qlw[2][lane] = (uint8_t)GSR_RB;
+                        if (lane >= n3 && lane < nread) qlw[3][lane] = (uint8_t)GSR_RB;
+                    }
+                    uint32_t lasts = 0xffffffffu;
                     wave_lds_handoff();
                     for (int jb = 0; jb < nmax; jb += 8) {
                         const uint2 sl = *reinterpret_cast<const uint2*>(ql + jb);
@@ -481,11 +502,12 @@ gsr_render_fwd_serial(const uint32_t* __restrict__ tile_off, const SplatRec* __r
                         for (int b = 0; b < 8; b += 2) {
                             if (jb + b < nmax) {              // wave-uniform
                                 const float4 e1a = sa[slot[b + 1]], e1b = sb[slot[b + 1]], e1c = sc[slot[b + 1]];
-                                GSR_COMPOSITE2(e0a, e0b, e0c, pos1 + slot[b], jb + b < nmine, e1a, e1b, e1c, pos1 + slot[b + 1], jb + b + 1 < nmine, 1.f, true,
+                                GSR_COMPOSITE2(e0a, e0b, e0c, slot[b], true, e1a, e1b, e1c, slot[b + 1], true, 1.f, true, lasts,
                                                if (b + 2 < 8) { e0a = sa[slot[b + 2]]; e0b = sb[slot[b + 2]]; e0c = sc[slot[b + 2]]; })   // in flight during entry b+1
                             }
                         }
                     }
+                    last = lasts != 0xffffffffu ? pos1 + lasts : last;
                     wave_lds_handoff();                       // reads above precede the next round's writes
                 }
             }
@@ -566,7 +588,7 @@ template __global__ void gsr_render_fwd_serial<true>(const uint32_t*, const Spla
         for (int j = 0; j < nhit; j += 2) {                                                                \
             const float4 e1a = sa[j + 1], e1b = sb[j + 1], e1c = sc[j + 1];                                \
             const uint32_t k0 = __float_as_uint(e0c.z);                                                    \
-            GSR_COMPOSITE2(e0a, e0b, e0c, k0, true, e1a, e1b, e1c, __float_as_uint(e1c.z), j + 1 < nhit, gate, true, \
+            GSR_COMPOSITE2(e0a, e0b, e0c, k0, true, e1a, e1b, e1c, __float_as_uint(e1c.z), j + 1 < nhit, gate, true, last, \
                            e0a = sa[j + 2]; e0b = sb[j + 2]; e0c = sc[j + 2];)                             \
         }                                                                                                  \
         wave_lds_handoff();                                                                                \
