@@ -263,6 +263,9 @@ def main():
                     help="what the timed step does about DreamGaussian's parameter activations (gs_renderer.py:134-142): "
                          "none = the rasterizer alone on activated inputs (the headline metric); torch = sigmoid/exp/normalize "
                          "as torch ops + their autograd, as Renderer.render does; fused = rasterize_gaussians_raw")
+    ap.add_argument("--hook", action="append", default=[], metavar="NAME=VALUE",
+                    help="A/B measurements only: a test hook of the library (dreamgaussian_amd._testing), e.g. fwd_lds_kb=44; "
+                         "recorded in the line's config (a line with hooks is not the headline)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -292,6 +295,11 @@ def main():
 
     import dreamgaussian_amd as D
     from dreamgaussian_amd import _lib, views
+    if a.hook:
+        from dreamgaussian_amd import _testing
+        for h in a.hook:
+            name, _, val = h.partition("=")
+            _testing.set(name, int(val))
 
     if a.step == "sds":
         res = run_sds(a, dev, rank, world)
@@ -485,7 +493,8 @@ def main():
                                    f"orbit camera r=2 fovy=49.1",
                        "views_per_step": world * a.views, "order": a.order, "activations": a.activations, "views_mode": ("single" if a.views == 1 else ("serial loop" if a.views_serial else "rasterize_views/chain")), "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU",
                        "N": wl["N"], "K": K, "V": st.get("V"), "M": st.get("M_ref"), "M_emitted": st.get("M"),
-                       "max_tile_list": st.get("max_tile"), "seg_shift": st.get("seg_shift")},
+                       "max_tile_list": st.get("max_tile"), "seg_shift": st.get("seg_shift"),
+                       **({"hooks": list(a.hook)} if a.hook else {})},
             "roofline": roof, "path_roofline": path_roof, "cpu_baseline": cpu,
             "kernels_ms_per_step": {k: round(v[0] / a.steps, 4) for k, v in sorted(kern.items())},
             "kernels_ms_per_step_raw": {k: round(v, 4) for k, v in sorted(kern_raw.items())} if kern else {},

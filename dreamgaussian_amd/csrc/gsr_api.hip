@@ -109,9 +109,9 @@ int once_per_device(F fn) {
 // A/B measurement through an explicit call. Nothing here is read from the process environment: two of them (forward mode, segment
 // length) decide where the per-pixel sums are cut, i.e. the rounding of the results, and that must not depend on who started the
 // process. -1 = the library decides.
-enum { OV_FWD_MODE, OV_SEG_SHIFT, OV_FWD_LISTS, OV_FWD_HINTS, OV_SPECULATE, OV_HIST_MAX, OV_K1_GRID, OV_FWD_GRID, OV_K6_GRID, OV_COUNT };
-const char* const kOvNames[OV_COUNT] = {"fwd_mode", "seg_shift", "fwd_lists", "fwd_hints", "speculate", "hist_max", "k1_grid", "fwd_grid", "k6_grid"};
-std::atomic<int> g_ov[OV_COUNT] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
+enum { OV_FWD_MODE, OV_SEG_SHIFT, OV_FWD_LISTS, OV_FWD_HINTS, OV_SPECULATE, OV_HIST_MAX, OV_K1_GRID, OV_FWD_GRID, OV_K6_GRID, OV_FWD_LDS_KB, OV_COUNT };
+const char* const kOvNames[OV_COUNT] = {"fwd_mode", "seg_shift", "fwd_lists", "fwd_hints", "speculate", "hist_max", "k1_grid", "fwd_grid", "k6_grid", "fwd_lds_kb"};
+std::atomic<int> g_ov[OV_COUNT] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
 inline int ov(int k) { return g_ov[k].load(std::memory_order_relaxed); }
 
 // K1's grid (a persistent grid: every workgroup walks the same number of 256-Gaussian batches; test hook "k1_grid" pins it). The
@@ -274,6 +274,19 @@ int seg_shift_for(int N, int tiles_per_view) {
     if (fwd_sequential_for(N, tiles_per_view)) return 6;
     const double x = 4.0 * (double)N / (double)(tiles_per_view > 0 ? tiles_per_view : 1);   // ~ list length of an average tile
     return x <= 512.0 ? 6 : 7;
+}
+// Dynamic LDS requested on top of the serial walk's own 14 KiB. The kernel does not use it: 42 KiB per workgroup keeps the walk at
+// THREE workgroups per CU instead of the five its registers allow. A dense single view has fewer busy tiles than the chip has
+// slots (1M Gaussians / 800^2: 777 of 2 500 tiles, heaviest first), all of them are placed at once, and with five slots some CUs
+// receive four or five of the heavy ones while others hold one or two; with three the 768 heaviest land three per CU. Measured on
+// one box, forward compositing, 5 / 4 / 3 / 3 (50 KiB) / 2 per CU: 0.1458 / 0.1445 / 0.1419 / 0.1419 / 0.1949 ms -- two per CU
+// starves it (the walk is latency-bound per wave and wants waves). 1M trained-like, 100k / 800^2, 250k / 512^2 at three: unchanged
+// (0.1054 / 0.1051, 0.0866 / 0.0869, 0.1066 / 0.1065). Batches of views bring more busy tiles than slots and keep the five
+// (not measured with three). Test hook "fwd_lds_kb": 0 = none, n = n KiB.
+size_t fwd_serial_lds_pad(int B) {
+    const int kb = ov(OV_FWD_LDS_KB);
+    if (kb >= 0) return (size_t)(kb > 144 ? 144 : kb) * 1024;
+    return B == 1 ? (size_t)28 * 1024 : 0;
 }
 // forward compositing kernel: 0 = per view (finish_impl), 1 = 8x8 block lists, 2 = quad lists (test hook "fwd_lists")
 int fwd_kernel_env() { const int v = ov(OV_FWD_LISTS); return v == 1 || v == 2 ? v : 0; }
@@ -507,10 +520,15 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
     const uint32_t zero_per = (zero_n + (uint32_t)TA - 1u) / (uint32_t)TA;       // float4s per workgroup (grid = TA)
     if (sequential) {
         // ---- K5s: the serial walk, one workgroup per tile
+        const size_t fwd_lds = fwd_serial_lds_pad(B);
+        if (fwd_lds > 32 * 1024) {
+            HIP_TRY(hipFuncSetAttribute((const void*)gsr_render_fwd_serial<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds));
+            HIP_TRY(hipFuncSetAttribute((const void*)gsr_render_fwd_serial<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds));
+        }
         prof_begin(stream);
         if (mask_q) {
             vs.view_mask = mask_q;
-            hipLaunchKernelGGL(gsr_render_fwd_serial<true>, dim3(TA), dim3(256), 0, stream, tile_off, recs, sorted_ids, W, H, vc.gx,
+            hipLaunchKernelGGL(gsr_render_fwd_serial<true>, dim3(TA), dim3(256), fwd_lds, stream, tile_off, recs, sorted_ids, W, H, vc.gx,
                                out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, order, shift,
                                plan_off, plan_tile, counters + 4, (uint32_t)BL.plan_cap, (unsigned long long)mask_q, (uint32_t)BL.items /* the first of the three spare records: store sink */,
                                counters, (uint32_t)M, maxc_cap, vs, zero4, zero_n, zero_per);
@@ -518,7 +536,7 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
         }
         if (mask_q != mask_all) {
             vs.view_mask = mask_all & ~mask_q;
-            hipLaunchKernelGGL(gsr_render_fwd_serial<false>, dim3(TA), dim3(256), 0, stream, tile_off, recs, sorted_ids, W, H, vc.gx,
+            hipLaunchKernelGGL(gsr_render_fwd_serial<false>, dim3(TA), dim3(256), fwd_lds, stream, tile_off, recs, sorted_ids, W, H, vc.gx,
                                out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, order, shift,
                                plan_off, plan_tile, counters + 4, (uint32_t)BL.plan_cap, (unsigned long long)mask_q, (uint32_t)BL.items /* the first of the three spare records: store sink */,
                                counters, (uint32_t)M, maxc_cap, vs, zero4, zero_n, zero_per);

@@ -126,6 +126,17 @@ __device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, flo
     }
 }
 
+// K6's results are written once and not read again by this library: non-temporal stores (global_store ... nt). With plain
+// stores the 248 MB of a 1M-Gaussian / SH 3 backward sat dirty in the memory-side cache when the kernel ended and were written
+// back under whatever ran next: measured on the same box (profiles/r04_ab_nt.txt), K6 0.087 -> 0.091 ms (it now waits for its
+// own writes) and the NEXT kernel -- K1 of the following step -- 0.095 -> 0.073; the dL/dSH rows alone: 0.087 -> 0.091 / 0.095 -> 0.076.
+// (Loading the backward's accumulators non-temporally on top cost K6 9 us: not done.)
+__device__ __forceinline__ void store_once(float4* p, float x, float y, float z, float w) {
+    typedef float gsr_v4f __attribute__((ext_vector_type(4)));
+    const gsr_v4f v = {x, y, z, w};
+    __builtin_nontemporal_store(v, reinterpret_cast<gsr_v4f*>(p));
+}
+
 // Stage `cnt` SH rows (each 3K floats, contiguous in HBM) into LDS with pitch 3K+1. `rowlive[r]` = 0: nobody will read row r
 // (a Gaussian no pixel gradient reached, three quarters of a dense scene) -- its 192 bytes are not fetched: the request goes to
 // the batch's first vector instead (one address for all such lanes, a cache hit; the loads stay branch-free and in flight
@@ -200,7 +211,8 @@ __device__ __forceinline__ void stage_rows_out(float* __restrict__ dst, const fl
             const float* s = lds + row * pitch + col;
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
             if (accumulate) o = d4[i];
-            d4[i] = accumulate ? make_float4(o.x + s[0], o.y + s[1], o.z + s[2], o.w + s[3]) : make_float4(s[0], s[1], s[2], s[3]);
+            if (accumulate) d4[i] = make_float4(o.x + s[0], o.y + s[1], o.z + s[2], o.w + s[3]);
+            else store_once(d4 + i, s[0], s[1], s[2], s[3]);
         }
     } else {
         for (int e = threadIdx.x; e < total; e += blockDim.x) {
@@ -970,7 +982,7 @@ gsr_preprocess_bwd(ViewTab tab, int first_view, int B /* B == 1: the view tab.v[
             const bool live = (idx < N) && (radius > 0) && (MULTI || touched);   // (MULTI: nothing is staged, the views differ)
             k6_gaussian<RAW>(vc, camf[MULTI ? v - first_view : 0], idx, N, K, live, in, vin, shs, cov3D_precomp, dL_dshs, stage, myrow, myrow_out,
                              MULTI && v != first_view + B - 1, accumulate, sh_in_regs, cur);
-            if (idx < N) { const gsr_f3 m2 = {cur.dm2[0], cur.dm2[1], 0.f}; *reinterpret_cast<gsr_f3u*>(dL_dmeans2D + ((size_t)v * N + idx) * 3) = m2; }
+            if (idx < N) { const gsr_f3 m2 = {cur.dm2[0], cur.dm2[1], 0.f}; __builtin_nontemporal_store(m2, reinterpret_cast<gsr_f3u*>(dL_dmeans2D + ((size_t)v * N + idx) * 3)); }
             // first pass (the last view): 0 + x = x exactly
 #pragma unroll
             for (int e = 0; e < 3; ++e) { out.dm[e] = out.dm[e] + cur.dm[e]; out.dsc[e] = out.dsc[e] + cur.dsc[e]; out.dcol[e] = out.dcol[e] + cur.dcol[e]; tsh[e] = tsh[e] + cur.dsh[e]; }
@@ -995,15 +1007,15 @@ gsr_preprocess_bwd(ViewTab tab, int first_view, int B /* B == 1: the view tab.v[
                 if (dL_dscales) { const gsr_f3 os = *reinterpret_cast<const gsr_f3u*>(dL_dscales + 3 * (size_t)idx); out.dsc[0] = os.x + out.dsc[0]; out.dsc[1] = os.y + out.dsc[1]; out.dsc[2] = os.z + out.dsc[2]; }
                 if (dL_drots) { const float4 o = reinterpret_cast<const float4*>(dL_drots)[idx]; out.dq[0] = o.x + out.dq[0]; out.dq[1] = o.y + out.dq[1]; out.dq[2] = o.z + out.dq[2]; out.dq[3] = o.w + out.dq[3]; }
             }
-            { const gsr_f3 o3 = {out.dm[0], out.dm[1], out.dm[2]}; *reinterpret_cast<gsr_f3u*>(dL_dmeans3D + 3 * (size_t)idx) = o3; }
-            dL_dopac[idx] = out.dop;
+            { const gsr_f3 o3 = {out.dm[0], out.dm[1], out.dm[2]}; __builtin_nontemporal_store(o3, reinterpret_cast<gsr_f3u*>(dL_dmeans3D + 3 * (size_t)idx)); }
+            __builtin_nontemporal_store(out.dop, dL_dopac + idx);
             if (dL_dcolors) { const gsr_f3 o3 = {out.dcol[0], out.dcol[1], out.dcol[2]}; *reinterpret_cast<gsr_f3u*>(dL_dcolors + 3 * (size_t)idx) = o3; }
             if (dL_dcov3D) {
 #pragma unroll
                 for (int e = 0; e < 6; ++e) dL_dcov3D[6 * (size_t)idx + e] = out.dcov[e];
             }
-            if (dL_dscales) { const gsr_f3 o3 = {out.dsc[0], out.dsc[1], out.dsc[2]}; *reinterpret_cast<gsr_f3u*>(dL_dscales + 3 * (size_t)idx) = o3; }
-            if (dL_drots) reinterpret_cast<float4*>(dL_drots)[idx] = make_float4(out.dq[0], out.dq[1], out.dq[2], out.dq[3]);
+            if (dL_dscales) { const gsr_f3 o3 = {out.dsc[0], out.dsc[1], out.dsc[2]}; __builtin_nontemporal_store(o3, reinterpret_cast<gsr_f3u*>(dL_dscales + 3 * (size_t)idx)); }
+            if (dL_drots) store_once(reinterpret_cast<float4*>(dL_drots) + idx, out.dq[0], out.dq[1], out.dq[2], out.dq[3]);
         }
         if (stage) {
             lds_barrier();

@@ -889,9 +889,11 @@ gsr_render_fwd_fix(const uint2* __restrict__ walk_items, const unsigned long lon
 // four lists (at 1M Gaussians 1.5x fewer trips than one 8x8 list, tests/lane_stats.py).
 //
 // pass 1 (lane = pixel), eight list entries per batch: the serial front-to-back recurrence of
-//   T and the c.g prefix; (m, w) go to LDS:  mw[wave][quad][entry k][half h][8 pixels] float2,
-//   k-stride 160 B, h-stride 80 B (16 B of padding each: the 16 lanes a ds_read_b128 services
-//   per LDS cycle hit 16 distinct 4-bank slots in pass 2).
+//   T and the c.g prefix; (m, w) go to LDS:  mw[wave][quad][cell][8 pixels] float2 -- sixteen (entry k, pixel half h)
+//   cells of 16 floats at a 20-float pitch: cell = (k & 3) + 8 (k >> 2) + 4 h. The 16 lanes a ds_read_b128 services per
+//   LDS cycle in pass 2 hit 16 distinct 4-bank slots (the pitch), and the two halves of an entry sit 80 floats = 16 banks
+//   (mod 32) apart, so a 16-lane row's ds_write_b64 covers the 32 banks once (with h next to k -- pitch 40 / 20 -- the
+//   second half overlapped the first one's banks 0..3: a 2-way conflict on every store, 32 extra LDS cycles per batch).
 // pass 2 (lane = (quad, half h = l15 >> 3, entry k = l15 & 7)): each lane sums ITS entry over
 //   the eight pixels of ITS half -- S_0, S_x, S_y, S_xx, S_xy, S_yy and the four w * g sums are
 //   plain FMAs against per-pixel gradients held in registers -- the two halves meet through one
@@ -911,8 +913,8 @@ gsr_render_fwd_fix(const uint2* __restrict__ walk_items, const unsigned long lon
 // the largest possible row total, and the workgroup's sums no longer depend on the order of the adds.
 // -----------------------------------------------------------------------------------------
 #define GSR_Q2_BATCH 8
-#define GSR_Q2_KSTRIDE 40     // floats between consecutive entries of a quad's batch
-#define GSR_Q2_HSTRIDE 20     // floats between the two pixel halves of an entry
+#define GSR_Q2_KOFF(k) (20 * (k) + ((k) >= 4 ? 80 : 0))   // float offset of entry k's half-0 cell inside a quad's batch: cells 0..3 | 8..11
+#define GSR_Q2_HSTRIDE 80     // floats from an entry's half 0 to its half 1: cells 4..7 | 12..15
 #define GSR_QL_PITCH 80       // bytes per quad list (64 + zero padding, multiple of 8)
 #define GSR_Q2_ROW 10         // u64 per table row: S_x S_y S_xx S_xy S_yy | S_0 W0 W1 W2 W3
 
@@ -948,7 +950,7 @@ __global__ void __launch_bounds__(256, 4)   // <= 128 VGPRs: four workgroups per
 gsr_render_bwd_q2(GSR_BWD_PARAMS) {
     __shared__ float4 stage[4][3][GSR_RB + 1];                               // 12 KiB staged records, slot = fetching lane; slot 64 = an all-zero record (opacity 0: never blends)
     __shared__ __attribute__((aligned(8))) uint8_t qlist[4][4][GSR_QL_PITCH]; // 1.25 KiB [wave][quad][k] = staged slot of the quad's k-th entry
-    __shared__ __attribute__((aligned(16))) float mw[4][4][GSR_Q2_BATCH * GSR_Q2_KSTRIDE];   // 20 KiB
+    __shared__ __attribute__((aligned(16))) float mw[4][4][GSR_Q2_BATCH * 40];   // 20 KiB: 16 cells of 16 floats at a 20-float pitch
     __shared__ uint32_t gmax_w[4];                                           // per wave: max of gsum over its pixels (bits of a non-negative float)
     extern __shared__ __attribute__((aligned(16))) unsigned long long acc64[];   // [(1 << seg_shift) * GSR_Q2_ROW]
     if (blockIdx.x >= (uint32_t)plan_total[0]) return;
@@ -1068,7 +1070,7 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
     // pass 1 writes (m, w) of pixel l15 of entry k to mw1[k * KSTRIDE]; pass 2 lane (h2, k2) reads mw2[0..15]
     float* __restrict__ mw1 = &mw[wave][row][(l15 >> 3) * GSR_Q2_HSTRIDE + (l15 & 7) * 2];
     const int k2 = l15 & 7, h2 = l15 >> 3;
-    const float* __restrict__ mw2 = &mw[wave][row][k2 * GSR_Q2_KSTRIDE + h2 * GSR_Q2_HSTRIDE];
+    const float* __restrict__ mw2 = &mw[wave][row][GSR_Q2_KOFF(k2) + h2 * GSR_Q2_HSTRIDE];
     const float qxf = (float)qx, qyf = (float)(qy + 2 * h2);                 // first pixel of pass 2's half
     float4 g2[8];                                                            // gradients of the 8 pixels of pass 2's half
     wave_lds_handoff();
@@ -1104,7 +1106,7 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
             const float dL_dal = fmaf(T, cgi_, -(Rb * rc_));                                     \
             const float m = dL_dal * ae_;                     /* (opacity * dL/dalpha) * G */     \
             T *= om_;                                                                            \
-            *reinterpret_cast<float2*>(mw1 + (kslot) * GSR_Q2_KSTRIDE) = make_float2(m, w);       \
+            *reinterpret_cast<float2*>(mw1 + GSR_Q2_KOFF(kslot)) = make_float2(m, w);       \
         }
 
     for (uint32_t pos0 = seg_lo; pos0 < seg_hi; pos0 += GSR_RB) {   // 0-based positions pos0 .. pos0+63

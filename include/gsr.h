@@ -115,6 +115,7 @@ int gsr_abi_version(void);
  *   "speculate"    0 = gsr_forward waits for the instance count before binning
  *   "hist_max" "k1_grid" "fwd_grid" "k6_grid"   launch geometry (A/B measurements, multi-round paths; "k1_grid" is the grid of
  *                  K1 AND of the scatter kernel, which continues K1's per-workgroup list ranges)
+ *   "fwd_lds_kb"   KiB of unused dynamic LDS requested by the serial walk = how many of its workgroups share a CU (0 = none)
  * Returns 0, or -1 for an unknown name. dreamgaussian_amd/_testing.py wraps it. */
 int gsr_testing_override(const char* name, int32_t value);
 

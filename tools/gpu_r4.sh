@@ -42,6 +42,21 @@ ab)
       echo "== [$l] $wl"; GSR_LIB=$R/$l timeout 300 python bench.py --cpu-budget 0 --workload $wl $BENCH_ARGS 2>>gpurun_out/ab_err.log | tee -a gpurun_out/ab.jsonl | benchline
     done
   done;;
+hooks)
+  # A/B of test hooks on the same box and library: AB_HOOKS="none fwd_lds_kb=44 fwd_lds_kb=44,fwd_prio=1", AB_WL="1M-800-sh3 1M-800-sh3:trained"
+  for wl in ${AB_WL:-1M-800-sh3}; do
+    kind=blob; [ "${wl#*:}" != "$wl" ] && kind=${wl#*:}
+    for h in $AB_HOOKS; do
+      args=""; [ "$h" != none ] && for x in ${h//,/ }; do args="$args --hook $x"; done
+      echo "== [$h] $wl"; timeout 300 python bench.py --cpu-budget 0 --workload ${wl%%:*} --kind $kind $args $BENCH_ARGS 2>>gpurun_out/ab_err.log | tee -a gpurun_out/ab_hooks.jsonl | benchline
+    done
+  done;;
+abquick)
+  # the parity subset a variant library must pass before it is adopted (GSR_LIB=... in the environment of the call)
+  echo "== pytest parity subset [${GSR_LIB:-in-tree library}]"
+  timeout ${QUICK_TIMEOUT:-240} python -m pytest tests/test_parity_gpu.py tests/test_fuzz_gpu.py -m gpu -q -x -p no:cacheprovider --tb=short -rf --durations=8 \
+      -k "forward_backward_match_oracle or committed_golden or depth_ties or segment_lengths or stage1_trained or cfg1_100k_blob or (test_fuzz and not large)" > gpurun_out/pytest_abquick.log 2>&1
+  grep -a "passed\|failed\|FAILED\|Error\|assert\|s call" gpurun_out/pytest_abquick.log | cut -c1-300 | tail -24;;
 quick)
   echo "== pytest quick (GPU)"
   timeout 1200 python -m pytest tests/test_parity_gpu.py tests/test_fuzz_gpu.py tests/test_views_gpu.py tests/test_optim_gpu.py tests/test_densify_gpu.py -m gpu -q -p no:cacheprovider --tb=short -rf -k "not baseline_config and not cfg3 and not full_size" > gpurun_out/pytest_quick.log 2>&1
