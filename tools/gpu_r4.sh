@@ -54,8 +54,8 @@ hooks)
 abquick)
   # the parity subset a variant library must pass before it is adopted (GSR_LIB=... in the environment of the call)
   echo "== pytest parity subset [${GSR_LIB:-in-tree library}]"
-  timeout ${QUICK_TIMEOUT:-240} python -m pytest tests/test_parity_gpu.py tests/test_fuzz_gpu.py -m gpu -q -x -p no:cacheprovider --tb=short -rf --durations=8 \
-      -k "forward_backward_match_oracle or committed_golden or depth_ties or segment_lengths or stage1_trained or cfg1_100k_blob or (test_fuzz and not large)" > gpurun_out/pytest_abquick.log 2>&1
+  timeout ${QUICK_TIMEOUT:-240} python -m pytest ${QUICK_FILES:-tests/test_parity_gpu.py tests/test_fuzz_gpu.py} -m gpu -q -x -p no:cacheprovider --tb=short -rf --durations=8 \
+      -k "${QUICK_K:-forward_backward_match_oracle or committed_golden or depth_ties or segment_lengths or stage1_trained or cfg1_100k_blob or (test_fuzz and not large)}" > gpurun_out/pytest_abquick.log 2>&1
   grep -a "passed\|failed\|FAILED\|Error\|assert\|s call" gpurun_out/pytest_abquick.log | cut -c1-300 | tail -24;;
 quick)
   echo "== pytest quick (GPU)"
