@@ -261,7 +261,7 @@ static int hist_lds_max_tiles() {
 // call (a view of a batch renders bit-identically to its single-view call): the per-view tile count only.
 bool fwd_sequential_for(int N, int tiles_per_view) {
     (void)N;
-    if (ov(OV_FWD_MODE) == 1) return true;                // test hook: 1 = serial walk, 2 = depth-segmented
+    if (ov(OV_FWD_MODE) == 1 || ov(OV_FWD_MODE) == 3) return true;   // test hook: 1 = serial walk, 2 = depth-segmented, 3 = serial walk with two waves per block (experimental)
     if (ov(OV_FWD_MODE) == 2) return false;
     return tiles_per_view >= 1024;
 }
@@ -526,7 +526,14 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
             HIP_TRY(hipFuncSetAttribute((const void*)gsr_render_fwd_serial<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds));
         }
         prof_begin(stream);
-        if (mask_q) {
+        if (mask_q && ov(OV_FWD_MODE) == 3) {             // (test hook) EXPERIMENTAL: tester + blender wave per 8x8 block, see gsr_render_fwd_pair
+            vs.view_mask = mask_q;
+            hipLaunchKernelGGL(gsr_render_fwd_pair, dim3(TA), dim3(512), 0, stream, tile_off, recs, sorted_ids, W, H, vc.gx,
+                               out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, order, shift,
+                               plan_off, plan_tile, counters + 4, (uint32_t)BL.plan_cap, (unsigned long long)mask_q, (uint32_t)BL.items,
+                               counters, (uint32_t)M, maxc_cap, vs, zero4, zero_n, zero_per);
+            zero_n = 0u;
+        } else if (mask_q) {
             vs.view_mask = mask_q;
             hipLaunchKernelGGL(gsr_render_fwd_serial<true>, dim3(TA), dim3(256), fwd_lds, stream, tile_off, recs, sorted_ids, W, H, vc.gx,
                                out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, order, shift,

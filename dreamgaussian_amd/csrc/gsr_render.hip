@@ -319,10 +319,11 @@ template __global__ void gsr_render_fwd_seg<true>(const uint4*, const uint32_t*,
 // clears them: workgroup k of the launch stores zeros to slice k of `zero_n` float4s BEHIND its own work -- the compositing leaves
 // HBM idle, the workgroups finish spread over the kernel's length, and the 10 us fill in front of gsr_render_bwd_q2 (and its launch)
 // is gone. zero_n = 0: nothing to clear (GSR_VIEW_NO_BACKWARD, or the other instantiation's launch does it).
+template <uint32_t THREADS = 256u>      // (the workgroup's size: a constant, not blockDim -- no implicit-argument load in front of the stores)
 __device__ __forceinline__ void clear_slice(float4* __restrict__ zero4, uint32_t zero_n, uint32_t per /* float4s per workgroup (host: ceil(zero_n / grid)) */) {
     if (zero_n == 0u) return;
     const uint32_t lo = blockIdx.x * per, hi = min(lo + per, zero_n);
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += 256u) zero4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += THREADS) zero4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // =========================================================================================
@@ -560,6 +561,264 @@ template __global__ void gsr_render_fwd_serial<false>(const uint32_t*, const Spl
 template __global__ void gsr_render_fwd_serial<true>(const uint32_t*, const SplatRec*, const uint32_t*, int, int, int, float*, float*, float*, float*,
                                                      uint32_t*, float*, float*, const uint32_t*, const uint32_t*, int, uint32_t*, uint4*,
                                                      unsigned long long*, uint32_t, unsigned long long, uint32_t, const unsigned long long*, uint32_t, uint32_t, ViewSplit, float4*, uint32_t, uint32_t);
+
+// =========================================================================================
+// K5p: the serial walk with TWO waves per 8x8 block -- EXPERIMENTAL (test hook "fwd_mode" = 3 only; written at the end of round 4
+// after the last GPU minute was spent: it compiles, it has NOT run. DESIGN.md section 8 has the measurement it answers to).
+//
+// gsr_render_fwd_serial is latency-bound per wave, and a dense single view offers few waves: 777 busy tiles x 4 at 1M Gaussians /
+// 800^2 = 3 per SIMD (two per SIMD: +34 %, profiles/r04_ab_nt.txt). A round of a wave is ~1 250 instructions of which a third
+// (the exact ellipse-vs-quad tests of the 64 fetched records, the ballots, the staging and the four quad lists) does not depend on
+// the pixels' running state. Here a block has a TESTER wave (waves 4..7: fetches the records, tests them, stages the survivors and
+// builds the quad lists of round r + 1 into the other of two LDS buffers) and a BLENDER wave (waves 0..3: owns the 64 pixels,
+// writes the checkpoints, composites round r out of its buffer): 8 waves per tile, the blender's chain a third shorter.
+//   tester -> blender  ready[block][buf] = ((round + 1) << 8) | longest list (0..64), or | GSR_PAIR_END behind the list's end
+//   blender -> tester  freed[block][buf] = round + 1 once the buffer is consumed; GSR_PAIR_STOP when all 64 pixels have stopped;
+//                      alive[block] = the pixels still alive (the tester gates the quads with it, a round or two stale: a quad
+//                      list then holds entries for pixels that have stopped since -- blended with done = true, i.e. not at all)
+// Same arithmetic, same macros as gsr_render_fwd_serial<true>: images, checkpoints and work list are bit-identical to its output;
+// the quad masks left for the backward may carry the stale-gate entries above (its own per-pixel tests drop them).
+// Spins are bounded: a lost hand-shake ends the walk early (wrong pixels, caught by the tests) instead of hanging the GPU.
+// =========================================================================================
+#define GSR_PAIR_END 0xffu
+#define GSR_PAIR_STOP 0xffffffffu
+#define GSR_PAIR_SPINS (1 << 20)
+__device__ __forceinline__ uint32_t lds_flag_load(const uint32_t* p) {
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
+__device__ __forceinline__ void lds_flag_store(uint32_t* p, uint32_t v, int lane) {     // behind everything this wave wrote to LDS
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    if (lane == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__global__ void __launch_bounds__(512, 6)      // <= 80 VGPRs: three workgroups of eight waves per CU
+gsr_render_fwd_pair(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict__ recs,
+                    const uint32_t* __restrict__ ids, int W, int H, int gx,
+                    float* __restrict__ out_color, float* __restrict__ out_depth,
+                    float* __restrict__ out_alpha, float* __restrict__ final_T,
+                    uint32_t* __restrict__ n_contrib, float* __restrict__ totals /*[5][H*W]*/,
+                    float* __restrict__ rec_base, const uint32_t* __restrict__ tile_seg,
+                    const uint32_t* __restrict__ order, int seg_shift,
+                    uint32_t* __restrict__ plan_off, uint4* __restrict__ plan_items,
+                    unsigned long long* __restrict__ plan_total, uint32_t plan_cap, unsigned long long qmask_views, uint32_t sink_rec,
+                    const unsigned long long* __restrict__ counters, uint32_t capacity, uint32_t maxc_cap, ViewSplit vs,
+                    float4* __restrict__ zero4, uint32_t zero_n, uint32_t zero_per) {
+    if (counters[2] > (unsigned long long)capacity || counters[3] > (unsigned long long)maxc_cap) return;
+    __shared__ float4 stage[4][2][3][GSR_RB + 2];                            // [block][buffer][a | b | c][slot]; slot 64 = the all-zero record
+    __shared__ __attribute__((aligned(8))) uint8_t qlist[4][2][4][80];
+    __shared__ uint32_t ready[4][2], freed[4][2];
+    __shared__ unsigned long long alive_pub[4];
+    __shared__ uint32_t wl[4];
+    __shared__ uint32_t plan_base;
+    if (blockIdx.x == 0 && threadIdx.x == 0) plan_total[GSR_CNT_QMASK - GSR_CNT_PLAN] = qmask_views;
+    const int tg = (int)order[blockIdx.x];                // heaviest tiles first
+    const int view = tg / vs.tiles_per_view;
+    if (!((vs.view_mask >> view) & 1u)) { clear_slice<512>(zero4, zero_n, zero_per); return; }
+    const int tile = tg - view * vs.tiles_per_view;
+    const float* __restrict__ bg = vs.bg[view];
+    {
+        const size_t HWv = (size_t)W * H;
+        recs += (size_t)view * vs.N;
+        out_color += view * 3 * HWv; out_depth += view * HWv; out_alpha += view * HWv;
+        final_T += view * vs.img_stride; n_contrib += view * vs.img_stride; totals += view * vs.img_stride;
+    }
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int blk = wave & 3;                             // the 8x8 block; waves blk (blender) and blk + 4 (tester) share it
+    const bool tester = wave >= 4;
+    const int lane = threadIdx.x & 63;
+    const int row = lane >> 4, l15 = lane & 15;
+    const int bx = (tile % gx) * GSR_TILE + (blk & 1) * 8;
+    const int by = (tile / gx) * GSR_TILE + (blk >> 1) * 8;
+    const int lx = (row & 1) * 4 + (l15 & 3), ly = (row >> 1) * 4 + (l15 >> 2);
+    const int px = bx + lx, py = by + ly;
+    const bool inside = (px < W) && (py < H);
+    const float pxf = (float)px, pyf = (float)py;
+    const float bx0 = (float)bx, by0 = (float)by;
+    const uint32_t start = tile_off[tg];
+    const uint32_t tile_n = tile_off[tg + 1] - start;
+    const uint32_t n = (bx < W && by < H) ? tile_n : 0u;   // a block outside the image walks nothing
+    float* __restrict__ recw = rec_base + (size_t)tile_seg[tg] * GSR_CKPT_FLOATS;
+    float* __restrict__ rec0 = recw + (blk * 64 + ly * 8 + lx);
+    for (int q = threadIdx.x; q < 4 * 2 * 3 * (GSR_RB + 2); q += 512) (&stage[0][0][0][0])[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = threadIdx.x; q < 4 * 2 * 4 * 80 / 4; q += 512) reinterpret_cast<uint32_t*>(&qlist[0][0][0][0])[q] = 0u;
+    if (threadIdx.x < 8) { (&ready[0][0])[threadIdx.x] = 0u; (&freed[0][0])[threadIdx.x] = 0u; }
+    if (threadIdx.x < 4) alive_pub[threadIdx.x] = ~0ull;   // until the blender publishes: every quad takes entries
+    lds_barrier();
+
+    float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, A = 0.f;
+    uint32_t last = 0;
+    bool done = !inside;
+    float* const sinkf = rec_base + (size_t)sink_rec * GSR_CKPT_FLOATS + (blk * 64 + lane);
+    unsigned long long* const sink64 = reinterpret_cast<unsigned long long*>(rec_base + (size_t)sink_rec * GSR_CKPT_FLOATS + GSR_REC_HINT) + lane;
+    if (n > 0u && tester) {
+        // ---- the tester: two register sets take turns (round r tests set r & 1, requested a round ago, and requests round r + 1's
+        // records and round r + 2's list entries); it is never more than one round ahead of the blender, so its own latencies hide
+        // behind the wait for a free buffer
+        float4 r0a, r0b, r0c, r1a, r1b, r1c;
+        uint32_t idq;
+        {
+            const uint32_t id0 = ids[start + min((uint32_t)lane, n - 1u)];
+            idq = ids[start + min(GSR_RB + (uint32_t)lane, n - 1u)];
+            const float4* __restrict__ p0 = reinterpret_cast<const float4*>(recs + id0);
+            r0a = p0[0]; r0b = p0[1]; r0c = p0[2];
+        }
+        unsigned long long alive = __ballot(inside);
+        auto wait_free = [&](const uint32_t* f, uint32_t want) -> bool {     // false: the blender has stopped (or the hand-shake is lost)
+            uint32_t v = lds_flag_load(f);
+#pragma unroll 1
+            for (int spin = 0; v != want && v != GSR_PAIR_STOP && spin < GSR_PAIR_SPINS; ++spin) { __builtin_amdgcn_s_sleep(2); v = lds_flag_load(f); }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+            return v == want;
+        };
+        auto test_round = [&](const uint32_t r, float4 ra, float4 rb, float4 rc, float4& da, float4& db, float4& dc) -> bool {
+            const uint32_t rel = r * GSR_RB;
+            const int buf = (int)(r & 1u);
+            if (rel >= n) {                                 // behind the end of the list
+                if (r >= 2u && !wait_free(&freed[blk][buf], r - 1u)) return false;
+                lds_flag_store(&ready[blk][buf], ((r + 1u) << 8) | GSR_PAIR_END, lane);
+                return false;
+            }
+            {
+                const float4* __restrict__ p = reinterpret_cast<const float4*>(recs + idq);
+                da = p[0]; db = p[1]; dc = p[2];
+                idq = ids[start + min(rel + 2u * GSR_RB + (uint32_t)lane, n - 1u)];
+            }
+            const uint32_t i = rel + lane;
+            bool h0 = false, h1 = false, h2 = false, h3 = false;
+            if (i < n) {
+                const float thr = min_visible_power(rb.y);
+                float qp[4];
+                quad_max_powers(ra.x, ra.y, ra.z, ra.w, rb.x, bx0, by0, qp);
+                h0 = ((alive & 0x000000000000ffffull) != 0ull) && qp[0] >= thr;
+                h1 = ((alive & 0x00000000ffff0000ull) != 0ull) && qp[1] >= thr;
+                h2 = ((alive & 0x0000ffff00000000ull) != 0ull) && qp[2] >= thr;
+                h3 = ((alive & 0xffff000000000000ull) != 0ull) && qp[3] >= thr;
+            }
+            const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
+            {   // the round's four hit masks for the backward (GSR_CNT_QMASK), as gsr_render_fwd_serial<true> leaves them
+                unsigned long long* mp = reinterpret_cast<unsigned long long*>(recw + (size_t)(rel >> seg_shift) * GSR_CKPT_FLOATS + GSR_REC_HINT)
+                                         + (((rel >> 6) & ((1u << (seg_shift - 6)) - 1u)) * 16u + (uint32_t)blk * 4u);
+                *(lane < 4 ? mp + lane : sink64) = lane == 0 ? m0 : (lane == 1 ? m1 : (lane == 2 ? m2 : m3));
+            }
+            // the buffer is free once the blender has left round r - 2
+            if (r >= 2u) { if (!wait_free(&freed[blk][buf], r - 1u)) return false; }
+            else if (lds_flag_load(&freed[blk][buf]) == GSR_PAIR_STOP) return false;
+            alive = __hip_atomic_load(&alive_pub[blk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // gate of the NEXT round's quads (a superset of the pixels alive then)
+            int nmax = 0;
+            if ((m0 | m1 | m2 | m3) != 0ull) {
+                float4* __restrict__ sa = stage[blk][buf][0];
+                float4* __restrict__ sb = stage[blk][buf][1];
+                float4* __restrict__ sc = stage[blk][buf][2];
+                uint8_t (*qlw)[80] = qlist[blk][buf];
+                if (h0 | h1 | h2 | h3) { sa[lane] = ra; sb[lane] = rb; sc[lane] = rc; }
+                if (h0) qlw[0][lanes_below(m0)] = (uint8_t)lane;
+                if (h1) qlw[1][lanes_below(m1)] = (uint8_t)lane;
+                if (h2) qlw[2][lanes_below(m2)] = (uint8_t)lane;
+                if (h3) qlw[3][lanes_below(m3)] = (uint8_t)lane;
+                const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
+                nmax = max(max(n0, n1), max(n2, n3));
+                const int nread = (nmax + 7) & ~7;          // shorter lists end in the all-zero record up to the last batch that is read
+                if (lane >= n0 && lane < nread) qlw[0][lane] = (uint8_t)GSR_RB;
+                if (lane >= n1 && lane < nread) qlw[1][lane] = (uint8_t)GSR_RB;
+                if (lane >= n2 && lane < nread) qlw[2][lane] = (uint8_t)GSR_RB;
+                if (lane >= n3 && lane < nread) qlw[3][lane] = (uint8_t)GSR_RB;
+            }
+            lds_flag_store(&ready[blk][buf], ((r + 1u) << 8) | (uint32_t)nmax, lane);
+            return true;
+        };
+        for (uint32_t r = 0;; r += 2u) {
+            if (!test_round(r, r0a, r0b, r0c, r1a, r1b, r1c)) break;
+            if (!test_round(r + 1u, r1a, r1b, r1c, r0a, r0b, r0c)) break;
+        }
+    } else if (n > 0u) {
+        // ---- the blender
+#pragma unroll 1
+        for (uint32_t r = 0;; ++r) {
+            const uint32_t rel = r * GSR_RB;
+            const int buf = (int)(r & 1u);
+            uint32_t code = lds_flag_load(&ready[blk][buf]);
+#pragma unroll 1
+            for (int spin = 0; (code >> 8) != r + 1u && spin < GSR_PAIR_SPINS; ++spin) { __builtin_amdgcn_s_sleep(1); code = lds_flag_load(&ready[blk][buf]); }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+            if ((code >> 8) != r + 1u || (code & 0xffu) == GSR_PAIR_END) break;
+            const unsigned long long alive = __ballot(!done);
+            if (alive == 0ull) {                            // every pixel has stopped: release the tester, leave
+                lds_flag_store(&freed[blk][0], GSR_PAIR_STOP, lane);
+                lds_flag_store(&freed[blk][1], GSR_PAIR_STOP, lane);
+                break;
+            }
+            {   // segment cut: checkpoint for the backward
+                const bool cut = rel != 0u && (rel & ((1u << seg_shift) - 1u)) == 0u;
+                float* c = (cut && inside) ? rec0 + (size_t)((rel >> seg_shift) - 1u) * GSR_CKPT_FLOATS : sinkf;
+                c[0] = T; c[256] = C0; c[512] = C1; c[768] = C2; c[1024] = D; c[1280] = A;
+            }
+            const int nmax = (int)(code & 0xffu);
+            if (nmax > 0) {
+                const float4* __restrict__ sa = stage[blk][buf][0];
+                const float4* __restrict__ sb = stage[blk][buf][1];
+                const float4* __restrict__ sc = stage[blk][buf][2];
+                const uint8_t* __restrict__ ql = qlist[blk][buf][row];
+                const uint32_t pos1 = rel + 1u;               // 1-based list position of staged slot 0
+                uint32_t lasts = 0xffffffffu;
+                for (int jb = 0; jb < nmax; jb += 8) {
+                    const uint2 sl = *reinterpret_cast<const uint2*>(ql + jb);
+                    uint32_t slot[8];
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) slot[b] = ((b < 4 ? sl.x : sl.y) >> (8 * (b & 3))) & 0xffu;
+                    float4 e0a = sa[slot[0]], e0b = sb[slot[0]], e0c = sc[slot[0]];
+#pragma unroll
+                    for (int b = 0; b < 8; b += 2) {
+                        if (jb + b < nmax) {                  // wave-uniform
+                            const float4 e1a = sa[slot[b + 1]], e1b = sb[slot[b + 1]], e1c = sc[slot[b + 1]];
+                            GSR_COMPOSITE2(e0a, e0b, e0c, slot[b], true, e1a, e1b, e1c, slot[b + 1], true, 1.f, true, lasts,
+                                           if (b + 2 < 8) { e0a = sa[slot[b + 2]]; e0b = sb[slot[b + 2]]; e0c = sc[slot[b + 2]]; })
+                        }
+                    }
+                }
+                last = lasts != 0xffffffffu ? pos1 + lasts : last;
+            }
+            {   // the buffer goes back; the pixels still alive ride along for the tester's quad gate
+                const unsigned long long still = __ballot(!done);
+                if (lane == 0) __hip_atomic_store(&alive_pub[blk], still, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                lds_flag_store(&freed[blk][buf], r + 1u, lane);
+            }
+        }
+    }
+    if (inside && !tester) {
+        const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
+        final_T[pix] = T;
+        n_contrib[pix] = last;
+        out_color[pix] = fmaf(T, bg[0], C0);
+        out_color[HW + pix] = fmaf(T, bg[1], C1);
+        out_color[2 * HW + pix] = fmaf(T, bg[2], C2);
+        out_depth[pix] = D;
+        out_alpha[pix] = A;
+        totals[pix] = C0; totals[HW + pix] = C1; totals[2 * HW + pix] = C2;
+        totals[3 * HW + pix] = D; totals[4 * HW + pix] = A;
+    }
+    // ---- how deep the backward has to walk this tile's list, and its (tile, segment) work items
+    if (!tester) {
+        const uint32_t wmax = wave_max_u32(inside ? last : 0u);
+        if (lane == 0) wl[blk] = wmax;
+    }
+    lds_barrier();
+    if (threadIdx.x == 0) {
+        const uint32_t tl = max(max(wl[0], wl[1]), max(wl[2], wl[3]));
+        const uint32_t segs = (tl + (1u << seg_shift) - 1u) >> seg_shift;
+        const uint32_t base = segs ? (uint32_t)atomicAdd(plan_total, (unsigned long long)segs) : 0u;
+        plan_off[tg] = base;
+        plan_base = base;
+        wl[0] = segs;
+    }
+    lds_barrier();
+    {
+        const uint32_t segs = wl[0], base = plan_base;
+        for (uint32_t q = threadIdx.x; q < segs; q += 512)
+            if (base + q < plan_cap)
+                plan_items[base + q] = make_uint4((uint32_t)tg, tile_seg[tg] + q, start, q | ((min(1u << seg_shift, tile_n - (q << seg_shift)) - 1u) << 24));
+    }
+    clear_slice<512>(zero4, zero_n, zero_per);
+}
 
 // The exact walk of list positions [lo, hi) of a tile for the lanes with done == false (lane = pixel, row-major 8x8 block at
 // (bx0, by0)), `gate` = their transmittance in front of the segment. Updates T, C0, C1, C2, D, A, last, done: the segment's own

@@ -108,7 +108,8 @@ int gsr_abi_version(void);
 /* TEST HOOK -- not part of the drop-in surface. Forces one of the choices the library otherwise makes from the problem shape
  * (process-wide; value -1 = the library decides again). Nothing is read from the process environment: "fwd_mode" and "seg_shift"
  * decide where the per-pixel sums are cut, i.e. the rounding of the results.
- *   "fwd_mode"     1 = serial walk (gsr_render_fwd_serial), 2 = depth-segmented forward (K5a/b/c)
+ *   "fwd_mode"     1 = serial walk (gsr_render_fwd_serial), 2 = depth-segmented forward (K5a/b/c), 3 = serial walk with a tester
+ *                  and a blender wave per 8x8 block (gsr_render_fwd_pair: EXPERIMENTAL, not yet run on a GPU)
  *   "seg_shift"    6..8: log2 of the depth-segment length
  *   "fwd_lists"    1 = 8x8 block lists, 2 = quad lists in the forward compositing
  *   "fwd_hints"    1 = off, 2 = every segment behind a tile's first skipped (the chaining kernel walks them all)

@@ -405,6 +405,36 @@ def test_forward_variants_are_bit_identical(gpu, hooks, case):
         assert (sq[i].double() - base[i].double()).abs().max().item() <= 2e-5 * max(1.0, base[i].abs().max().item())   # vs the segmented mode
 
 
+@pytest.mark.skipif(not os.environ.get("GSR_TEST_EXPERIMENTAL"),
+                    reason="gsr_render_fwd_pair (fwd_mode = pair) was written after round 4's last GPU minute: compiled, never run. "
+                           "GSR_TEST_EXPERIMENTAL=1 runs this test; it joins the suite (and the kernel the default path) once it has passed")
+@pytest.mark.parametrize("case", [("blob", 20_000, 0, 256, 6), ("trained", 30_000, 2, 320, 6), ("blob", 60_000, 3, 400, 7),
+                                  ("trained", 8_000, 1, 136, 8)], ids=["blob", "trained", "blob_sh3_shift7", "small_odd_shift8"])
+def test_pair_forward_is_bit_identical_to_the_serial_walk(gpu, hooks, case):
+    """EXPERIMENTAL kernel: the serial walk with a tester and a blender wave per 8x8 block must leave the bits of the serial walk --
+    images, radii and (through the checkpoints, the work list and the quad masks it writes) the backward's gradients up to the order
+    of their atomics -- and must terminate (bounded spins: a lost hand-shake shows up as wrong pixels here, not as a hang)."""
+    kind, N, deg, size, shift = case
+    sc = O.make_scene(N, deg, 2, kind)
+    S = O.make_settings(O.orbit_pose(-8.0, 25.0, 2.0), size, size, sh_degree=deg)
+    w = weights_for(size, size)
+    hooks.set("seg_shift", shift)
+    hooks.set("fwd_lists", "q")
+    hooks.set("fwd_mode", "seq")
+    base, gbase, st = run_hip(sc, S, gpu, w)
+    assert st["max_tile"] > 3 * 64, st                               # several rounds per tile
+    hooks.set("fwd_mode", "pair")
+    for rep in range(3):                                               # (a race would not show every time)
+        ho, hg, st2 = run_hip(sc, S, gpu, w)
+        assert st2["M"] == st["M"]
+        for i in range(4):
+            assert torch.equal(ho[i], base[i]), (rep, i, float((ho[i].double() - base[i].double()).abs().max()))
+        floors = grad_floors(sc, gbase)
+        for k_ in hg:
+            scale = max(gbase[k_].abs().max().item(), floors.get(k_, 0.0)) + 1e-30
+            assert (hg[k_] - gbase[k_]).abs().max().item() <= 2e-5 * scale, (rep, k_)
+
+
 @pytest.mark.parametrize("mode", ["seg", "seq"])
 @pytest.mark.parametrize("shift", [6, 7, 8])
 def test_segment_lengths_match_oracle(gpu, hooks, shift, mode):
