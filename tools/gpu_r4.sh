@@ -57,6 +57,20 @@ abquick)
   timeout ${QUICK_TIMEOUT:-240} python -m pytest ${QUICK_FILES:-tests/test_parity_gpu.py tests/test_fuzz_gpu.py} -m gpu -q -x -p no:cacheprovider --tb=short -rf --durations=8 \
       -k "${QUICK_K:-forward_backward_match_oracle or committed_golden or depth_ties or segment_lengths or stage1_trained or cfg1_100k_blob or (test_fuzz and not large)}" > gpurun_out/pytest_abquick.log 2>&1
   grep -a "passed\|failed\|FAILED\|Error\|assert\|s call" gpurun_out/pytest_abquick.log | cut -c1-300 | tail -24;;
+pair)
+  # the experimental two-waves-per-block forward (gsr_render_fwd_pair, test hook fwd_mode = 3): parity gate first, then the A/B
+  echo "== pytest -k pair (GSR_TEST_EXPERIMENTAL=1)"
+  GSR_TEST_EXPERIMENTAL=1 timeout 300 python -m pytest tests/test_parity_gpu.py -m gpu -q -x -p no:cacheprovider --tb=short -rf -k pair > gpurun_out/pytest_pair.log 2>&1
+  tail -15 gpurun_out/pytest_pair.log | cut -c1-300
+  if grep -q " passed" gpurun_out/pytest_pair.log && ! grep -q "failed" gpurun_out/pytest_pair.log; then
+    for wl in 1M-800-sh3 1M-800-sh3:trained 100k-800-sh3 250k-512-sh0; do
+      kind=blob; [ "${wl#*:}" != "$wl" ] && kind=${wl#*:}
+      for h in none fwd_mode=3 none fwd_mode=3; do
+        args=""; [ "$h" != none ] && args="--hook $h"
+        echo "== [$h] $wl"; timeout 300 python bench.py --cpu-budget 0 --workload ${wl%%:*} --kind $kind --steps 60 --warmup 10 $args 2>>gpurun_out/ab_err.log | tee -a gpurun_out/ab_pair.jsonl | benchline
+      done
+    done
+  fi;;
 quick)
   echo "== pytest quick (GPU)"
   timeout 1200 python -m pytest tests/test_parity_gpu.py tests/test_fuzz_gpu.py tests/test_views_gpu.py tests/test_optim_gpu.py tests/test_densify_gpu.py -m gpu -q -p no:cacheprovider --tb=short -rf -k "not baseline_config and not cfg3 and not full_size" > gpurun_out/pytest_quick.log 2>&1
