@@ -109,9 +109,9 @@ int once_per_device(F fn) {
 // A/B measurement through an explicit call. Nothing here is read from the process environment: two of them (forward mode, segment
 // length) decide where the per-pixel sums are cut, i.e. the rounding of the results, and that must not depend on who started the
 // process. -1 = the library decides.
-enum { OV_FWD_MODE, OV_SEG_SHIFT, OV_FWD_LISTS, OV_FWD_HINTS, OV_SPECULATE, OV_HIST_MAX, OV_K1_GRID, OV_FWD_GRID, OV_K6_GRID, OV_FWD_LDS_KB, OV_COUNT };
-const char* const kOvNames[OV_COUNT] = {"fwd_mode", "seg_shift", "fwd_lists", "fwd_hints", "speculate", "hist_max", "k1_grid", "fwd_grid", "k6_grid", "fwd_lds_kb"};
-std::atomic<int> g_ov[OV_COUNT] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
+enum { OV_FWD_MODE, OV_SEG_SHIFT, OV_FWD_LISTS, OV_FWD_HINTS, OV_SPECULATE, OV_HIST_MAX, OV_K1_GRID, OV_FWD_GRID, OV_K6_GRID, OV_FWD_LDS_KB, OV_BWD_GRID, OV_K6_COMPACT, OV_COUNT };
+const char* const kOvNames[OV_COUNT] = {"fwd_mode", "seg_shift", "fwd_lists", "fwd_hints", "speculate", "hist_max", "k1_grid", "fwd_grid", "k6_grid", "fwd_lds_kb", "bwd_grid", "k6_compact"};
+std::atomic<int> g_ov[OV_COUNT] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
 inline int ov(int k) { return g_ov[k].load(std::memory_order_relaxed); }
 
 // K1's grid (a persistent grid: every workgroup walks the same number of 256-Gaussian batches; test hook "k1_grid" pins it). The
@@ -156,7 +156,7 @@ GeomLayout geom_layout(int N, int H, int W, int B = 1) {
     L.plan_off = o; o += align_up(BT * 4);
     // the backward's screen-space gradient accumulators [B][N][12] f32: cleared by the FORWARD (forward_impl) so that the backward
     // starts on its first kernel
-    L.g2d = o; o += align_up(BN * GSR_G2D_STRIDE * 4);
+    L.g2d = o; o += align_up(BN * GSR_G2D_STRIDE * 4 + (size_t)B * GSR_LIVE_BYTES(N));   // ... and, right behind them, the [B][N] byte flags "this Gaussian received a gradient"
     // where each of K1's workgroups starts inside every tile's list ([view][workgroup][tile] u32, written by K1's histogram flush,
     // read by the scatter): last, so that nothing else moves with K1's grid
     L.wg_base = o; o += align_up((size_t)B * (size_t)k1_grid_for(N) * (size_t)L.nTiles * 4);
@@ -516,7 +516,7 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
     uint4* plan_tile = (uint4*)(bbuf + BL.plan_tile);
     // the backward's accumulators, cleared by the per-tile kernel's workgroups (the first launch of the two instantiations)
     float4* zero4 = (float4*)(gbuf + GL.g2d);
-    uint32_t zero_n = prepare_bwd ? (uint32_t)((size_t)B * (size_t)N * GSR_G2D_STRIDE / 4) : 0u;
+    uint32_t zero_n = prepare_bwd ? (uint32_t)(((size_t)B * (size_t)N * GSR_G2D_STRIDE * 4 + (size_t)B * GSR_LIVE_BYTES(N)) / 16) : 0u;   // accumulators + live flags
     const uint32_t zero_per = (zero_n + (uint32_t)TA - 1u) / (uint32_t)TA;       // float4s per workgroup (grid = TA)
     if (sequential) {
         // ---- K5s: the serial walk, one workgroup per tile
@@ -526,7 +526,14 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
             HIP_TRY(hipFuncSetAttribute((const void*)gsr_render_fwd_serial<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds));
         }
         prof_begin(stream);
-        if (mask_q && ov(OV_FWD_MODE) == 3) {             // (test hook) EXPERIMENTAL: tester + blender wave per 8x8 block, see gsr_render_fwd_pair
+        // Two waves per 8x8 block (gsr_render_fwd_pair: a tester that fetches, tests and stages round r + 1 while the blender composites
+        // round r) where the launch has fewer busy waves than the chip has SIMDs to keep fed: one view of 1 024 .. 2 047 tiles (512^2:
+        // ~350 busy tiles x 4 waves = 1.4 per SIMD). Measured round 5, same box, forward compositing: 250k / 512^2 0.1060 -> 0.0897 ms;
+        // at 2 500 tiles it does nothing (1M / 800^2 0.1404 -> 0.1385, trained-like 0.1032 -> 0.1033: three waves per SIMD already, and
+        // the blender's and the tester's halves of a round are about equally long) and the plain walk stays. Same bits either way
+        // (tests/test_parity_gpu.py::test_pair_forward_is_bit_identical_to_the_serial_walk). Test hook "fwd_mode": 1 = never, 3 = always.
+        const bool pair = ov(OV_FWD_MODE) == 3 || (ov(OV_FWD_MODE) < 0 && B == 1 && TA < 2048);
+        if (mask_q && pair) {
             vs.view_mask = mask_q;
             hipLaunchKernelGGL(gsr_render_fwd_pair, dim3(TA), dim3(512), 0, stream, tile_off, recs, sorted_ids, W, H, vc.gx,
                                out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, order, shift,
@@ -733,13 +740,41 @@ int backward_impl(const GsrView* views, int B, int32_t N, int32_t K,
         g2d = (float*)(const_cast<char*>(gbuf) + GL.g2d);   // cleared by the forward (forward_impl)
     } else {                                              // no GsrStats, GSR_VIEW_NO_BACKWARD, or a second backward of the same forward
         if (!tmp.resize) return fail(-1, "tmp allocator is required%s", "");
-        g2d = (float*)tmp.resize(tmp.ctx, align_up(g2d_view * 4 * (size_t)B));
+        const size_t acc_bytes = g2d_view * 4 * (size_t)B + (size_t)B * GSR_LIVE_BYTES(N);   // accumulators | live flags
+        g2d = (float*)tmp.resize(tmp.ctx, align_up(acc_bytes));
         if (!g2d) return fail(-4, "tmp scratch allocation failed%s", "");
         prof_begin(stream);
-        HIP_TRY(hipMemsetAsync(g2d, 0, g2d_view * 4 * (size_t)B, stream));
+        HIP_TRY(hipMemsetAsync(g2d, 0, acc_bytes, stream));
         prof_end(stream, "memset_bwd");
     }
+    uint8_t* live = (uint8_t*)(g2d + g2d_view * (size_t)B);
 
+    // ONE view, concatenated SH layout (gsr_preprocess_bwd_compact): the compositing kernel clears every gradient array on the side and
+    // marks the Gaussians it hands a gradient to; K6 then visits those only -- a quarter of the 1M blob scene, 6 % of the trained-like
+    // one -- instead of streaming all of them and storing 248 bytes each, most of them zeros.
+    ZeroRegions zr;
+    memset(&zr, 0, sizeof(zr));
+    // Where it pays: the clearing costs the compositing kernel ~8 us per 100 MB (HBM writes under its gathers), so the gradient arrays
+    // must be large for the streaming kernel's stores to be the bigger evil. Measured round 5, K6 + render_bwd, streaming -> compact:
+    // 1M / SH 3 blob (248 MB of gradients, 27 % live) 0.265 -> 0.258 ms, trained-like (6 % live) 0.175 -> 0.134; 100k / SH 3 (25 MB)
+    // 0.131 -> 0.139, 250k / SH 0 (17 MB) 0.093 -> 0.098, 5k 0.028 -> 0.032. Test hook "k6_compact": 0 = never, 1 = whenever possible.
+    const size_t grad_bytes = (size_t)N * (size_t)(3 * (shs ? K : 1) + 14) * 4;
+    bool compact = M > 0 && B == 1 && !view->shs_rest && (ov(OV_K6_COMPACT) == 1 || (ov(OV_K6_COMPACT) < 0 && grad_bytes >= ((size_t)64 << 20)));
+    if (compact) {
+        const struct { float* p; size_t n; } arr[GSR_ZERO_MAX] = {
+            {dL_dmeans3D, (size_t)N * 3}, {dL_dmeans2D, (size_t)N * 3}, {dL_dopacities, (size_t)N}, {shs ? dL_dshs : nullptr, (size_t)N * 3 * K},
+            {dL_dcolors, (size_t)N * 3}, {dL_dscales, (size_t)N * 3}, {dL_drotations, (size_t)N * 4}, {dL_dcov3D, (size_t)N * 6}};
+        size_t total4 = 0;
+        for (int r = 0; r < GSR_ZERO_MAX; ++r) {
+            if (!arr[r].p) continue;
+            if ((uintptr_t)arr[r].p & 15) compact = false;        // (the float4 slices)
+            zr.p[zr.count] = arr[r].p; zr.n4[zr.count] = (uint32_t)(arr[r].n / 4); zr.tail[zr.count] = (uint32_t)(arr[r].n & 3);
+            total4 += arr[r].n / 4; ++zr.count;
+        }
+        if (total4 >= 0x7fffffffull) compact = false;
+        zr.total4 = (uint32_t)total4;
+        if (!compact) memset(&zr, 0, sizeof(zr));
+    }
     prof_begin(stream);
     if (M > 0) {
         const BinLayout BL = bin_layout((size_t)M, TA, shift);
@@ -752,12 +787,13 @@ int backward_impl(const GsrView* views, int B, int32_t N, int32_t K,
         // the caller handed the forward's statistics back; the list's capacity otherwise)
         size_t gmax = BL.plan_cap;
         if (fwd_stats && fwd_stats->num_instances > 0) gmax = ((size_t)fwd_stats->num_instances >> shift) + (size_t)TA + 1;
-        const unsigned grid = (unsigned)(gmax < BL.plan_cap ? gmax : BL.plan_cap);
+        unsigned grid = (unsigned)(gmax < BL.plan_cap ? gmax : BL.plan_cap);
+        if (ov(OV_BWD_GRID) > 0 && (unsigned)ov(OV_BWD_GRID) < grid) grid = (unsigned)ov(OV_BWD_GRID);   // (timing experiments only: items beyond the grid are dropped)
         // workgroup table: [2^shift][10] 64-bit fixed-point sums
         const size_t dyn = ((size_t)GSR_Q2_ROW * 8) << shift;
         hipLaunchKernelGGL(gsr_render_bwd_q2, dim3(grid), dim3(256), dyn, stream, tile_off, recs, sorted_ids, W, H, vc.gx,
                            final_T, n_contrib, totals, ckpt, tile_seg, dL_dcolor, dL_ddepth, dL_dalpha, g2d, shift,
-                           plan_tile, plan_off, plan_total, vs);
+                           plan_tile, plan_off, plan_total, vs, zr, live);
     }
     LAUNCH_CHECK(view, stream, "render_bwd");
 
@@ -782,7 +818,22 @@ int backward_impl(const GsrView* views, int B, int32_t N, int32_t K,
     // several views in ONE launch: always when nothing is staged; with staged SH rows when input + output rows of a workgroup fit
     // the CU's LDS twice over (two workgroups per CU at least): 50 KiB at 16 coefficients
     const size_t lds_multi = 2 * lds;
-    if (B > 1 && lds_multi <= 80 * 1024) {
+    if (compact) {
+        tab.v[0] = make_view(views);
+        const size_t lds_c = (shs && K > 1) ? (size_t)GSR_K6C_NT * (3 * K + 1) * 4 : 0;
+        if (lds_c > 150 * 1024) return fail(-1, "preprocess_bwd needs more than 160 KiB of LDS%s", "");
+        auto k6c = vc.raw_act ? gsr_preprocess_bwd_compact<true> : gsr_preprocess_bwd_compact<false>;
+        if (lds_c > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k6c, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
+        // a persistent grid of 128-thread workgroups, six per CU (25 KiB of staged rows each at 16 coefficients; 168 VGPRs): small
+        // chunks balance the random number of live Gaussians a workgroup finds, and six chains overlap their phases
+        const int rounds = (N + GSR_K6C_ROUND - 1) / GSR_K6C_ROUND;
+        const int gcap = ov(OV_K6_GRID) < 1 ? 1536 : ov(OV_K6_GRID);
+        prof_begin(stream);
+        hipLaunchKernelGGL(k6c, dim3(rounds < gcap ? rounds : gcap), dim3(GSR_K6C_NT), lds_c, stream, tab, N, K, means3D, shs, colors_precomp, opacities, scales,
+                           rotations, cov3D_precomp, flags8, g2d, live, dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacities,
+                           dL_dscales, dL_drotations, dL_dcov3D);
+        LAUNCH_CHECK(view, stream, "preprocess_bwd");
+    } else if (B > 1 && lds_multi <= 80 * 1024) {
         for (int v = 0; v < B; ++v) tab.v[v] = make_view(views + v);
         if (lds_multi > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k6m, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi));
         prof_begin(stream);

@@ -71,6 +71,20 @@ struct __attribute__((aligned(16))) EmitRec {
 // [6..8] dL/drgb  [9] dL/ddepth  [10..11] pad
 #define GSR_G2D_STRIDE 12
 
+// The backward's "live" flags: one BYTE per (view, Gaussian), set (a plain store of 1: racing writers store the same value; an atomic OR
+// on a bit mask cost gsr_render_bwd_q2 13 us at 1M Gaussians) when the compositing kernel adds a non-zero row to the Gaussian's
+// accumulators. They sit right behind the accumulators ([views][N][12] floats | [views][GSR_LIVE_BYTES(N)] bytes) and are cleared with them.
+#define GSR_LIVE_BYTES(N) (((size_t)(N) + 15) & ~(size_t)15)      // per view, a multiple of 16 bytes
+// Caller-owned arrays a kernel clears on the side (by-value kernel argument): float4 slices + up to three floats of tail each.
+#define GSR_ZERO_MAX 8
+struct ZeroRegions {
+    float* p[GSR_ZERO_MAX];
+    uint32_t n4[GSR_ZERO_MAX];       // float4s
+    uint32_t tail[GSR_ZERO_MAX];     // floats behind them (0..3)
+    uint32_t total4;                 // sum of n4
+    int count;
+};
+
 struct ViewConst {           // by-value kernel argument (scalar registers)
     int W, H, gx, gy;
     float tanfovx, tanfovy, focal_x, focal_y;

@@ -658,7 +658,8 @@ __device__ __forceinline__ void k6_gaussian(const ViewConst& vc, const float* ca
                                             float* __restrict__ dL_dshs, bool stage, const float* myrow /* staged SH row (input) */,
                                             float* myrow_out /* LDS row of dL/dSH (the same row as the input for one view per launch) */,
                                             bool lds_accum /* several views per launch: add to myrow_out instead of overwriting it */, int accumulate,
-                                            bool sh_reg /* K == 1, several views per launch: dL/dSH of this view goes to out.dsh */, K6Out& out) {
+                                            bool sh_reg /* K == 1, several views per launch: dL/dSH of this view goes to out.dsh */, K6Out& out,
+                                            bool sparse = false /* the caller never writes out the staged row of a Gaussian that is not `live` */) {
     const int rowlen = 3 * K;
     const bool use_sh = (shs != nullptr);
     const float* V = cam;
@@ -853,7 +854,7 @@ __device__ __forceinline__ void k6_gaussian(const ViewConst& vc, const float* ca
 #pragma unroll
         for (int k = 0; k < 3; ++k) out.dm[k] += V[4 * k] * dtx + V[4 * k + 1] * dty + V[4 * k + 2] * dtz;
     } else if (idx < N && use_sh && !sh_reg) {
-        if (stage) { if (!lds_accum) for (int e = 0; e < rowlen; ++e) myrow_out[e] = 0.f; }
+        if (stage) { if (!lds_accum && !sparse) for (int e = 0; e < rowlen; ++e) myrow_out[e] = 0.f; }
         else if (!accumulate) { float* o = dL_dshs + (size_t)idx * rowlen; for (int e = 0; e < rowlen; ++e) o[e] = 0.f; }
     }
 
@@ -1027,6 +1028,183 @@ gsr_preprocess_bwd(ViewTab tab, int first_view, int B /* B == 1: the view tab.v[
 
 template __global__ void gsr_preprocess_bwd<false, false>(ViewTab, int, int, int, int, const float*, const float*, const float*, float*, const float*, const float*, const float*, const float*, const float*, const int32_t*, const uint8_t*, const float*, float*, float*, float*, float*, float*, float*, float*, float*, int);
 template __global__ void gsr_preprocess_bwd<true, false>(ViewTab, int, int, int, int, const float*, const float*, const float*, float*, const float*, const float*, const float*, const float*, const float*, const int32_t*, const uint8_t*, const float*, float*, float*, float*, float*, float*, float*, float*, float*, int);
+
+// ---------------------------------------------------------------------------------------
+// K6c: preprocess backward for ONE view, over the Gaussians that HAVE a gradient only.
+//
+// In a dense scene a quarter of the Gaussians are reached by a pixel gradient (27 % of the 1M blob, 6 % of the trained-like scene:
+// the rest is hidden behind the stop or never reaches alpha 1/255), in an order that is random against the index.
+// gsr_preprocess_bwd above -- lane = Gaussian -- streams every Gaussian, runs its ~1 900 vector instructions per wave for every wave
+// that holds ONE live lane (3.0e7 wave-instructions = 43 us of a 90 us kernel at the rate its mix can issue) and stores 248 bytes
+// per Gaussian, three quarters of them zeros. Here nothing is streamed:
+//   * gsr_render_bwd_q2 sets one byte per Gaussian it adds a non-zero row to (`live`, cleared with the accumulators) and clears
+//     every gradient array on the side (ZeroRegions: a slice of zeros per workgroup, under an issue-bound kernel);
+//   A  a persistent 128-thread workgroup turns 256 flags per round (two per lane) into a ring of live indices in LDS (wave scan);
+//   B  as soon as the ring holds 128: lane = entry -- inputs, gradient row and SH row of the ENTRY (gathers), the arithmetic of
+//      k6_gaussian with every lane busy, the entry's outputs. What is left in the ring is flushed at the end.
+// Same arithmetic per Gaussian as gsr_preprocess_bwd<RAW, false> (one function). A Gaussian without a bit is not touched at all:
+// its gradients are the zeros the compositing kernel stored.
+// Not here (the host falls back to the kernel above): several views per launch, accumulation onto an earlier view's result, the
+// split SH layout, gradient arrays that are not 16-byte aligned, a backward without the compositing kernel (no instances).
+// dynamic LDS: GSR_K6C_NT * (3K + 1) floats when SH rows are staged (K > 1).
+// ---------------------------------------------------------------------------------------
+#define GSR_K6C_NT 128                                    // threads per workgroup = queue entries per round of phase B
+#define GSR_K6C_PER 2                                     // Gaussians (flag bytes) per lane and round of phase A
+#define GSR_K6C_ROUND (GSR_K6C_NT * GSR_K6C_PER)
+#define GSR_K6C_RING (GSR_K6C_NT + GSR_K6C_ROUND)         // ring of live indices: < NT waiting + one round of phase A (1.5 KiB: with
+                                                          // the 25 KiB of staged rows at 16 coefficients six workgroups share a CU)
+__device__ __forceinline__ uint32_t k6c_slot(uint32_t head, uint32_t off) { const uint32_t p = head + off; return p >= GSR_K6C_RING ? p - GSR_K6C_RING : p; }   // head, off < RING
+template <bool RAW>
+__global__ void __launch_bounds__(GSR_K6C_NT, 4)      // <= 128 VGPRs (0.0688 -> 0.0614 ms at 1M against three waves per SIMD and 130 VGPRs)
+gsr_preprocess_bwd_compact(ViewTab tab /* the view: tab.v[0] */, int N, int K,
+                           const float* __restrict__ means3D, const float* __restrict__ shs,
+                           const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
+                           const float* __restrict__ scales, const float* __restrict__ rotations,
+                           const float* __restrict__ cov3D_precomp,
+                           const uint8_t* __restrict__ flags8, const float* __restrict__ g2d /* [N][12] */,
+                           const uint8_t* __restrict__ live /* [GSR_LIVE_BYTES(N)] */,
+                           float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D /* [N][3] */,
+                           float* __restrict__ dL_dshs, float* __restrict__ dL_dcolors,
+                           float* __restrict__ dL_dopac, float* __restrict__ dL_dscales,
+                           float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D) {
+    constexpr uint32_t NT = GSR_K6C_NT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_pp[];
+    float* shbuf = reinterpret_cast<float*>(smem_pp);
+    const int rowlen = 3 * K, pitch = rowlen + 1;
+    const bool use_sh = (shs != nullptr);
+    const bool stage = use_sh && (K > 1);
+    const ViewConst vc = tab.v[0];
+    __shared__ __attribute__((aligned(16))) float camf[36];
+    __shared__ uint32_t ring[GSR_K6C_RING];               // indices of live Gaussians, in index order
+    __shared__ uint32_t wcnt[NT / 64];
+    if (threadIdx.x < 35) camf[threadIdx.x] = threadIdx.x < 16 ? vc.view[cam_index(threadIdx.x, vc.mat_t & 1)]
+                                              : (threadIdx.x < 32 ? vc.proj[cam_index(threadIdx.x - 16, vc.mat_t & 2)] : vc.campos[threadIdx.x - 32]);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t head = 0, qn = 0;                            // (uniform) ring[head ...], wrapping: qn entries waiting
+    const int stride = gridDim.x * GSR_K6C_ROUND;
+    int base = blockIdx.x * GSR_K6C_ROUND;
+    // the first round's flags travel while the camera is staged; every later round's are requested a round ahead
+    // (GSR_K6C_PER = 2 flags = one aligned 16-bit load per lane: the array is padded to a multiple of 16 bytes)
+    const unsigned short* live16 = reinterpret_cast<const unsigned short*>(live);
+    const int npairs = (int)(GSR_LIVE_BYTES(N) / 2);
+    uint32_t next_flags = live16[min((base >> 1) + (int)threadIdx.x, npairs - 1)];
+    lds_barrier();
+    for (;;) {
+        const bool more = base < N && qn < NT;            // (uniform) a round of phase A only when phase B has nothing full to do
+        if (more) {
+            // ---- phase A: this round's flags -> ring entries (lane = GSR_K6C_PER consecutive Gaussians)
+            uint32_t f = next_flags;
+            if ((base >> 1) + (int)threadIdx.x >= npairs) f = 0u;    // (pairs past the end; bytes past N inside the padding are never set)
+            next_flags = live16[min(((base + stride) >> 1) + (int)threadIdx.x, npairs - 1)];
+            const int i0 = base + (int)threadIdx.x * GSR_K6C_PER;
+            const bool l0 = (f & 0xffu) != 0u, l1 = (f >> 8) != 0u;
+            const uint32_t c = (uint32_t)l0 + (uint32_t)l1;
+            uint32_t incl = c;                            // inclusive scan of the counts over the wave
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t u = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += u; }
+            if (lane == 63) wcnt[wave] = incl;
+            lds_barrier();
+            uint32_t off = incl - c, tot = 0;
+#pragma unroll
+            for (int w = 0; w < (int)(NT / 64); ++w) { const uint32_t x = wcnt[w]; off += w < wave ? x : 0u; tot += x; }
+            if (l0) { ring[k6c_slot(head, qn + off)] = (uint32_t)i0; ++off; }
+            if (l1) ring[k6c_slot(head, qn + off)] = (uint32_t)(i0 + 1);
+            lds_barrier();                                // the ring's new entries (and wcnt free again)
+            qn += tot;
+            base += stride;
+        }
+        const bool last = base >= N;                      // (uniform) nothing left to look at: the rest of the ring goes out as it is
+        const uint32_t take = qn >= NT ? NT : (last ? qn : 0u);    // a full round of entries, or the rest at the very end
+        if (take == 0u) { if (last) break; continue; }
+        // ---- phase B: `take` queue entries, lane = entry
+        const bool mine = threadIdx.x < take;
+        const uint32_t e_idx = ring[k6c_slot(head, min(threadIdx.x, take - 1u))];   // (lanes past the end: a valid index, unused)
+        K6In in;
+        K6ViewIn vin;
+        {
+            const size_t ic = (size_t)e_idx;
+            const gsr_f3 m = *reinterpret_cast<const gsr_f3u*>(means3D + 3 * ic);
+            in.mx = m.x; in.my = m.y; in.mz = m.z;
+            in.op = opacities[ic];
+            in.q = make_float4(1.f, 0.f, 0.f, 0.f); in.sx = in.sy = in.sz = 0.f;
+            if (!cov3D_precomp) {                         // (uniform)
+                in.q = reinterpret_cast<const float4*>(rotations)[ic];
+                const gsr_f3 sc3 = *reinterpret_cast<const gsr_f3u*>(scales + 3 * ic);
+                in.sx = sc3.x; in.sy = sc3.y; in.sz = sc3.z;
+            }
+            vin.flags = flags8[ic];
+            const float4* gp = reinterpret_cast<const float4*>(g2d + ic * GSR_G2D_STRIDE);
+            vin.g0 = gp[0]; vin.g1 = gp[1]; vin.g2 = gp[2];
+        }
+        if (stage) {
+            // the entries' SH rows: lane = 16 bytes of a row (a row is rowlen * 4 contiguous bytes), twelve requests in flight per lane
+            if ((rowlen & 3) == 0) {
+                constexpr int STAGE_U = 12;
+                const int nvec = (int)take * rowlen / 4;
+                for (int i0 = threadIdx.x; i0 < nvec; i0 += NT * STAGE_U) {
+                    float4 v[STAGE_U];
+#pragma unroll
+                    for (int u = 0; u < STAGE_U; ++u) {
+                        const int i = min(i0 + u * NT, nvec - 1);
+                        const int e = 4 * i, row = e / rowlen, col = e - row * rowlen;
+                        v[u] = *reinterpret_cast<const float4*>(shs + (size_t)ring[k6c_slot(head, (uint32_t)row)] * rowlen + col);
+                    }
+#pragma unroll
+                    for (int u = 0; u < STAGE_U; ++u) {
+                        const int i = i0 + u * NT;
+                        if (i < nvec) {
+                            const int e = 4 * i, row = e / rowlen, col = e - row * rowlen;
+                            float* d = shbuf + row * pitch + col;
+                            d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+                        }
+                    }
+                }
+            } else {
+                for (int e = threadIdx.x; e < (int)take * rowlen; e += NT) {
+                    const int row = e / rowlen, col = e - row * rowlen;
+                    shbuf[row * pitch + col] = shs[(size_t)ring[k6c_slot(head, (uint32_t)row)] * rowlen + col];
+                }
+            }
+            lds_barrier();
+        }
+        K6Out cur;
+        float* myrow = shbuf + threadIdx.x * pitch;
+        k6_gaussian<RAW>(vc, camf, mine ? (int)e_idx : N, N, K, mine, in, vin, shs, cov3D_precomp, dL_dshs, stage, myrow, myrow,
+                         false, 0, false, cur, true);
+        if (mine) {
+            const size_t o = (size_t)e_idx;
+            { const gsr_f3 o3 = {cur.dm[0], cur.dm[1], cur.dm[2]}; __builtin_nontemporal_store(o3, reinterpret_cast<gsr_f3u*>(dL_dmeans3D + 3 * o)); }
+            { const gsr_f3 m2 = {cur.dm2[0], cur.dm2[1], 0.f}; __builtin_nontemporal_store(m2, reinterpret_cast<gsr_f3u*>(dL_dmeans2D + 3 * o)); }
+            __builtin_nontemporal_store(cur.dop, dL_dopac + o);
+            if (dL_dcolors) { const gsr_f3 o3 = {cur.dcol[0], cur.dcol[1], cur.dcol[2]}; *reinterpret_cast<gsr_f3u*>(dL_dcolors + 3 * o) = o3; }
+            if (dL_dcov3D) {
+#pragma unroll
+                for (int e = 0; e < 6; ++e) dL_dcov3D[6 * o + e] = cur.dcov[e];
+            }
+            if (dL_dscales) { const gsr_f3 o3 = {cur.dsc[0], cur.dsc[1], cur.dsc[2]}; __builtin_nontemporal_store(o3, reinterpret_cast<gsr_f3u*>(dL_dscales + 3 * o)); }
+            if (dL_drots) store_once(reinterpret_cast<float4*>(dL_drots) + o, cur.dq[0], cur.dq[1], cur.dq[2], cur.dq[3]);
+        }
+        if (stage) {
+            lds_barrier();
+            if ((rowlen & 3) == 0) {
+                for (int i = threadIdx.x; i < (int)take * rowlen / 4; i += NT) {
+                    const int e = 4 * i, row = e / rowlen, col = e - row * rowlen;
+                    const float* sp = shbuf + row * pitch + col;
+                    store_once(reinterpret_cast<float4*>(dL_dshs + (size_t)ring[k6c_slot(head, (uint32_t)row)] * rowlen + col), sp[0], sp[1], sp[2], sp[3]);
+                }
+            } else {
+                for (int e = threadIdx.x; e < (int)take * rowlen; e += NT) {
+                    const int row = e / rowlen, col = e - row * rowlen;
+                    dL_dshs[(size_t)ring[k6c_slot(head, (uint32_t)row)] * rowlen + col] = shbuf[row * pitch + col];
+                }
+            }
+        }
+        lds_barrier();                                    // the rows and the ring's slots are free again
+        head = k6c_slot(head, take); qn -= take;
+    }
+}
+template __global__ void gsr_preprocess_bwd_compact<false>(ViewTab, int, int, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const uint8_t*, const float*, const uint8_t*, float*, float*, float*, float*, float*, float*, float*, float*);
+template __global__ void gsr_preprocess_bwd_compact<true>(ViewTab, int, int, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const uint8_t*, const float*, const uint8_t*, float*, float*, float*, float*, float*, float*, float*, float*);
 
 // visible[i] = view-space z > 0.2  (frustum rule of A.3)
 extern "C" __global__ void __launch_bounds__(256)

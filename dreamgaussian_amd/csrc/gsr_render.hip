@@ -563,8 +563,9 @@ template __global__ void gsr_render_fwd_serial<true>(const uint32_t*, const Spla
                                                      unsigned long long*, uint32_t, unsigned long long, uint32_t, const unsigned long long*, uint32_t, uint32_t, ViewSplit, float4*, uint32_t, uint32_t);
 
 // =========================================================================================
-// K5p: the serial walk with TWO waves per 8x8 block -- EXPERIMENTAL (test hook "fwd_mode" = 3 only; written at the end of round 4
-// after the last GPU minute was spent: it compiles, it has NOT run. DESIGN.md section 8 has the measurement it answers to).
+// K5p: the serial walk with TWO waves per 8x8 block -- the host's choice for ONE view of 1 024 .. 2 047 tiles (finish_impl in
+// gsr_api.hip; test hook "fwd_mode" = 3 forces it). Written at the end of round 4, first run in round 5: bit-identical to
+// gsr_render_fwd_serial<true> in every case tried, 15 % faster at 250k Gaussians / 512^2 (354 busy tiles), nothing at 800^2.
 //
 // gsr_render_fwd_serial is latency-bound per wave, and a dense single view offers few waves: 777 busy tiles x 4 at 1M Gaussians /
 // 800^2 = 3 per SIMD (two per SIMD: +34 %, profiles/r04_ab_nt.txt). A round of a wave is ~1 250 instructions of which a third
@@ -1135,7 +1136,7 @@ gsr_render_fwd_fix(const uint2* __restrict__ walk_items, const unsigned long lon
     const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha,                     \
     float* __restrict__ g2d, int seg_shift, const uint4* __restrict__ plan_items,                 \
     const uint32_t* __restrict__ plan_off, const unsigned long long* __restrict__ plan_total,     \
-    ViewSplit vs
+    ViewSplit vs, ZeroRegions zr, uint8_t* __restrict__ live /* [views][GSR_LIVE_BYTES(N)], cleared with g2d */
 
 // -----------------------------------------------------------------------------------------
 // K5b: quad lists + two passes + fixed-point accumulation.
@@ -1212,7 +1213,30 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
     __shared__ __attribute__((aligned(16))) float mw[4][4][GSR_Q2_BATCH * 40];   // 20 KiB: 16 cells of 16 floats at a 20-float pitch
     __shared__ uint32_t gmax_w[4];                                           // per wave: max of gsum over its pixels (bits of a non-negative float)
     extern __shared__ __attribute__((aligned(16))) unsigned long long acc64[];   // [(1 << seg_shift) * GSR_Q2_ROW]
-    if (blockIdx.x >= (uint32_t)plan_total[0]) return;
+    // Every gradient K6 produces starts from zero and K6 (gsr_preprocess_bwd_compact) then writes only the rows of the Gaussians a
+    // pixel gradient reached (a quarter of a dense scene, 6 % of a trained one): the workgroups that HAVE an item clear a slice each
+    // -- this kernel is bound by vector-instruction issue and leaves HBM idle; K6 was bound by its stores, 248 bytes per Gaussian and
+    // three quarters of them zeros. Slices over the items, not over the launched grid: the grid is an upper bound whose tail (two
+    // thirds of it at 1M Gaussians) is handed out when the kernel is nearly over. No item at all: every workgroup clears.
+    const uint32_t nitems = (uint32_t)min(plan_total[0], (unsigned long long)gridDim.x);
+    const uint32_t nclear = nitems ? nitems : gridDim.x;
+    auto clear_rows = [&]() {
+        if (zr.total4 == 0u || blockIdx.x >= nclear) return;
+        const uint32_t per = (zr.total4 + nclear - 1u) / nclear;
+        const uint32_t lo = min(blockIdx.x * per, zr.total4), hi = min(lo + per, zr.total4);   // (per * nclear < 2^32: total4 < 2^31 on the host)
+        typedef float gsr_v4f __attribute__((ext_vector_type(4)));
+        const gsr_v4f z = {0.f, 0.f, 0.f, 0.f};
+        uint32_t first = 0;                               // the regions laid end to end, in float4s
+        for (int r = 0; r < zr.count; ++r) {
+            const uint32_t rlo = max(lo, first), rhi = min(hi, first + zr.n4[r]);
+            gsr_v4f* __restrict__ dst = reinterpret_cast<gsr_v4f*>(zr.p[r]);
+            for (uint32_t i = rlo + threadIdx.x; i < rhi; i += 256u) __builtin_nontemporal_store(z, dst + (i - first));
+            if (blockIdx.x == 0 && threadIdx.x < zr.tail[r]) zr.p[r][(size_t)zr.n4[r] * 4 + threadIdx.x] = 0.f;
+            first += zr.n4[r];
+        }
+    };
+    clear_rows();                                         // (in front of the set-up loads: 2.5 us better than behind the flush, same box)
+    if (blockIdx.x >= nitems) return;
     // {tile among all views' tiles, the segment's record, list start, segment | (entries - 1) << 24}: ONE scalar load, and every
     // vector load of the set-up below depends on nothing else (only the records hang off the list entries).
     const uint4 item = plan_items[blockIdx.x];
@@ -1228,6 +1252,7 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
         const size_t HWv = (size_t)W * H;
         recs += (size_t)view * vs.N;
         g2d += (size_t)view * vs.N * GSR_G2D_STRIDE;
+        live += (size_t)view * GSR_LIVE_BYTES(vs.N);
         dL_dcolor += view * 3 * HWv; dL_ddepth += view * HWv; dL_dalpha += view * HWv;
         final_T += view * vs.img_stride; n_contrib += view * vs.img_stride; totals += view * vs.img_stride;
     }
@@ -1536,6 +1561,8 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
     float* accf = &mw[0][0][0] + 256;
     uint32_t* gids = reinterpret_cast<uint32_t*>(&mw[0][0][0]);
     if (threadIdx.x < len) {
+        // the Gaussian carries a gradient: K6 takes its work list from these flags
+        if (any) live[gid] = (uint8_t)1;
         gids[threadIdx.x] = any ? gid : 0xffffffffu;
 #pragma unroll
         for (int q = 0; q < GSR_G2D_STRIDE; ++q) accf[threadIdx.x * GSR_G2D_STRIDE + q] = any ? out[q] : 0.f;

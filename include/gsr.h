@@ -94,9 +94,9 @@ typedef struct GsrStats {
                                  * from the previous call (+25 %) so that nothing waits for the host; the backward needs it */
     int64_t seg_shift;          /* log2 of the depth-segment length (6..8) the forward cut the tile lists with; the backward
                                  * walks the same segments */
-    int64_t bwd_prepared;       /* 1: the forward has cleared the backward's per-Gaussian accumulators inside `geom` (on a second
-                                 * stream, while its compositing runs) -- gsr_backward then neither allocates `tmp` nor clears
-                                 * anything. One-shot: a caller that runs a SECOND backward from the same forward state must pass
+    int64_t bwd_prepared;       /* 1: the forward has cleared the backward's per-Gaussian accumulators inside `geom` (every workgroup
+                                 * of its per-tile compositing kernel stores a slice of zeros behind its own work) -- gsr_backward
+                                 * then neither allocates `tmp` nor clears anything. One-shot: a caller that runs a SECOND backward from the same forward state must pass
                                  * 0 (the first one has accumulated into them); 0 also without GsrStats or under NO_BACKWARD */
 } GsrStats;
 
@@ -109,7 +109,8 @@ int gsr_abi_version(void);
  * (process-wide; value -1 = the library decides again). Nothing is read from the process environment: "fwd_mode" and "seg_shift"
  * decide where the per-pixel sums are cut, i.e. the rounding of the results.
  *   "fwd_mode"     1 = serial walk (gsr_render_fwd_serial), 2 = depth-segmented forward (K5a/b/c), 3 = serial walk with a tester
- *                  and a blender wave per 8x8 block (gsr_render_fwd_pair: EXPERIMENTAL, not yet run on a GPU)
+ *                  and a blender wave per 8x8 block (gsr_render_fwd_pair: the library's choice for ONE view of 1 024 .. 2 047 tiles;
+ *                  the same bits as 1)
  *   "seg_shift"    6..8: log2 of the depth-segment length
  *   "fwd_lists"    1 = 8x8 block lists, 2 = quad lists in the forward compositing
  *   "fwd_hints"    1 = off, 2 = every segment behind a tile's first skipped (the chaining kernel walks them all)
@@ -117,6 +118,11 @@ int gsr_abi_version(void);
  *   "hist_max" "k1_grid" "fwd_grid" "k6_grid"   launch geometry (A/B measurements, multi-round paths; "k1_grid" is the grid of
  *                  K1 AND of the scatter kernel, which continues K1's per-workgroup list ranges)
  *   "fwd_lds_kb"   KiB of unused dynamic LDS requested by the serial walk = how many of its workgroups share a CU (0 = none)
+ *   "k6_compact"   how the per-Gaussian backward of a single view runs: 0 = it streams every Gaussian, lane = Gaussian
+ *                  (gsr_preprocess_bwd); 1 = it visits only those the compositing kernel marked as carrying a gradient
+ *                  (gsr_preprocess_bwd_compact, every gradient array cleared under the compositing kernel) whenever the layout
+ *                  allows; the library picks 1 from 64 MB of gradient arrays on
+ *   "bwd_grid"     caps the grid of the backward's compositing kernel (TIMING experiments only: work beyond the cap is dropped)
  * Returns 0, or -1 for an unknown name. dreamgaussian_amd/_testing.py wraps it. */
 int gsr_testing_override(const char* name, int32_t value);
 

@@ -405,15 +405,13 @@ def test_forward_variants_are_bit_identical(gpu, hooks, case):
         assert (sq[i].double() - base[i].double()).abs().max().item() <= 2e-5 * max(1.0, base[i].abs().max().item())   # vs the segmented mode
 
 
-@pytest.mark.skipif(not os.environ.get("GSR_TEST_EXPERIMENTAL"),
-                    reason="gsr_render_fwd_pair (fwd_mode = pair) was written after round 4's last GPU minute: compiled, never run. "
-                           "GSR_TEST_EXPERIMENTAL=1 runs this test; it joins the suite (and the kernel the default path) once it has passed")
 @pytest.mark.parametrize("case", [("blob", 20_000, 0, 256, 6), ("trained", 30_000, 2, 320, 6), ("blob", 60_000, 3, 400, 7),
                                   ("trained", 8_000, 1, 136, 8)], ids=["blob", "trained", "blob_sh3_shift7", "small_odd_shift8"])
 def test_pair_forward_is_bit_identical_to_the_serial_walk(gpu, hooks, case):
-    """EXPERIMENTAL kernel: the serial walk with a tester and a blender wave per 8x8 block must leave the bits of the serial walk --
-    images, radii and (through the checkpoints, the work list and the quad masks it writes) the backward's gradients up to the order
-    of their atomics -- and must terminate (bounded spins: a lost hand-shake shows up as wrong pixels here, not as a hang)."""
+    """gsr_render_fwd_pair (the default for one view of 1 024 .. 2 047 tiles, e.g. 512^2): the serial walk with a tester and a blender
+    wave per 8x8 block must leave the bits of the serial walk -- images, radii and (through the checkpoints, the work list and the quad
+    masks it writes) the backward's gradients up to the order of their atomics -- and must terminate (bounded spins: a lost hand-shake
+    shows up as wrong pixels here, not as a hang). First run on the MI355X in round 5: 4 cases x 3 repetitions identical."""
     kind, N, deg, size, shift = case
     sc = O.make_scene(N, deg, 2, kind)
     S = O.make_settings(O.orbit_pose(-8.0, 25.0, 2.0), size, size, sh_degree=deg)
@@ -433,6 +431,53 @@ def test_pair_forward_is_bit_identical_to_the_serial_walk(gpu, hooks, case):
         for k_ in hg:
             scale = max(gbase[k_].abs().max().item(), floors.get(k_, 0.0)) + 1e-30
             assert (hg[k_] - gbase[k_]).abs().max().item() <= 2e-5 * scale, (rep, k_)
+
+
+@pytest.mark.parametrize("case", [("blob", 30_000, 3, 320, 256, {}), ("trained", 20_011, 2, 200, 168, {}), ("blob", 700, 0, 96, 80, {}),
+                                  ("blob", 4_097, 1, 96, 80, {}), ("blob", 2_000, 3, 64, 64, {"hidden": True}),
+                                  ("trained", 1_500, 0, 128, 96, {"precomp": True}), ("blob", 513, 3, 40, 24, {"empty": True})],
+                         ids=["blob_sh3", "trained_sh2_ragged", "sh0_unstaged", "ragged_sh1", "mostly_hidden", "precomputed", "nothing_live"])
+def test_k6_compact_matches_lane_per_gaussian(gpu, hooks, case):
+    """Round 5: one view's per-Gaussian backward visits only the Gaussians gsr_render_bwd_q2 marked as carrying a gradient (a bit per
+    Gaussian; gsr_preprocess_bwd_compact: ring of live indices in LDS, lane = entry) and every gradient array is cleared by that
+    compositing kernel's workgroups on the side. Against the streaming kernel that writes every row itself (test hook k6_compact = 0):
+    the same function per Gaussian, so the same gradients up to the order of render_bwd's atomics; exact zeros in the same rows --
+    also when the gradient buffer is recycled memory full of NaNs."""
+    kind, N, deg, W, H, opt = case
+    sc = O.make_scene(N, deg, 5, kind)
+    if opt.get("hidden"):
+        sc["opacities"][:] = 0.95                        # almost everything hidden behind the first few: most rows untouched
+    if opt.get("precomp"):
+        Sig = O.covariance3d(sc["scales"], 1.0, sc["rotations"])
+        cov6 = torch.stack([Sig[:, 0, 0], Sig[:, 0, 1], Sig[:, 0, 2], Sig[:, 1, 1], Sig[:, 1, 2], Sig[:, 2, 2]], -1)
+        sc = dict(means3D=sc["means3D"], opacities=sc["opacities"], cov3D_precomp=cov6,
+                  colors_precomp=torch.rand(N, 3, generator=torch.Generator().manual_seed(5)))
+    S = O.make_settings(O.orbit_pose(10.0, -30.0, 2.0), W, H, sh_degree=deg)
+    w = weights_for(H, W)
+    if opt.get("empty"):
+        w = [torch.zeros_like(x) for x in w]              # zero incoming gradient: no work item blends anything, nothing is live
+    hooks.set("k6_compact", 0)
+    _, gd, _ = run_hip(sc, S, gpu, w)
+    hooks.set("k6_compact", 1)                           # (the library picks it from 64 MB of gradient arrays on)
+    # poison the allocator's free blocks: the gradient buffer of the next backward is recycled memory, not fresh zeros
+    junk = [torch.full((N * 64 + 4096,), float("nan"), device=gpu) for _ in range(3)]
+    del junk
+    for rep in range(2):
+        _, gs, _ = run_hip(sc, S, gpu, w)
+        floors = grad_floors(sc, gd) if "scales" in sc else {}
+        for k_ in gs:
+            assert torch.isfinite(gs[k_]).all(), (rep, k_)
+            scale = max(gd[k_].abs().max().item(), floors.get(k_, 0.0)) + 1e-30
+            assert (gs[k_] - gd[k_]).abs().max().item() <= 2e-5 * scale, (rep, k_)
+        # a Gaussian no pixel gradient reached has EXACT zeros everywhere, from either kernel (a single attribute may also cancel to
+        # zero by arithmetic -- dL/drotations of an isotropic Gaussian -- and the two instantiations round that differently)
+        zd = torch.stack([(gd[k_].reshape(N, -1) == 0).all(1) for k_ in gd]).all(0)
+        zs = torch.stack([(gs[k_].reshape(N, -1) == 0).all(1) for k_ in gs]).all(0)
+        assert torch.equal(zd, zs), (rep, int(zd.sum()), int(zs.sum()))
+        if opt.get("empty"):
+            assert bool(zs.all())
+        elif N >= 5_000 or opt.get("hidden"):
+            assert int(zd.sum()) > 0 and int((~zd).sum()) > 0          # both kinds of rows exist, or the test is empty
 
 
 @pytest.mark.parametrize("mode", ["seg", "seq"])

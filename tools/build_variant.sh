@@ -1,5 +1,5 @@
 #!/bin/bash
-# Build a VARIANT of libgsr.so for same-box A/B runs (GSR_LIB=..., tools/gpu_r4.sh ab): the working tree's csrc/ + include/ are
+# Build a VARIANT of libgsr.so for same-box A/B runs (GSR_LIB=..., tools/gpu_r5.sh ab): the working tree's csrc/ + include/ are
 # copied to _exp/src_<name>/, edited there by the commands on stdin (cwd = that copy: `sed -i ... dreamgaussian_amd/csrc/x.hip`,
 # `git -C $ROOT show <ref>:<path> > <path>`, ...) and compiled with build.py's flags into _exp/libgsr_<name>.so.
 # The product tree is never touched; nothing under _exp/ is committed.

@@ -1,5 +1,6 @@
 #!/bin/bash
-# Round-4 gpurun driver: sections chosen by arguments. Outputs -> gpurun_out/.
+# gpurun driver (rounds 4 and 5): sections chosen by arguments. Outputs -> gpurun_out/.
+#   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/gpu_r5.sh new bench1m'
 R=$(pwd)
 mkdir -p gpurun_out
 export TMPDIR=/tmp
@@ -57,6 +58,17 @@ abquick)
   timeout ${QUICK_TIMEOUT:-240} python -m pytest ${QUICK_FILES:-tests/test_parity_gpu.py tests/test_fuzz_gpu.py} -m gpu -q -x -p no:cacheprovider --tb=short -rf --durations=8 \
       -k "${QUICK_K:-forward_backward_match_oracle or committed_golden or depth_ties or segment_lengths or stage1_trained or cfg1_100k_blob or (test_fuzz and not large)}" > gpurun_out/pytest_abquick.log 2>&1
   grep -a "passed\|failed\|FAILED\|Error\|assert\|s call" gpurun_out/pytest_abquick.log | cut -c1-300 | tail -24;;
+new)
+  # the tests of this round's kernel changes, first (fail fast), then the parity subset
+  echo "== pytest: round-5 tests"
+  timeout ${QUICK_TIMEOUT:-400} python -m pytest tests/test_parity_gpu.py -m gpu -q -x -p no:cacheprovider --tb=short -rf -k "${NEW_K:-pair or k6_compact}" > gpurun_out/pytest_new.log 2>&1
+  grep -a "passed\|failed\|FAILED\|Error\|assert" gpurun_out/pytest_new.log | cut -c1-300 | tail -12;;
+quick)
+  # the parity subset a variant library must pass before it is adopted (GSR_LIB=... in the environment of the call)
+  echo "== pytest parity subset [${GSR_LIB:-in-tree library}]"
+  timeout ${QUICK_TIMEOUT:-240} python -m pytest ${QUICK_FILES:-tests/test_parity_gpu.py tests/test_fuzz_gpu.py} -m gpu -q -x -p no:cacheprovider --tb=short -rf --durations=8 \
+      -k "${QUICK_K:-forward_backward_match_oracle or committed_golden or depth_ties or segment_lengths or stage1_trained or cfg1_100k_blob or (test_fuzz and not large)}" > gpurun_out/pytest_abquick.log 2>&1
+  grep -a "passed\|failed\|FAILED\|Error\|assert\|s call" gpurun_out/pytest_abquick.log | cut -c1-300 | tail -24;;
 pair)
   # the experimental two-waves-per-block forward (gsr_render_fwd_pair, test hook fwd_mode = 3): parity gate first, then the A/B
   echo "== pytest -k pair (GSR_TEST_EXPERIMENTAL=1)"
@@ -80,22 +92,22 @@ pytest)
   grep -a "fragile:\|observed:\|passed\|failed\|FAILED\|Error" gpurun_out/pytest_gpu.log | cut -c1-700 | tail -40;;
 prof)
   echo "== rocprofv3 kernel trace (1M)"
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_1M -o r04 -- python $R/bench.py --steps 20 --warmup 5 --cpu-budget 0 --no-roofline > $R/gpurun_out/prof_1M.log 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_1M -o r05 -- python $R/bench.py --steps 20 --warmup 5 --cpu-budget 0 --no-roofline > $R/gpurun_out/prof_1M.log 2>&1)
   tail -2 gpurun_out/prof_1M.log
-  f=$(find gpurun_out/prof_1M -name "r04*kernel_stats.csv" | head -1); [ -n "$f" ] && python - "$f" <<'PY'
+  f=$(find gpurun_out/prof_1M -name "r05*kernel_stats.csv" | head -1); [ -n "$f" ] && python - "$f" <<'PY'
 import csv, sys
 for r in csv.DictReader(open(sys.argv[1])):
     print(r['Name'][:70].ljust(70), r['Calls'], r['AverageNs'], r['MinNs'], r['MaxNs'])
 PY
   ;;
 prof5k)
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_5k -o r04 -- python $R/bench.py --workload 5k-256-sh0 --steps 20 --warmup 5 --cpu-budget 0 --no-roofline > $R/gpurun_out/prof_5k.log 2>&1)
-  f=$(find gpurun_out/prof_5k -name "r04*kernel_stats.csv" | head -1); [ -n "$f" ] && head -16 "$f" | cut -c1-60,200-320;;
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_5k -o r05 -- python $R/bench.py --workload 5k-256-sh0 --steps 20 --warmup 5 --cpu-budget 0 --no-roofline > $R/gpurun_out/prof_5k.log 2>&1)
+  f=$(find gpurun_out/prof_5k -name "r05*kernel_stats.csv" | head -1); [ -n "$f" ] && head -16 "$f" | cut -c1-60,200-320;;
 pmc)
   echo "== rocprofv3 PMC passes (1M)"
   for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE SQ_INSTS_VMEM SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS"; do
     tag=$(echo $c | cut -d" " -f1)
-    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_$tag -o r04 -- python $R/bench.py --steps 3 --warmup 1 --cpu-budget 0 --no-roofline $PMC_ARGS > $R/gpurun_out/pmc_$tag.log 2>&1)
+    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_$tag -o r05 -- python $R/bench.py --steps 3 --warmup 1 --cpu-budget 0 --no-roofline $PMC_ARGS > $R/gpurun_out/pmc_$tag.log 2>&1)
     tail -1 gpurun_out/pmc_$tag.log | cut -c1-200
   done
   python tools/pmc_summary.py gpurun_out --json gpurun_out/pmc_traffic.json --key ${PMC_KEY:-1M-800-sh3/blob} 2>&1 | tee gpurun_out/pmc_summary.txt | tail -40;;
@@ -117,7 +129,7 @@ pmcmorton)
   echo "== rocprofv3 PMC passes, --order morton (1M)"
   mkdir -p gpurun_out/pmcm
   for c in "FETCH_SIZE" "WRITE_SIZE"; do
-    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmcm/pmc_$c -o r04 -- python $R/bench.py --steps 3 --warmup 1 --cpu-budget 0 --no-roofline --order morton > $R/gpurun_out/pmcm/pmc_$c.log 2>&1)
+    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmcm/pmc_$c -o r05 -- python $R/bench.py --steps 3 --warmup 1 --cpu-budget 0 --no-roofline --order morton > $R/gpurun_out/pmcm/pmc_$c.log 2>&1)
   done
   python tools/pmc_summary.py gpurun_out/pmcm 2>&1 | tee gpurun_out/pmc_morton_summary.txt | cut -c1-300;;
 smoke)
