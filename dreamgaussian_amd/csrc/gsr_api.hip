@@ -109,9 +109,9 @@ int once_per_device(F fn) {
 // A/B measurement through an explicit call. Nothing here is read from the process environment: two of them (forward mode, segment
 // length) decide where the per-pixel sums are cut, i.e. the rounding of the results, and that must not depend on who started the
 // process. -1 = the library decides.
-enum { OV_FWD_MODE, OV_SEG_SHIFT, OV_FWD_LISTS, OV_FWD_HINTS, OV_SPECULATE, OV_HIST_MAX, OV_K1_GRID, OV_FWD_GRID, OV_K6_GRID, OV_FWD_LDS_KB, OV_BWD_GRID, OV_K6_COMPACT, OV_COUNT };
-const char* const kOvNames[OV_COUNT] = {"fwd_mode", "seg_shift", "fwd_lists", "fwd_hints", "speculate", "hist_max", "k1_grid", "fwd_grid", "k6_grid", "fwd_lds_kb", "bwd_grid", "k6_compact"};
-std::atomic<int> g_ov[OV_COUNT] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
+enum { OV_FWD_MODE, OV_SEG_SHIFT, OV_FWD_LISTS, OV_FWD_HINTS, OV_SPECULATE, OV_HIST_MAX, OV_K1_GRID, OV_FWD_GRID, OV_K6_GRID, OV_FWD_LDS_KB, OV_BWD_GRID, OV_K6_COMPACT, OV_SCAN_FOLD, OV_COUNT };
+const char* const kOvNames[OV_COUNT] = {"fwd_mode", "seg_shift", "fwd_lists", "fwd_hints", "speculate", "hist_max", "k1_grid", "fwd_grid", "k6_grid", "fwd_lds_kb", "bwd_grid", "k6_compact", "scan_fold"};
+std::atomic<int> g_ov[OV_COUNT] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
 inline int ov(int k) { return g_ov[k].load(std::memory_order_relaxed); }
 
 // K1's grid (a persistent grid: every workgroup walks the same number of 256-Gaussian batches; test hook "k1_grid" pins it). The
@@ -356,7 +356,7 @@ int begin_impl(const GsrView* views, int B, int32_t N, int32_t K,
                const float* means3D, const float* shs, const float* colors_precomp,
                const float* opacities, const float* scales, const float* rotations,
                const float* cov3D_precomp, int32_t* radii, char* gbuf, int shift,
-               unsigned long long* host_counters, int counter_words, hipStream_t stream) {
+               unsigned long long* host_counters, int counter_words, bool scan_in_scatter, hipStream_t stream) {
     const GsrView* view = views;
     unsigned long long* host_counters_dev = nullptr;       // the pinned block as the device addresses it
     HIP_TRY(hipHostGetDevicePointer((void**)&host_counters_dev, host_counters, 0));
@@ -405,10 +405,13 @@ int begin_impl(const GsrView* views, int B, int32_t N, int32_t K,
                            (uint32_t*)(gbuf + GL.tile_count), zero_words, flag_word, epoch, (uint32_t*)(gbuf + GL.wg_base));
         LAUNCH_CHECK(view, stream, "preprocess_fwd");
     }
+    if (scan_in_scatter) return 0;                         // (finish_impl: a workgroup of gsr_scatter runs K2 beside the scatter)
     // one single-workgroup kernel: scan of the counts, K1's statistics, the segment forward's depth-major work list
-    prof_begin(stream); hipLaunchKernelGGL(gsr_tile_scan, dim3(1), dim3(1024), 0, stream, tile_count, (uint32_t*)(gbuf + GL.tile_off), GL.allTiles, counters,
+    // (the tile counts pass through LDS when they fit beside the kernel's 9 KiB: one trip to memory instead of one per phase)
+    const int scan_words = (size_t)GL.allTiles + 1 <= (48 * 1024 - sizeof(TileScanLds)) / 4 ? GL.allTiles + 1 : 0;
+    prof_begin(stream); hipLaunchKernelGGL(gsr_tile_scan, dim3(1), dim3(1024), (size_t)scan_words * 4, stream, tile_count, (uint32_t*)(gbuf + GL.tile_off), GL.allTiles, counters,
                        (uint32_t*)(gbuf + GL.tile_seg), shift, (const unsigned long long*)(gbuf + GL.block_stats), N > 0 ? grid_pre * B : 0, B,
-                       (uint32_t*)(gbuf + GL.order), (uint2*)(gbuf + GL.order_span), (uint32_t*)(gbuf + GL.level_off), host_counters_dev, counter_words, kCounterWords);
+                       (uint32_t*)(gbuf + GL.order), (uint2*)(gbuf + GL.order_span), (uint32_t*)(gbuf + GL.level_off), host_counters_dev, counter_words, kCounterWords, scan_words);
     LAUNCH_CHECK(view, stream, "tile_scan");
     // (the scan kernel stores the counters and then the arrival flag into the pinned block itself: no copy kernels and no event
     // marker in the stream -- the marker alone was a 5 us hole in front of the scatter)
@@ -423,7 +426,7 @@ int sort_class(unsigned long long maxc) { return maxc <= 2048 ? 0 : (maxc <= 819
 int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float* out_depth, float* out_alpha,
                 char* gbuf, char* ibuf, GsrAlloc bin, int shift,
                 const unsigned long long* per_view /* (M_ref, V) of every view */,
-                unsigned long long cap, unsigned long long maxc, bool prepare_bwd, hipStream_t stream) {
+                unsigned long long cap, unsigned long long maxc, bool prepare_bwd, bool scan_in_scatter, int counter_words, hipStream_t stream) {
     const GsrView* view = views;
     const ViewConst vc = make_view(view);
     const int H = vc.H, W = vc.W;
@@ -466,8 +469,23 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
         prof_begin(stream);
         if (hist_in_lds) {
             // K1's grid and Gaussian -> workgroup assignment: every workgroup continues the list ranges its K1 twin reserved
-            hipLaunchKernelGGL(gsr_scatter, dim3(k1_grid_for(N), B), dim3(256), lds, stream, N, emit, tile_off, (const uint32_t*)(gbuf + GL.wg_base), entries,
-                               vc.gx, T, (uint32_t)M, counters, level_off, order, tile_seg, shift, items, items_cap);
+            ScanFold fold;
+            memset(&fold, 0, sizeof(fold));
+            size_t lds_sc = lds;
+            if (scan_in_scatter) {
+                unsigned long long* host_dev = nullptr;
+                HIP_TRY(hipHostGetDevicePointer((void**)&host_dev, g_pinned, 0));
+                fold.on = 1; fold.tile_count = (const uint32_t*)(gbuf + GL.tile_count); fold.tile_off_w = tile_off; fold.tile_seg_w = tile_seg;
+                fold.block_stats = (const unsigned long long*)(gbuf + GL.block_stats); fold.nblocks = k1_grid_for(N) * B;
+                fold.order_w = order; fold.order_span = (uint2*)(gbuf + GL.order_span); fold.level_off_w = (uint32_t*)(gbuf + GL.level_off);
+                fold.host_out = host_dev; fold.host_words = counter_words; fold.host_flag = kCounterWords;
+                const size_t scan_base = (sizeof(TileScanLds) + 15) & ~(size_t)15;
+                if (scan_base + ((size_t)TA + 1) * 4 <= 24 * 1024) fold.lds_words = TA + 1;      // (every workgroup of the launch is given the same dynamic LDS: keep it small)
+                if (lds_sc < scan_base + (size_t)fold.lds_words * 4) lds_sc = scan_base + (size_t)fold.lds_words * 4;
+                if (lds_sc > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)gsr_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc));
+            }
+            hipLaunchKernelGGL(gsr_scatter, dim3(k1_grid_for(N) + (scan_in_scatter ? 1 : 0), B), dim3(256), lds_sc, stream, N, emit, tile_off, (const uint32_t*)(gbuf + GL.wg_base), entries,
+                               vc.gx, T, (uint32_t)M, counters, level_off, order, tile_seg, shift, items, items_cap, k1_grid_for(N), fold);
         } else {
             const int grid_sc = (int)fmin((double)((N + 255) / 256), 512.0);
             hipLaunchKernelGGL(gsr_scatter_global, dim3(grid_sc, B), dim3(256), 0, stream, N, emit, tile_off, cursor, entries,
@@ -639,8 +657,18 @@ int forward_impl(const GsrView* views, int B, int32_t N, int32_t K,
     // of its per-tile kernel (gsr_render_fwd_serial / gsr_render_fwd_combine) clears a slice of them behind its own work. (A fill on
     // a second stream was measured first: the two cross-stream waits cost 15 us of bubbles, more than the fill.)
     const bool prepare = N > 0 && !(view->flags & GSR_VIEW_NO_BACKWARD);
+    const bool spec = ov(OV_SPECULATE) != 0 && g_hint.valid && g_hint.N == N && g_hint.H == vcs.H && g_hint.W == vcs.W && g_hint.B == B && N > 0;
+    // K2 (scan of the tile counts, statistics, tile order, the counters for the host) inside the scatter's launch: when the forward is
+    // enqueued in one go (speculation), the tile counters sit in LDS (no global cursors) and the compositing takes its tiles from
+    // `order` (the depth-major item list of the segmented mode is written BY the scatter FROM K2's results). Test hook "scan_fold" = 0: never.
+    // ... and when the forward is long enough for the host: its one wait (for K2's counters) ends a scatter later with the fold, and what it
+    // then has to enqueue (the caller's loss, the backward) must still arrive before the compositing ends -- 250k / 512^2 and 100k / 800^2
+    // lost 50 us per step to GPU idle time with it (their sort + compositing take ~0.1 ms), 1M / 800^2 gains 6-13: from 2M instances on.
+    // (and for up to 4 096 tiles in the launch: K2 on 256 threads is the tail of the scatter beyond that -- 8 x 1 024 tiles: +20 us)
+    const bool fold = spec && GLs.nTiles <= hist_lds_max_tiles() && GLs.allTiles <= 4096 && fwd_sequential_for(N, GLs.nTiles) &&
+                      (ov(OV_SCAN_FOLD) == 1 || (ov(OV_SCAN_FOLD) < 0 && g_hint.M >= 2000000ull));
     if (int rc = begin_impl(views, B, N, K, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                            radii, gbuf, shift, g_pinned, 8 + 2 * B, stream)) {
+                            radii, gbuf, shift, g_pinned, 8 + 2 * B, fold, stream)) {
         (void)hipStreamSynchronize(stream);               // nothing may still write the pinned block when the next call re-arms it
         return rc;
     }
@@ -651,14 +679,17 @@ int forward_impl(const GsrView* views, int B, int32_t N, int32_t K,
     // tests/test_parity_gpu.py::test_speculative_forward_recovers_from_mispredictions). Measured, ms per fwd+bwd, wait-first /
     // speculative with the event / speculative with the flag: 5k-256^2 0.402 / 0.396 / 0.313, 250k-512^2 0.366 / 0.352 / 0.354,
     // 100k-800^2 0.369 / 0.348 / 0.350, 1M-800^2 0.751 / 0.750 / 0.747 (round 2).
-    const bool spec = ov(OV_SPECULATE) != 0 && g_hint.valid && g_hint.N == N && g_hint.H == vcs.H && g_hint.W == vcs.W && g_hint.B == B && N > 0;
     unsigned long long cap = 0, capc = 0;
     int rc = 0;
     if (spec) {
         cap = g_hint.M + g_hint.M / 4 + 4096;
         const unsigned long long c = g_hint.maxc + g_hint.maxc / 4 + 64;
         capc = c <= 2048 ? 2048 : (c <= 8192 ? 8192 : (c <= 16384 ? 16384 : ~0ull));
-        rc = finish_impl(views, B, N, out_color, out_depth, out_alpha, gbuf, ibuf, bin, shift, g_hint.per_view, cap, capc, prepare, stream);
+        rc = finish_impl(views, B, N, out_color, out_depth, out_alpha, gbuf, ibuf, bin, shift, g_hint.per_view, cap, capc, prepare, fold, 8 + 2 * B, stream);
+        if (rc && fold) {                                 // K2 never ran: nothing will ever arrive in the pinned block
+            (void)hipStreamSynchronize(stream);
+            return rc;
+        }
     }
     if (int rcw = wait_counters(g_pinned, stream)) return rcw;    // also on a failed tail: nothing may stay pending on the pinned block
     if (rc) return rc;
@@ -670,7 +701,7 @@ int forward_impl(const GsrView* views, int B, int32_t N, int32_t K,
     }
     if (!spec || cap == 0) {
         cap = M;
-        rc = finish_impl(views, B, N, out_color, out_depth, out_alpha, gbuf, ibuf, bin, shift, g_pinned + 8, M, maxc, prepare, stream);
+        rc = finish_impl(views, B, N, out_color, out_depth, out_alpha, gbuf, ibuf, bin, shift, g_pinned + 8, M, maxc, prepare, false, 8 + 2 * B, stream);
     }
     if (stats) { stats->num_instances = (int64_t)M; stats->num_instances_ref = (int64_t)M_ref; stats->num_visible = (int64_t)V;
                  stats->max_tile_count = (int64_t)maxc; stats->bin_capacity = (int64_t)cap; stats->seg_shift = shift;

@@ -27,26 +27,44 @@
 // segments, ... -- no list is written, gsr_render_fwd_seg finds its level with two ballots over level_off[0..1023].
 // level_off[c] = the item total for every c >= the number of levels.
 // ---------------------------------------------------------------------------------------
-#define GSR_NCLS (GSR_NLEV + 1)          // 1024 = one class per thread of the scan workgroup
+#define GSR_NCLS (GSR_NLEV + 1)          // 1024 classes
 
-// exclusive scan over the 1024 threads of the workgroup, one value each (wsum: 16 words of LDS); *total = sum of all
-__device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t* wsum, uint32_t* total) {
+// in-place exclusive scan of a[0 .. n) in LDS by the NT threads of the workgroup (wsum: NT / 64 words); returns the total
+template <int NT>
+__device__ __forceinline__ uint32_t block_excl_scan_lds(uint32_t* a, int n, uint32_t* wsum) {
+    const int per = (n + NT - 1) / NT;
+    const int beg = min((int)threadIdx.x * per, n), end = min(beg + per, n);
+    uint32_t local = 0;
+    for (int i = beg; i < end; ++i) local += a[i];
+    uint32_t incl = local;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t incl = v;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
     __syncthreads();                                   // wsum may still be read by the previous scan
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
     uint32_t base = 0, all = 0;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) { const uint32_t x = wsum[w]; all += x; base += w < wave ? x : 0u; }
-    if (total) *total = all;
-    return base + incl - v;
+    for (int w = 0; w < NT / 64; ++w) { const uint32_t x = wsum[w]; all += x; base += w < wave ? x : 0u; }
+    uint32_t run = base + incl - local;
+    for (int i = beg; i < end; ++i) { const uint32_t c = a[i]; a[i] = run; run += c; }
+    __syncthreads();
+    return all;
 }
 
-extern "C" __global__ void __launch_bounds__(1024)
-gsr_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_off, int T,
+// LDS of one scan workgroup (static in gsr_tile_scan; inside the dynamic block of gsr_scatter's scan workgroup)
+struct TileScanLds {
+    unsigned long long wsum[16], sref[16], svis[16], smax[16];
+    uint32_t wsegs[16], wmax[16], scratch[16];
+    uint32_t cls[GSR_NCLS], tmp[GSR_NCLS];
+};
+
+// The body of K2 for a workgroup of NT threads (1 024: the kernel of its own; 256: a workgroup of gsr_scatter, see there).
+// `A`: T + 1 words of LDS, or NULL. With it the tile counts are read from HBM ONCE, coalesced and all requests in flight together,
+// become the list starts in place, and every later phase (segment classes, the order) takes count and start from LDS; without it
+// (tile grids beyond the buffer) each phase reads tile_count again and the order reads tile_off back from memory.
+template <int NT>
+__device__ __forceinline__ void tile_scan_body(TileScanLds& L, uint32_t* A, const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_off, int T,
               unsigned long long* __restrict__ counters, uint32_t* __restrict__ tile_seg, int seg_shift,
               const unsigned long long* __restrict__ block_stats, int nblocks /* all views */, int nviews,
               uint32_t* __restrict__ order /* tiles by segment count, descending */, uint2* __restrict__ order_span /* (list start, length) of order[k] */,
@@ -54,19 +72,26 @@ gsr_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ ti
               unsigned long long* __restrict__ host_out /* pinned host memory (device-mapped): the first `host_words` counters land in
                                                            words 0.., the arrival flag in word `host_flag` */,
               int host_words, int host_flag) {
+    constexpr int NW = NT / 64;
     // tile_seg[t] = index of tile t's first segment record = exclusive scan of ceil(n_t / 2^seg_shift)
-    __shared__ unsigned long long wsum[16];
-    __shared__ uint32_t wsegs[16];
-    __shared__ uint32_t wmax[16];
-    __shared__ uint32_t cls[GSR_NCLS];
     const uint32_t round = (1u << seg_shift) - 1u;
-    const int per = (T + 1023) / 1024;
+    const int per = (T + NT - 1) / NT;
     const int beg = min((int)threadIdx.x * per, T), end = min(beg + per, T);
     unsigned long long local = 0;
     uint32_t lmax = 0, lsegs = 0;
-    cls[threadIdx.x] = 0u;
+    for (int c = threadIdx.x; c < GSR_NCLS; c += NT) L.cls[c] = 0u;
+    if (A) {
+        for (int t0 = threadIdx.x; t0 < T; t0 += NT * 4) {            // (four requests in flight per thread, indices clamped: branch-free)
+            uint32_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = tile_count[min(t0 + u * NT, T - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (t0 + u * NT < T) A[t0 + u * NT] = v[u];
+        }
+        __syncthreads();
+    }
     for (int i = beg; i < end; ++i) {
-        const uint32_t c = tile_count[i];
+        const uint32_t c = A ? A[i] : tile_count[i];
         local += c; lmax = max(lmax, c); lsegs += (c + round) >> seg_shift;
     }
     // inclusive scan inside the wave
@@ -80,36 +105,35 @@ gsr_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ ti
         if (lane >= off) { incl += o; sincl += so; }
     }
     lmax = wave_max_u32(lmax);
-    if (lane == 63) { wsum[wave] = incl; wsegs[wave] = sincl; }
-    if (lane == 0) wmax[wave] = lmax;
+    if (lane == 63) { L.wsum[wave] = incl; L.wsegs[wave] = sincl; }
+    if (lane == 0) L.wmax[wave] = lmax;
     __syncthreads();
     unsigned long long wave_base = 0;
     uint32_t seg_base = 0;
-    for (int w = 0; w < wave; ++w) { wave_base += wsum[w]; seg_base += wsegs[w]; }
+    for (int w = 0; w < wave; ++w) { wave_base += L.wsum[w]; seg_base += L.wsegs[w]; }
     unsigned long long run = wave_base + incl - local;
     uint32_t srun = seg_base + sincl - lsegs;
     for (int i = beg; i < end; ++i) {
-        const uint32_t c = tile_count[i];
-        tile_off[i] = (uint32_t)run; run += c;
+        const uint32_t c = A ? A[i] : tile_count[i];
+        tile_off[i] = (uint32_t)run; if (A) A[i] = (uint32_t)run; run += c;
         tile_seg[i] = srun; srun += (c + round) >> seg_shift;
     }
     {   // K1's per-workgroup statistics (M_ref, V): parallel sum over the workgroups
-        __shared__ unsigned long long sref[16], svis[16], smax[16];
         unsigned long long a = 0, b = 0, c = 0;
-        for (int i = threadIdx.x; i < nblocks; i += 1024) { a += block_stats[3 * i]; b += block_stats[3 * i + 1]; c = max(c, block_stats[3 * i + 2]); }
+        for (int i = threadIdx.x; i < nblocks; i += NT) { a += block_stats[3 * i]; b += block_stats[3 * i + 1]; c = max(c, block_stats[3 * i + 2]); }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); c = max(c, (unsigned long long)__shfl_xor(c, off, 64)); }
-        if (lane == 0) { sref[wave] = a; svis[wave] = b; smax[wave] = c; }
+        if (lane == 0) { L.sref[wave] = a; L.svis[wave] = b; L.smax[wave] = c; }
         __syncthreads();
         if (threadIdx.x == 0) {
             unsigned long long ta = 0, tb = 0, tc = 0;
-            for (int w = 0; w < 16; ++w) { ta += sref[w]; tb += svis[w]; tc = max(tc, smax[w]); }
+            for (int w = 0; w < NW; ++w) { ta += L.sref[w]; tb += L.svis[w]; tc = max(tc, L.smax[w]); }
             counters[0] = ta; counters[1] = tb; counters[5] = tc;
         }
         // per view (block_stats is [view][workgroup][3]): counters[8 + 2v] = M_ref, [9 + 2v] = V -- the host picks the
         // compositing kernel of every view from them exactly as a single-view call would
         const int per_view = nviews > 0 ? nblocks / nviews : 0;
-        for (int v = wave; v < nviews; v += 16) {
+        for (int v = wave; v < nviews; v += NW) {
             unsigned long long va = 0, vb = 0;
             for (int i = lane; i < per_view; i += 64) { va += block_stats[3 * (v * per_view + i)]; vb += block_stats[3 * (v * per_view + i) + 1]; }
 #pragma unroll
@@ -118,51 +142,54 @@ gsr_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ ti
         }
     }
     uint32_t maxc = 0;
-    for (int w = 0; w < 16; ++w) maxc = max(maxc, wmax[w]);
-    if (threadIdx.x == 1023) {
+    for (int w = 0; w < NW; ++w) maxc = max(maxc, L.wmax[w]);
+    if (threadIdx.x == NT - 1) {
         tile_off[T] = (uint32_t)(wave_base + incl);
+        if (A) A[T] = (uint32_t)(wave_base + incl);
         counters[2] = wave_base + incl;
         counters[3] = maxc;
         const uint32_t nlev = min((maxc + round) >> seg_shift, (uint32_t)GSR_NLEV);
         counters[7] = (unsigned long long)nlev | ((unsigned long long)seg_shift << 32);
     }
+    __syncthreads();                                      // (A: now the list starts, A[T] = M)
     // ---- classes: histogram of min(segments, GSR_NLEV). Empty tiles (two thirds of a 512^2 view) all fall into class 0:
     // one atomic per wave for them, not one per tile
-    for (int t0 = 0; t0 < T; t0 += 1024) {
+    for (int t0 = 0; t0 < T; t0 += NT) {
         const int t = t0 + (int)threadIdx.x;
-        const uint32_t n = t < T ? tile_count[t] : 0u;
+        const uint32_t n = t < T ? (A ? A[t + 1] - A[t] : tile_count[t]) : 0u;
         const unsigned long long em = __ballot(t < T && n == 0u);
-        if (t < T && n != 0u) atomicAdd(&cls[min((n + round) >> seg_shift, (uint32_t)GSR_NLEV)], 1u);
-        if (em != 0ull && lane == __builtin_ctzll(em)) atomicAdd(&cls[0], (uint32_t)__popcll(em));
+        if (t < T && n != 0u) atomicAdd(&L.cls[min((n + round) >> seg_shift, (uint32_t)GSR_NLEV)], 1u);
+        if (em != 0ull && lane == __builtin_ctzll(em)) atomicAdd(&L.cls[0], (uint32_t)__popcll(em));
     }
     __syncthreads();
-    uint32_t* scratch = wsegs;                            // 16 words, free from here on
-    // S[h] = #tiles of class > h: thread i <-> class h = 1023 - i, exclusive scan in i
-    const uint32_t mine = cls[(GSR_NCLS - 1) - threadIdx.x];
-    const uint32_t S_rev = block_scan_1024(mine, scratch, nullptr);
-    __syncthreads();                                      // every count is read: the array becomes S (and then the cursors)
-    cls[(GSR_NCLS - 1) - threadIdx.x] = S_rev;
+    // S[h] = #tiles of class > h = the exclusive scan of the counts in REVERSED class order, read back reversed
+    for (int c = threadIdx.x; c < GSR_NCLS; c += NT) L.tmp[c] = L.cls[(GSR_NCLS - 1) - c];
     __syncthreads();
-    // level_off[c] = sum of S[c'] for c' < c: thread j <-> level c = j
-    level_off[threadIdx.x] = block_scan_1024(cls[threadIdx.x], scratch, nullptr);
+    block_excl_scan_lds<NT>(L.tmp, GSR_NCLS, L.scratch);
+    for (int c = threadIdx.x; c < GSR_NCLS; c += NT) L.cls[c] = L.tmp[(GSR_NCLS - 1) - c];      // every count is read: the array becomes S (and then the cursors)
     __syncthreads();
+    // level_off[c] = sum of S[c'] for c' < c
+    for (int c = threadIdx.x; c < GSR_NCLS; c += NT) L.tmp[c] = L.cls[c];
+    __syncthreads();
+    block_excl_scan_lds<NT>(L.tmp, GSR_NCLS, L.scratch);
+    for (int c = threadIdx.x; c < GSR_NCLS; c += NT) level_off[c] = L.tmp[c];
     // order[S[class]++] = tile: descending classes, the empty tiles last
-    for (int t0 = 0; t0 < T; t0 += 1024) {
+    for (int t0 = 0; t0 < T; t0 += NT) {
         const int t = t0 + (int)threadIdx.x;
-        const uint32_t n = t < T ? tile_count[t] : 0u;
+        const uint32_t n = t < T ? (A ? A[t + 1] - A[t] : tile_count[t]) : 0u;
         const bool empty = t < T && n == 0u;
         const unsigned long long em = __ballot(empty);
-        // (tile_off was stored by other threads of this workgroup in front of several barriers; the sort kernels take a tile's
-        // (start, length) from ONE load at its position in the order instead of order -> tile_off)
+        // (without A: tile_off was stored by other threads of this workgroup in front of several barriers. The sort kernels take a
+        // tile's (start, length) from ONE load at its position in the order instead of order -> tile_off)
         if (t < T && n != 0u) {
-            const uint32_t pos = atomicAdd(&cls[min((n + round) >> seg_shift, (uint32_t)GSR_NLEV)], 1u);
+            const uint32_t pos = atomicAdd(&L.cls[min((n + round) >> seg_shift, (uint32_t)GSR_NLEV)], 1u);
             order[pos] = (uint32_t)t;
-            order_span[pos] = make_uint2(__hip_atomic_load(tile_off + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), n);
+            order_span[pos] = make_uint2(A ? A[t] : __hip_atomic_load(tile_off + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), n);
         }
         if (em != 0ull) {
             const int leader = __builtin_ctzll(em);
             uint32_t b = 0;
-            if (lane == leader) b = atomicAdd(&cls[0], (uint32_t)__popcll(em));
+            if (lane == leader) b = atomicAdd(&L.cls[0], (uint32_t)__popcll(em));
             b = __builtin_amdgcn_readlane(b, leader);
             if (empty) {
                 const uint32_t pos = b + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
@@ -183,6 +210,18 @@ gsr_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ ti
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_store(host_out + host_flag, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+}
+
+extern "C" __global__ void __launch_bounds__(1024)
+gsr_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_off, int T,
+              unsigned long long* __restrict__ counters, uint32_t* __restrict__ tile_seg, int seg_shift,
+              const unsigned long long* __restrict__ block_stats, int nblocks, int nviews,
+              uint32_t* __restrict__ order, uint2* __restrict__ order_span, uint32_t* __restrict__ level_off,
+              unsigned long long* __restrict__ host_out, int host_words, int host_flag, int lds_words /* dynamic LDS, in words */) {
+    __shared__ TileScanLds L;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];      // (T + 1) words when the host found room for them, else nothing
+    tile_scan_body<1024>(L, lds_words > T ? reinterpret_cast<uint32_t*>(smem_raw) : nullptr, tile_count, tile_off, T, counters, tile_seg, seg_shift, block_stats, nblocks, nviews, order, order_span, level_off,
+                         host_out, host_words, host_flag);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -210,41 +249,94 @@ __device__ __forceinline__ void write_forward_items(const uint32_t* __restrict__
     }
 }
 
-// LDS-histogram mode (tile grids of up to 16 384 tiles): K1's twin. Same grid, same Gaussians per workgroup (batches blockIdx.x,
-// blockIdx.x + gridDim.x, ... of 256): K1's histogram flush has reserved, per tile, the range of this workgroup's entries
+// What gsr_scatter's scan workgroup needs to run K2 inside the scatter's launch (by-value kernel argument).
+struct ScanFold {
+    int on;                                  // 0: gsr_tile_scan ran in front of this launch (tile_off is in memory)
+    const uint32_t* tile_count;              // [views * nTiles]
+    uint32_t* tile_off_w; uint32_t* tile_seg_w;
+    const unsigned long long* block_stats; int nblocks;
+    uint32_t* order_w; uint2* order_span; uint32_t* level_off_w;
+    unsigned long long* host_out; int host_words, host_flag;
+    int lds_words;                           // words of dynamic LDS behind the TileScanLds block (all tiles' counts fit: K2 keeps them there)
+};
+
+// LDS-histogram mode (tile grids of up to 16 384 tiles): K1's twin. Same grid, same Gaussians per workgroup (batches bx,
+// bx + k1_grid, ... of 256): K1's histogram flush has reserved, per tile, the range of this workgroup's entries
 // (wg_base); the positions inside it are handed out from LDS. ONE pass, no global atomics.
-// dynamic LDS: nTiles uint32.
+//
+// K2 FOLDED IN (fold.on, round 5; the speculative forward of views whose compositing takes its tiles from `order`): the scatter needs
+// of K2 only where every tile's list starts -- an exclusive scan of the tile counts K1 left, which every workgroup here takes for
+// itself in LDS (2 500 counts: ~1 us, the counts are L2 hits) -- and the rest of K2 (segment bases, K1's statistics, the tiles
+// ordered by length for the sort and the compositing, the counters for the host) is needed by the kernels BEHIND the scatter. So
+// workgroup x = 0 of view 0 runs K2's body (256 threads instead of 1 024: it has the scatter's 35 us to hide in) and the scatter
+// workgroups are x = 1 .. k1_grid: one launch and 15-18 us of a single-workgroup kernel fewer per forward.
+// dynamic LDS: max(nTiles uint32, sizeof(TileScanLds) + (views * nTiles + 1) uint32 when that fits 64 KiB).
 #define GSR_SC_R 4      // emission records a thread requests at once (K1's default grid: four batches per workgroup)
 extern "C" __global__ void __launch_bounds__(256)
 gsr_scatter(int N, const EmitRec* __restrict__ emit, const uint32_t* __restrict__ tile_off,
             const uint32_t* __restrict__ wg_base, unsigned long long* __restrict__ entries,
             int gx, int nTiles, uint32_t capacity, unsigned long long* __restrict__ counters,
             const uint32_t* __restrict__ level_off, const uint32_t* __restrict__ order, const uint32_t* __restrict__ tile_seg,
-            int seg_shift, uint4* __restrict__ items, uint32_t items_cap) {
+            int seg_shift, uint4* __restrict__ items, uint32_t items_cap, int k1_grid, ScanFold fold) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint32_t* next = reinterpret_cast<uint32_t*>(smem_raw);      // [nTiles]: the next free position of this workgroup's range in the tile's list
-    // The scratch may have been sized BEFORE the host knew M (gsr_forward: previous call + 25 %). M is on the
-    // device: every consumer of the lists leaves at once when they do not fit, and the host repeats the tail.
-    if (counters[2] > (unsigned long long)capacity) return;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) counters[6] = capacity;    // for a backward called without GsrStats
     __shared__ uint32_t lev[GSR_NLEV + 1];
-    if (items_cap) write_forward_items(level_off, order, tile_off, tile_seg, seg_shift, items, items_cap, lev);
+    __shared__ uint32_t red[8];
+    int bx = (int)blockIdx.x;
+    if (fold.on) {
+        if (bx == 0) {
+            if (blockIdx.y == 0)
+                tile_scan_body<256>(*reinterpret_cast<TileScanLds*>(smem_raw),
+                                    fold.lds_words > nTiles * (int)gridDim.y ? reinterpret_cast<uint32_t*>(smem_raw + ((sizeof(TileScanLds) + 15) & ~(size_t)15)) : nullptr, fold.tile_count, fold.tile_off_w, nTiles * (int)gridDim.y, counters,
+                                    fold.tile_seg_w, seg_shift, fold.block_stats, fold.nblocks, (int)gridDim.y, fold.order_w, fold.order_span,
+                                    fold.level_off_w, fold.host_out, fold.host_words, fold.host_flag);
+            return;
+        }
+        --bx;
+    } else if (counters[2] > (unsigned long long)capacity) return;
+    // (the scratch may have been sized BEFORE the host knew M -- gsr_forward: previous call + 25 %. M is on the device: every consumer
+    // of the lists leaves at once when they do not fit, and the host repeats the tail)
     // blockIdx.y = view: its records and its tiles (tile_off holds positions in the one list array of all views)
     emit += (size_t)blockIdx.y * (size_t)N;
-    tile_off += (size_t)blockIdx.y * nTiles;
-    const uint32_t* __restrict__ base_row = wg_base + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * nTiles;
-    const int stride = gridDim.x * 256;
-    const int first = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t* __restrict__ base_row = wg_base + ((size_t)blockIdx.y * k1_grid + bx) * nTiles;
+    const int stride = k1_grid * 256;
+    const int first = bx * 256 + threadIdx.x;
     // a thread's first records travel while the ranges are loaded
     uint4 em[GSR_SC_R];
 #pragma unroll
     for (int r = 0; r < GSR_SC_R; ++r) em[r] = reinterpret_cast<const uint4*>(emit)[min(first + r * stride, N - 1)];   // branch-free (index clamped)
-    for (int t0 = threadIdx.x; t0 < nTiles; t0 += 256 * 4) {      // (eight loads in flight per thread; entries of tiles nobody here emits into: never used)
-        uint32_t a[4], b[4];
+    if (fold.on) {
+        // this view's list starts: the counts of the views in front summed, the own view's scanned in LDS; M = the sum over all views
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int before = (int)blockIdx.y * nTiles, all = (int)gridDim.y * nTiles;
+        uint32_t s_before = 0, s_after = 0;
+        for (int t = threadIdx.x; t < all; t += 256) {
+            if (t >= before && t < before + nTiles) continue;
+            const uint32_t c = fold.tile_count[t];
+            if (t < before) s_before += c; else s_after += c;
+        }
+        for (int t = threadIdx.x; t < nTiles; t += 256) next[t] = fold.tile_count[before + t];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int t = min(t0 + 256 * u, nTiles - 1); a[u] = tile_off[t]; b[u] = base_row[t]; }
+        for (int off = 32; off >= 1; off >>= 1) { s_before += __shfl_xor(s_before, off, 64); s_after += __shfl_xor(s_after, off, 64); }
+        if (lane == 0) { red[wave] = s_before; red[4 + wave] = s_after; }
+        __syncthreads();
+        const uint32_t own = block_excl_scan_lds<256>(next, nTiles, lev);     // (lev: free here -- no items in this mode; 4 words used)
+        const uint32_t lists_before = red[0] + red[1] + red[2] + red[3];
+        const unsigned long long M_all = (unsigned long long)lists_before + own + red[4] + red[5] + red[6] + red[7];
+        if (M_all > (unsigned long long)capacity) return;                        // (the scan workgroup tells the host; the tail is repeated)
+        if (bx == 0 && blockIdx.y == 0 && threadIdx.x == 0) counters[6] = capacity;
+        for (int t = threadIdx.x; t < nTiles; t += 256) next[t] += lists_before + base_row[t];
+    } else {
+        if (bx == 0 && blockIdx.y == 0 && threadIdx.x == 0) counters[6] = capacity;    // for a backward called without GsrStats
+        if (items_cap) write_forward_items(level_off, order, tile_off, tile_seg, seg_shift, items, items_cap, lev);
+        tile_off += (size_t)blockIdx.y * nTiles;
+        for (int t0 = threadIdx.x; t0 < nTiles; t0 += 256 * 4) {      // (eight loads in flight per thread; entries of tiles nobody here emits into: never used)
+            uint32_t a[4], b[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) if (t0 + 256 * u < nTiles) next[t0 + 256 * u] = a[u] + b[u];
+            for (int u = 0; u < 4; ++u) { const int t = min(t0 + 256 * u, nTiles - 1); a[u] = tile_off[t]; b[u] = base_row[t]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (t0 + 256 * u < nTiles) next[t0 + 256 * u] = a[u] + b[u];
+        }
     }
     lds_barrier();
     for (int base = first; base < N; base += GSR_SC_R * stride) {

@@ -122,6 +122,8 @@ int gsr_abi_version(void);
  *                  (gsr_preprocess_bwd); 1 = it visits only those the compositing kernel marked as carrying a gradient
  *                  (gsr_preprocess_bwd_compact, every gradient array cleared under the compositing kernel) whenever the layout
  *                  allows; the library picks 1 from 64 MB of gradient arrays on
+ *   "scan_fold"    0 = the scan of the tile counts (K2) always runs as a kernel of its own, 1 = inside the scatter's launch whenever
+ *                  the forward is speculative and composites from the tile order (the library: from 2M predicted instances on)
  *   "bwd_grid"     caps the grid of the backward's compositing kernel (TIMING experiments only: work beyond the cap is dropped)
  * Returns 0, or -1 for an unknown name. dreamgaussian_amd/_testing.py wraps it. */
 int gsr_testing_override(const char* name, int32_t value);

@@ -363,6 +363,51 @@ def test_speculative_forward_recovers_from_mispredictions(gpu):
         assert_grads_close(hg, og, aux, floors=grad_floors(sc, og))
 
 
+def test_scan_folded_into_the_scatter_is_bit_identical(gpu, hooks):
+    """Round 5: in the speculative forward of views whose compositing takes its tiles from `order` (serial walk / pair), K2 runs as a
+    workgroup of gsr_scatter's launch and every scatter workgroup scans the tile counts for itself. Same frames, same order, with
+    the fold and without (test hook scan_fold = 0): images, radii, counters bit-identical, gradients up to the order of the atomics --
+    through frames whose instance counts and longest lists mispredict each other (the tail is repeated with K2's results in memory)
+    and for several views in one launch chain (a scatter workgroup adds the lists of the views in front of its own)."""
+    W = H = 96
+    S = O.make_settings(O.orbit_pose(0, 0, 2.0), W, H, sh_degree=0)
+    w = weights_for(H, W)
+    N = 12000
+    spread_out = _cluster_scene(N, 1.2, 0.0, False, seed=3)
+    big = dict(spread_out); big["scales"] = spread_out["scales"] * 4.0
+    one_tile = _cluster_scene(N, 0.15, 0.229, False, seed=4)
+    frames = (("spread", spread_out), ("spread 2", spread_out), ("big", big), ("spread again", spread_out), ("one tile", one_tile), ("big again", big), ("big 3", big))
+    hooks.set("fwd_mode", "seq")
+    res = {}
+    for fold in (0, 1):
+        hooks.set("scan_fold", fold)
+        dummy = _cluster_scene(N, 0.5, 0.1, False, seed=9)           # (both passes start from the same prediction state)
+        run_hip(dummy, S, gpu, w)
+        res[fold] = [run_hip(sc, S, gpu, w) for _, sc in frames]
+    for (name, sc), a, b in zip(frames, res[0], res[1]):
+        for i in range(4):
+            assert torch.equal(a[0][i], b[0][i]), (name, i)
+        assert a[2]["M"] == b[2]["M"] and a[2]["max_tile"] == b[2]["max_tile"] and a[2]["V"] == b[2]["V"] and a[2]["M_ref"] == b[2]["M_ref"], name
+        floors = grad_floors(sc, a[1])
+        for k_ in a[1]:
+            scale = max(a[1][k_].abs().max().item(), floors.get(k_, 0.0)) + 1e-30
+            assert (a[1][k_] - b[1][k_]).abs().max().item() <= 2e-5 * scale, (name, k_)
+    # the last frame against the oracle as well
+    oo, og, aux = run_oracle(big, S, w, torch.float64)
+    assert_forward_close(res[1][-1][0], oo, aux)
+    # several views in one chain
+    sc = {k: v.to(gpu) for k, v in O.make_scene(9000, 1, 3, "trained").items()}
+    vs = [settings_to(O.make_settings(O.orbit_pose(5.0 * i, 70.0 * i, 2.0), 80, 64, sh_degree=1), gpu) for i in range(3)]
+    outs = {}
+    for fold in (0, 1):
+        hooks.set("scan_fold", fold)
+        for rep in range(2):                                            # the second call is the speculative one
+            m2 = torch.zeros(3, 9000, 3, device=gpu)
+            outs[fold] = D.rasterize_views(sc["means3D"], m2, sc["opacities"], vs, shs=sc["shs"], scales=sc["scales"], rotations=sc["rotations"])
+    for i in range(4):
+        assert torch.equal(outs[0][i], outs[1][i]), ("views", i)
+
+
 def _render_bits(sc, S, gpu, w):
     ho, hg, st = run_hip(sc, S, gpu, w)
     return ho, hg, st
