@@ -33,7 +33,9 @@ def test_hot_kernels_have_no_loads_waited_for_on_the_spot(asm):
         "_Z21gsr_render_fwd_serialILb1E": 1,      # the work-list reservation (returning atomic) at the end
         "_Z21gsr_render_fwd_serialILb0E": 1,
         "_Z17gsr_render_bwd_q2": 4,               # later rounds of segments longer than 64 entries: list entry -> records
-        "gsr_scatter": 11,                        # the segment forward's work items (rare path), the tail of the eight-deep fetch of the ranges, the refill of a pinned grid's later rounds
+        "gsr_scatter": 32,                        # the segment forward's work items (rare path), the tail of the eight-deep fetch of the ranges, the refill of a pinned grid's later rounds: 11;
+                                                  # + round 5: K2's body inlined for the launch's ONE scan workgroup (a chain of dependent phases by nature: 17) and the
+                                                  # scatter workgroups' own scan of the tile counts (the counts of the other views, the tail of the fetch: 2)
         "_Z18gsr_preprocess_fwdILb0E": 10,        # camera staging, cov3D_precomp / colors_precomp / degree-0 paths, the two polls of the "counters cleared" tag,
         "_Z18gsr_preprocess_fwdILb1E": 10,        # the last of the flush's four reserving atomics (their results are what is stored)
         "_Z18gsr_preprocess_bwdILb0ELb0E": 14,    # camera staging, the accumulate read-modify-write of views after the first, the
