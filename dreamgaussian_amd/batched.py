@@ -28,7 +28,7 @@ class _RasterizeViews(torch.autograd.Function):
     """Up to GSR_MAX_VIEWS cameras through gsr_forward_views / gsr_backward_views."""
 
     @staticmethod
-    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings):
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings, grad_mode=True):
         _require_gpu(means3D)
         lib = _lib.load()
         dev = means3D.device
@@ -55,7 +55,7 @@ class _RasterizeViews(torch.autograd.Function):
         views = (_lib.GsrView * B)()
         keeps = []
         for v in range(B):
-            views[v], keep = _view_struct(settings[v], dev, no_backward=not any(ctx.needs_input_grad))
+            views[v], keep = _view_struct(settings[v], dev, no_backward=not (grad_mode and any(ctx.needs_input_grad)))   # (grad_mode: rasterizer.py)
             keeps.append(keep)
         geom, binb, img, st = _lib.Scratch(dev), _lib.Scratch(dev), _lib.Scratch(dev), _lib.GsrStats()
         P = _lib.ptr
@@ -115,7 +115,7 @@ class _RasterizeViews(torch.autograd.Function):
         sh_ = ctx.shapes
         r = lambda g, shape: None if g is None or shape is None else g.reshape(shape)
         return (r(d_m3, sh_[0]), d_m2, r(d_sh, sh_[1]), r(d_col, sh_[2]), r(d_op, sh_[3]),
-                r(d_sc, sh_[4]), r(d_rot, sh_[5]), r(d_cov, sh_[6]), None)
+                r(d_sc, sh_[4]), r(d_rot, sh_[5]), r(d_cov, sh_[6]), None, None)
 
 
 def rasterize_views(means3D, means2D, opacities, raster_settings: Sequence[GaussianRasterizationSettings],
@@ -130,10 +130,10 @@ def rasterize_views(means3D, means2D, opacities, raster_settings: Sequence[Gauss
     settings = tuple(raster_settings)
     if len(settings) <= _lib.GSR_MAX_VIEWS:
         return _RasterizeViews.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                     cov3D_precomp, settings)
+                                     cov3D_precomp, settings, torch.is_grad_enabled())
     parts = []
     for i0 in range(0, len(settings), _lib.GSR_MAX_VIEWS):
         sl = slice(i0, i0 + _lib.GSR_MAX_VIEWS)
         parts.append(_RasterizeViews.apply(means3D, means2D[sl], shs, colors_precomp, opacities, scales, rotations,
-                                           cov3D_precomp, settings[sl]))
+                                           cov3D_precomp, settings[sl], torch.is_grad_enabled()))
     return tuple(torch.cat([p[i] for p in parts], 0) for i in range(4))

@@ -125,6 +125,12 @@ int k1_grid_for(int N) {
     return (batches + rounds - 1) / rounds;
 }
 
+// Largest tile grid whose per-tile counters a workgroup of K1 / the scatter keeps in LDS (64 KiB)
+static int hist_lds_max_tiles() {
+    const int t = ov(OV_HIST_MAX);
+    return t < 0 ? 16384 : (t > 16384 ? 16384 : t);
+}
+
 struct GeomLayout {
     size_t recs, emit, flags8, block_stats, tile_count, cursor, counters, tile_off, tile_seg, order, order_span, level_off, sat, plan_off, g2d, wg_base, total;
     int nTiles;        // per view
@@ -154,17 +160,18 @@ GeomLayout geom_layout(int N, int H, int W, int B = 1) {
     L.level_off = o; o += align_up((GSR_NLEV + 1) * 4);
     L.sat = o; o += align_up(BT * 4 * 8);                         // hint word per (tile, wave) of the segment forward
     L.plan_off = o; o += align_up(BT * 4);
-    // the backward's screen-space gradient accumulators [B][N][12] f32: cleared by the FORWARD (forward_impl) so that the backward
-    // starts on its first kernel
-    L.g2d = o; o += align_up(BN * GSR_G2D_STRIDE * 4 + (size_t)B * GSR_LIVE_BYTES(N));   // ... and, right behind them, the [B][N] byte flags "this Gaussian received a gradient"
     // where each of K1's workgroups starts inside every tile's list ([view][workgroup][tile] u32, written by K1's histogram flush,
-    // read by the scatter): last, so that nothing else moves with K1's grid
-    L.wg_base = o; o += align_up((size_t)B * (size_t)k1_grid_for(N) * (size_t)L.nTiles * 4);
+    // read by the scatter) -- only with the tile counters in LDS: larger tile grids use global cursors and never touch it
+    L.wg_base = o; o += L.nTiles <= hist_lds_max_tiles() ? align_up((size_t)B * (size_t)k1_grid_for(N) * (size_t)L.nTiles * 4) : 0;
+    // LAST: the backward's screen-space gradient accumulators [B][N][12] f32 and, right behind them, the [B][N] byte flags "this Gaussian
+    // received a gradient": cleared by the FORWARD (forward_impl) so that the backward starts on its first kernel. A forward that
+    // no backward can follow (GSR_VIEW_NO_BACKWARD) allocates the block up to here only (`L.g2d` bytes).
+    L.g2d = o; o += align_up(BN * GSR_G2D_STRIDE * 4 + (size_t)B * GSR_LIVE_BYTES(N));
     L.total = o;
     return L;
 }
 struct BinLayout { size_t entries, ids, ckpt, plan_tile, plan_cap, items, item_recs, walk_items, total; };
-BinLayout bin_layout(size_t M, int nTiles, int shift) {
+BinLayout bin_layout(size_t M, int nTiles, int shift, bool records = true /* false: a serial-walk forward no backward follows keeps no segment records */) {
     BinLayout L;
     size_t o = 0;
     // first: the sorted lists (4-byte Gaussian indices) -- the backward finds them at offset 0
@@ -173,7 +180,7 @@ BinLayout bin_layout(size_t M, int nTiles, int shift) {
     L.entries = o; o += align_up(M * 8);
     // (tile, segment) items of the forward = segment records: sum over tiles of ceil(n_t >> shift) <= (M >> shift) + nTiles
     L.items = (M >> shift) + (size_t)nTiles;
-    L.ckpt = o; o += align_up((L.items + 3) * (size_t)GSR_CKPT_FLOATS * 4);   // + 3 spare records: the store sink of the serial walk (gsr_render.hip)
+    L.ckpt = o; o += align_up(((records ? L.items : 0) + 3) * (size_t)GSR_CKPT_FLOATS * 4);   // + 3 spare records: the store sink of the serial walk (gsr_render.hip)
     // backward work list: sum over tiles of ceil(last_t / 2^shift) <= the same bound
     L.plan_cap = L.items + 1;
     L.plan_tile = o; o += align_up(L.plan_cap * 16);      // 16-byte work items of the backward: (tile, the segment's record, list start, segment | (entries - 1) << 24)
@@ -241,12 +248,6 @@ int check_inputs(int N, int K, const GsrView* v, const float* means3D, const flo
     if (shs && K < (v->sh_degree + 1) * (v->sh_degree + 1)) return fail(-1, "shs has fewer coefficients than sh_degree needs%s", "");
     if (v->shs_rest && (!shs || K < 2)) return fail(-1, "split SH input (GsrView.shs_rest) needs shs = features_dc and K >= 2%s", "");
     return 0;
-}
-
-// Largest tile grid whose per-tile counters a workgroup of K1 / the scatter keeps in LDS (64 KiB)
-static int hist_lds_max_tiles() {
-    const int t = ov(OV_HIST_MAX);
-    return t < 0 ? 16384 : (t > 16384 ? 16384 : t);
 }
 
 // How the forward composites. Depth-segmented (K5a + K5b + K5c) where a view has few tiles: there the serial walk of a
@@ -450,15 +451,20 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
     if (M >= 0xfffffff0ull) return fail(-5, "too many tile instances (%s%lld)", "", (long long)M);
     const uint32_t maxc_cap = maxc >= 0xffffffffull ? 0xffffffffu : (uint32_t)maxc;
 
-    const BinLayout BL = bin_layout((size_t)M, TA, shift);
+    const bool sequential = fwd_sequential_for(N, T);
+    // GSR_VIEW_NO_BACKWARD + the serial walk: no checkpoints, no quad masks, no records in the scratch (the segmented mode composites
+    // THROUGH its records and keeps them)
+    const bool keep_state = prepare_bwd || !sequential;
+    const BinLayout BL = bin_layout((size_t)M, TA, shift, keep_state);
     if (BL.items >= 0x7fffffffull) return fail(-5, "too many depth segments (%s%lld)", "", (long long)BL.items);
+    const unsigned long long no_state_bit = keep_state ? 0ull : (1ull << 63);
+    const uint32_t sink_rec = keep_state ? (uint32_t)BL.items : 0u;     // the first of the three spare records: the serial walk's store sink
     char* bbuf = (char*)bin.resize(bin.ctx, BL.total);
     if (!bbuf) return fail(-4, "bin scratch allocation failed%s", "");
     unsigned long long* entries = (unsigned long long*)(bbuf + BL.entries);
     uint32_t* sorted_ids = (uint32_t*)(bbuf + BL.ids);
     float* ckpt = (float*)(bbuf + BL.ckpt);
 
-    const bool sequential = fwd_sequential_for(N, T);
     if (M > 0) {
         const size_t lds = hist_in_lds ? (size_t)T * 4 : 0;
         if (lds > 48 * 1024)
@@ -555,14 +561,14 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
             vs.view_mask = mask_q;
             hipLaunchKernelGGL(gsr_render_fwd_pair, dim3(TA), dim3(512), 0, stream, tile_off, recs, sorted_ids, W, H, vc.gx,
                                out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, order, shift,
-                               plan_off, plan_tile, counters + 4, (uint32_t)BL.plan_cap, (unsigned long long)mask_q, (uint32_t)BL.items,
+                               plan_off, plan_tile, counters + 4, (uint32_t)BL.plan_cap, (unsigned long long)mask_q | no_state_bit, sink_rec,
                                counters, (uint32_t)M, maxc_cap, vs, zero4, zero_n, zero_per);
             zero_n = 0u;
         } else if (mask_q) {
             vs.view_mask = mask_q;
             hipLaunchKernelGGL(gsr_render_fwd_serial<true>, dim3(TA), dim3(256), fwd_lds, stream, tile_off, recs, sorted_ids, W, H, vc.gx,
                                out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, order, shift,
-                               plan_off, plan_tile, counters + 4, (uint32_t)BL.plan_cap, (unsigned long long)mask_q, (uint32_t)BL.items /* the first of the three spare records: store sink */,
+                               plan_off, plan_tile, counters + 4, (uint32_t)BL.plan_cap, (unsigned long long)mask_q | no_state_bit, sink_rec,
                                counters, (uint32_t)M, maxc_cap, vs, zero4, zero_n, zero_per);
             zero_n = 0u;
         }
@@ -570,7 +576,7 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
             vs.view_mask = mask_all & ~mask_q;
             hipLaunchKernelGGL(gsr_render_fwd_serial<false>, dim3(TA), dim3(256), fwd_lds, stream, tile_off, recs, sorted_ids, W, H, vc.gx,
                                out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, order, shift,
-                               plan_off, plan_tile, counters + 4, (uint32_t)BL.plan_cap, (unsigned long long)mask_q, (uint32_t)BL.items /* the first of the three spare records: store sink */,
+                               plan_off, plan_tile, counters + 4, (uint32_t)BL.plan_cap, (unsigned long long)mask_q | no_state_bit, sink_rec,
                                counters, (uint32_t)M, maxc_cap, vs, zero4, zero_n, zero_per);
         }
         LAUNCH_CHECK(view, stream, "render_fwd");
@@ -649,14 +655,14 @@ int forward_impl(const GsrView* views, int B, int32_t N, int32_t K,
     const ViewConst vcs = make_view(view);
     const GeomLayout GLs = geom_layout(N, vcs.H, vcs.W, B);
     const int shift = seg_shift_for(N, GLs.nTiles);
-    char* gbuf = (char*)geom.resize(geom.ctx, GLs.total);
-    char* ibuf = (char*)img.resize(img.ctx, gsr_img_bytes(vcs.H, vcs.W) * (size_t)B);
-    if (!gbuf || !ibuf) return fail(-4, "scratch allocation failed%s", "");
     // The backward accumulates its screen-space gradients with atomics into [B][N][12] floats that must start from zero -- 48 MB at
     // 1M Gaussians, a 10 us fill in front of gsr_render_bwd_q2 in round 3. The forward's compositing leaves HBM idle: every workgroup
     // of its per-tile kernel (gsr_render_fwd_serial / gsr_render_fwd_combine) clears a slice of them behind its own work. (A fill on
     // a second stream was measured first: the two cross-stream waits cost 15 us of bubbles, more than the fill.)
     const bool prepare = N > 0 && !(view->flags & GSR_VIEW_NO_BACKWARD);
+    char* gbuf = (char*)geom.resize(geom.ctx, prepare ? GLs.total : GLs.g2d);      // (no backward: no accumulators at the end of the block)
+    char* ibuf = (char*)img.resize(img.ctx, gsr_img_bytes(vcs.H, vcs.W) * (size_t)B);
+    if (!gbuf || !ibuf) return fail(-4, "scratch allocation failed%s", "");
     const bool spec = ov(OV_SPECULATE) != 0 && g_hint.valid && g_hint.N == N && g_hint.H == vcs.H && g_hint.W == vcs.W && g_hint.B == B && N > 0;
     // K2 (scan of the tile counts, statistics, tile order, the counters for the host) inside the scatter's launch: when the forward is
     // enqueued in one go (speculation), the tile counters sit in LDS (no global cursors) and the compositing takes its tiles from
@@ -694,6 +700,11 @@ int forward_impl(const GsrView* views, int B, int32_t N, int32_t K,
     if (int rcw = wait_counters(g_pinned, stream)) return rcw;    // also on a failed tail: nothing may stay pending on the pinned block
     if (rc) return rc;
     const unsigned long long M_ref = g_pinned[0], V = g_pinned[1], M = g_pinned[2], maxc = g_pinned[3];
+    if (M_ref >= (1ull << 62)) {                          // a workgroup of K1 gave up waiting for the cleared tile counters (gsr_preprocess.hip)
+        (void)hipStreamSynchronize(stream);
+        g_hint.valid = false;
+        return fail(-2, "the per-Gaussian kernel never saw the tile counters cleared (device error)%s", "");
+    }
     if (spec && (M > cap || sort_class(maxc) > sort_class(capc))) {
         // misprediction: the kernels above left without writing; clear what the scatter accumulates into
         HIP_TRY(hipMemsetAsync(gbuf + GLs.cursor, 0, GLs.counters - GLs.cursor, stream));
@@ -705,7 +716,7 @@ int forward_impl(const GsrView* views, int B, int32_t N, int32_t K,
     }
     if (stats) { stats->num_instances = (int64_t)M; stats->num_instances_ref = (int64_t)M_ref; stats->num_visible = (int64_t)V;
                  stats->max_tile_count = (int64_t)maxc; stats->bin_capacity = (int64_t)cap; stats->seg_shift = shift;
-                 stats->bwd_prepared = (prepare && rc == 0) ? 1 : 0; }
+                 stats->bwd_prepared = (prepare && rc == 0) ? 1 : (prepare ? 0 : -1); }
     if (rc == 0) {
         g_hint.valid = true; g_hint.N = N; g_hint.H = vcs.H; g_hint.W = vcs.W; g_hint.B = B; g_hint.M = M; g_hint.maxc = maxc;
         for (int v = 0; v < 2 * B; ++v) g_hint.per_view[v] = g_pinned[8 + v];
@@ -752,13 +763,15 @@ int backward_impl(const GsrView* views, int B, int32_t N, int32_t K,
     unsigned long long M = 0;
     int shift = 6;
     if (fwd_stats) {
+        if (fwd_stats->bwd_prepared < 0) return fail(-1, "the forward ran with GSR_VIEW_NO_BACKWARD: it left no state for gsr_backward%s", "");
         M = (unsigned long long)(fwd_stats->num_instances > 0 ? fwd_stats->bin_capacity : 0);
         shift = (int)fwd_stats->seg_shift;
         if (shift < 6 || shift > 8) return fail(-1, "fwd_stats is not the GsrStats of a gsr_forward of this library version%s", "");
     } else {
-        unsigned long long h[8];
+        unsigned long long h[kCounterSlots];
         HIP_TRY(hipMemcpyAsync(h, counters, sizeof(h), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
+        if (h[2] > 0 && (h[GSR_CNT_QMASK] >> 63)) return fail(-1, "the forward ran with GSR_VIEW_NO_BACKWARD: it left no state for gsr_backward%s", "");
         M = h[2] > 0 ? h[6] : 0;
         shift = (int)(h[7] >> 32);
         if (shift < 6 || shift > 8) return fail(-1, "geom does not hold the state of a forward%s", "");

@@ -276,24 +276,32 @@ gsr_preprocess_fwd(ViewTab views /* camera of this workgroup: views.v[blockIdx.y
     // before its first atomic on a tile count (~80 us later at 1M Gaussians): the hipMemsetAsync in front of K1 (a launch of its
     // own, 6 us on the driver's box) is gone. Stale memory never holds this launch's tag (a process-wide counter).
     unsigned long long* const zflag = reinterpret_cast<unsigned long long*>(zero_base + flag_word);
+    __shared__ uint32_t zfail_s;
     if (blockIdx.x == 0 && blockIdx.y == 0) {
         for (uint32_t i = threadIdx.x; i < zero_words; i += blockDim.x)
             if ((i & ~1u) != flag_word) zero_base[i] = 0u;
+        // EVERY zeroing thread makes its own stores visible at agent scope before the barrier (the barrier alone does not wait for
+        // another wave's stores to reach L2): only then may the tag follow them
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(zflag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (threadIdx.x == 0) __hip_atomic_store(zflag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
-    auto wait_zeroed = [&]() {                            // (block-uniform call sites)
+    // false: the tag never arrived (2^22 polls, seconds) -- the caller must not touch the counters; the workgroup reports it through
+    // its M_ref statistic (>= 2^62: gsr_forward returns an error instead of results built on memory that may not be cleared)
+    auto wait_zeroed = [&]() -> bool {                    // (block-uniform call sites)
         if (threadIdx.x == 0) {
+            int spin = 0;
 #pragma unroll 1
-            for (int spin = 0; spin < (1 << 22) && __hip_atomic_load(zflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch; ++spin)
+            for (; spin < (1 << 22) && __hip_atomic_load(zflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch; ++spin)
                 __builtin_amdgcn_s_sleep(8);
+            zfail_s = spin >= (1 << 22) ? 1u : 0u;
         }
         __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the zeros behind the tag
+        return zfail_s == 0u;
     };
+    bool zeroed_ok = true;
     const int nTiles = vc.gx * vc.gy;
     // 256 bytes behind the statistics that nobody reads: where the lanes past the end of the array store (below)
     char* const sink = reinterpret_cast<char*>(block_stats) + (size_t)gridDim.y * 2048 * 3 * 8;
@@ -310,7 +318,11 @@ gsr_preprocess_fwd(ViewTab views /* camera of this workgroup: views.v[blockIdx.y
 
     if (hist_in_lds) {
         for (int t = threadIdx.x; t < nTiles; t += blockDim.x) hist[t] = 0;
-    } else wait_zeroed();                                 // tile grids beyond the LDS histogram: every emission is a global atomic
+    } else zeroed_ok = wait_zeroed();                     // tile grids beyond the LDS histogram: every emission is a global atomic
+    if (!zeroed_ok) {                                     // (block-uniform)
+        if (threadIdx.x == 0) { block_stats[3 * blockIdx.x] = 1ull << 62; block_stats[3 * blockIdx.x + 1] = 0; block_stats[3 * blockIdx.x + 2] = 0; }
+        return;
+    }
     // The camera sits in LDS: read through its device pointers it comes back as VECTOR-memory loads (the compiler cannot
     // prove the memory read-only), and waiting for one of those at the top of a batch also waits for the previous batch's
     // stores (one in-order counter for a wave's loads and stores).
@@ -607,7 +619,10 @@ gsr_preprocess_fwd(ViewTab views /* camera of this workgroup: views.v[blockIdx.y
         block_stats[3 * blockIdx.x + threadIdx.x] = sum;
     }
     if (hist_in_lds) {
-        wait_zeroed();
+        if (!wait_zeroed()) {
+            if (threadIdx.x == 0) block_stats[3 * blockIdx.x] = 1ull << 62;
+            return;
+        }
         // every workgroup starts its flush at a different tile: no burst of atomics on one address
         // The flush RESERVES: the value the atomic returns is the number of entries other workgroups have claimed in that tile's list so
         // far = where this workgroup's entries start. It goes to wg_base; gsr_scatter, on the same grid with the same Gaussians, hands

@@ -354,6 +354,9 @@ gsr_render_fwd_serial(const uint32_t* __restrict__ tile_off, const SplatRec* __r
     __shared__ __attribute__((aligned(8))) uint8_t qlist[QUAD ? 4 : 1][4][80];
     __shared__ uint32_t wl[4];
     __shared__ uint32_t plan_base;
+    // bit 63 of qmask_views: no backward follows this forward (GSR_VIEW_NO_BACKWARD) -- no checkpoints, no quad masks (118 MB of
+    // stores at 1M Gaussians), and gsr_backward refuses the state
+    const bool keep_state = (qmask_views >> 63) == 0ull;
     if (blockIdx.x == 0 && threadIdx.x == 0) plan_total[GSR_CNT_QMASK - GSR_CNT_PLAN] = qmask_views;   // the views whose records carry quad masks
     const int tg = (int)order[blockIdx.x];                // heaviest tiles first
     const int view = tg / vs.tiles_per_view;
@@ -379,7 +382,7 @@ gsr_render_fwd_serial(const uint32_t* __restrict__ tile_off, const SplatRec* __r
     const uint32_t start = tile_off[tg];
     const uint32_t tile_n = tile_off[tg + 1] - start;
     const uint32_t n = (bx < W && by < H) ? tile_n : 0u;   // a block outside the image walks nothing
-    float* __restrict__ recw = rec_base + (size_t)tile_seg[tg] * GSR_CKPT_FLOATS;     // (wave-uniform) the tile's first segment record
+    float* __restrict__ recw = rec_base + (size_t)(keep_state ? tile_seg[tg] : 0u) * GSR_CKPT_FLOATS;     // (wave-uniform) the tile's first segment record
     float* __restrict__ rec0 = recw + (wave * 64 + ly * 8 + lx);
     float4* __restrict__ sa = stage[wave][0];
     float4* __restrict__ sb = stage[wave][1];
@@ -425,7 +428,7 @@ gsr_render_fwd_serial(const uint32_t* __restrict__ tile_off, const SplatRec* __r
                 idq = ids[start + min(rel + 3u * GSR_RB + (uint32_t)lane, n - 1u)];
             }
             {   // segment cut: checkpoint for the backward
-                const bool cut = rel != 0u && (rel & ((1u << seg_shift) - 1u)) == 0u;
+                const bool cut = keep_state && rel != 0u && (rel & ((1u << seg_shift) - 1u)) == 0u;
                 float* c = (cut && inside) ? rec0 + (size_t)((rel >> seg_shift) - 1u) * GSR_CKPT_FLOATS : sinkf;
                 c[0] = T; c[256] = C0; c[512] = C1; c[768] = C2; c[1024] = D; c[1280] = A;
             }
@@ -468,7 +471,7 @@ gsr_render_fwd_serial(const uint32_t* __restrict__ tile_off, const SplatRec* __r
                 {   // the round's four hit masks: the backward's quad tests (GSR_CNT_QMASK). Lanes 0..3 store one each, the others into the sink
                     unsigned long long* mp = reinterpret_cast<unsigned long long*>(recw + (size_t)(rel >> seg_shift) * GSR_CKPT_FLOATS + GSR_REC_HINT)
                                              + (((rel >> 6) & ((1u << (seg_shift - 6)) - 1u)) * 16u + (uint32_t)wave * 4u);
-                    *(lane < 4 ? mp + lane : sink64) = lane == 0 ? m0 : (lane == 1 ? m1 : (lane == 2 ? m2 : m3));
+                    *((lane < 4 && keep_state) ? mp + lane : sink64) = lane == 0 ? m0 : (lane == 1 ? m1 : (lane == 2 ? m2 : m3));
                 }
                 if ((m0 | m1 | m2 | m3) != 0ull) {
                     uint8_t (*qlw)[80] = qlist[QUAD ? wave : 0];
@@ -611,6 +614,7 @@ gsr_render_fwd_pair(const uint32_t* __restrict__ tile_off, const SplatRec* __res
     __shared__ unsigned long long alive_pub[4];
     __shared__ uint32_t wl[4];
     __shared__ uint32_t plan_base;
+    const bool keep_state = (qmask_views >> 63) == 0ull;  // (as in gsr_render_fwd_serial)
     if (blockIdx.x == 0 && threadIdx.x == 0) plan_total[GSR_CNT_QMASK - GSR_CNT_PLAN] = qmask_views;
     const int tg = (int)order[blockIdx.x];                // heaviest tiles first
     const int view = tg / vs.tiles_per_view;
@@ -638,7 +642,7 @@ gsr_render_fwd_pair(const uint32_t* __restrict__ tile_off, const SplatRec* __res
     const uint32_t start = tile_off[tg];
     const uint32_t tile_n = tile_off[tg + 1] - start;
     const uint32_t n = (bx < W && by < H) ? tile_n : 0u;   // a block outside the image walks nothing
-    float* __restrict__ recw = rec_base + (size_t)tile_seg[tg] * GSR_CKPT_FLOATS;
+    float* __restrict__ recw = rec_base + (size_t)(keep_state ? tile_seg[tg] : 0u) * GSR_CKPT_FLOATS;
     float* __restrict__ rec0 = recw + (blk * 64 + ly * 8 + lx);
     for (int q = threadIdx.x; q < 4 * 2 * 3 * (GSR_RB + 2); q += 512) (&stage[0][0][0][0])[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int q = threadIdx.x; q < 4 * 2 * 4 * 80 / 4; q += 512) reinterpret_cast<uint32_t*>(&qlist[0][0][0][0])[q] = 0u;
@@ -699,7 +703,7 @@ gsr_render_fwd_pair(const uint32_t* __restrict__ tile_off, const SplatRec* __res
             {   // the round's four hit masks for the backward (GSR_CNT_QMASK), as gsr_render_fwd_serial<true> leaves them
                 unsigned long long* mp = reinterpret_cast<unsigned long long*>(recw + (size_t)(rel >> seg_shift) * GSR_CKPT_FLOATS + GSR_REC_HINT)
                                          + (((rel >> 6) & ((1u << (seg_shift - 6)) - 1u)) * 16u + (uint32_t)blk * 4u);
-                *(lane < 4 ? mp + lane : sink64) = lane == 0 ? m0 : (lane == 1 ? m1 : (lane == 2 ? m2 : m3));
+                *((lane < 4 && keep_state) ? mp + lane : sink64) = lane == 0 ? m0 : (lane == 1 ? m1 : (lane == 2 ? m2 : m3));
             }
             // the buffer is free once the blender has left round r - 2
             if (r >= 2u) { if (!wait_free(&freed[blk][buf], r - 1u)) return false; }
@@ -749,7 +753,7 @@ gsr_render_fwd_pair(const uint32_t* __restrict__ tile_off, const SplatRec* __res
                 break;
             }
             {   // segment cut: checkpoint for the backward
-                const bool cut = rel != 0u && (rel & ((1u << seg_shift) - 1u)) == 0u;
+                const bool cut = keep_state && rel != 0u && (rel & ((1u << seg_shift) - 1u)) == 0u;
                 float* c = (cut && inside) ? rec0 + (size_t)((rel >> seg_shift) - 1u) * GSR_CKPT_FLOATS : sinkf;
                 c[0] = T; c[256] = C0; c[512] = C1; c[768] = C2; c[1024] = D; c[1280] = A;
             }

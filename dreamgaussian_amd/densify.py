@@ -208,6 +208,7 @@ def quaternion_to_matrix(r: torch.Tensor) -> torch.Tensor:
     return R.reshape(-1, 3, 3)
 
 
+@torch.no_grad()
 def densify_and_split(gaussians, grads: torch.Tensor, grad_threshold: float, scene_extent: float, N: int = 2, build_rotation=None) -> None:
     """`GaussianModel.densify_and_split` (gs_renderer.py:554-580): selection and the random offsets as the reference computes
     them (same torch calls, same RNG stream), the rows through one compaction + one gather, then the one-launch postfix and

@@ -106,7 +106,7 @@ def carve_gradients(N: int, widths, device):
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                cov3Ds_precomp, raster_settings, raw=False, sh_rest=None):
+                cov3Ds_precomp, raster_settings, raw=False, sh_rest=None, grad_mode=True):
         _require_gpu(means3D)
         ctx.raw = bool(raw)
         lib = _lib.load()
@@ -139,8 +139,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         geom, binb, img = _lib.Scratch(dev), _lib.Scratch(dev), _lib.Scratch(dev)
         stats = _lib.GsrStats()
         with torch.cuda.device(dev):
-            # (inference -- torch.no_grad(), or no input that requires a gradient: the backward's accumulators are not prepared)
-            view, keep = _view_struct(rs, dev, ctx.raw, no_backward=not any(ctx.needs_input_grad))
+            # inference -- torch.no_grad() around the call (`grad_mode`, taken by the wrappers below BEFORE .apply: inside forward() grad
+            # mode is always off, and needs_input_grad mirrors requires_grad whatever the mode), or no input that requires a gradient:
+            # the backward's accumulators are not prepared
+            view, keep = _view_struct(rs, dev, ctx.raw, no_backward=not (grad_mode and any(ctx.needs_input_grad)))
             if rest is not None:
                 view.shs_rest = rest.data_ptr()
                 keep.append(rest)
@@ -228,13 +230,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs_ = lambda g, shape: None if g is None or shape is None else g.reshape(shape)
         return (rs_(d_m3, s[0]), rs_(d_m2, s[1]) if tuple(s[1]) == (N, 3) else None, rs_(d_sh, s[2]),
                 rs_(d_col, s[3]), rs_(d_op, s[4]), rs_(d_sc, s[5]), rs_(d_rot, s[6]), rs_(d_cov, s[7]),
-                None, None, rs_(d_rest, ctx.rest_shape))
+                None, None, rs_(d_rest, ctx.rest_shape), None)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                         cov3Ds_precomp, raster_settings):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales,
-                                     rotations, cov3Ds_precomp, raster_settings)
+                                     rotations, cov3Ds_precomp, raster_settings, False, None, torch.is_grad_enabled())
 
 
 def rasterize_gaussians_raw(means3D, means2D, sh, opacity_raw, scaling_raw, rotation_raw, raster_settings):
@@ -244,7 +246,7 @@ def rasterize_gaussians_raw(means3D, means2D, sh, opacity_raw, scaling_raw, rota
     elementwise launches and their five backward launches per render disappear. Same outputs as
     `rasterize_gaussians(means3D, means2D, sh, None, sigmoid(o), exp(s), normalize(q), None, settings)`."""
     return _RasterizeGaussians.apply(means3D, means2D, sh, None, opacity_raw, scaling_raw, rotation_raw,
-                                     None, raster_settings, True)
+                                     None, raster_settings, True, None, torch.is_grad_enabled())
 
 
 def rasterize_gaussians_split(means3D, means2D, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw,
@@ -254,7 +256,7 @@ def rasterize_gaussians_split(means3D, means2D, features_dc, features_rest, opac
     `torch.cat` copy per render (gs_renderer.py:209-212), gradients written straight into two tensors of the same
     shapes. Same outputs as `rasterize_gaussians_raw(means3D, means2D, cat((features_dc, features_rest), 1), ...)`."""
     return _RasterizeGaussians.apply(means3D, means2D, features_dc, None, opacity_raw, scaling_raw, rotation_raw,
-                                     None, raster_settings, True, features_rest)
+                                     None, raster_settings, True, features_rest, torch.is_grad_enabled())
 
 
 class GaussianRasterizer(nn.Module):

@@ -74,7 +74,9 @@ typedef struct GsrView {
                                   * storage of the reference's `world_view_transform` holds -- a `.transpose(0, 1)` VIEW of the row-major
                                   * w2c (gs_renderer.py:662-664) -- so that binding needs no `.contiguous()` copy kernel per render */
 #define GSR_VIEW_PROJMATRIX_T 2  /* the same for projmatrix */
-#define GSR_VIEW_NO_BACKWARD 4   /* no gsr_backward will follow this forward (inference): the backward's accumulators are not prepared */
+#define GSR_VIEW_NO_BACKWARD 4   /* no gsr_backward will follow this forward (inference): the backward's accumulators are neither allocated nor
+                                  * cleared and the serial-walk forward keeps neither checkpoints nor quad masks (118 MB of stores and 0.4 GB of
+                                  * scratch at 1M Gaussians / 800^2). GsrStats.bwd_prepared = -1; gsr_backward on such a state returns -1 */
 
 /* Scratch allocator: resize(ctx, bytes) must return a device pointer, 256-byte aligned, to
  * at least `bytes` bytes that stay alive until the matching backward has run. */
@@ -97,7 +99,8 @@ typedef struct GsrStats {
     int64_t bwd_prepared;       /* 1: the forward has cleared the backward's per-Gaussian accumulators inside `geom` (every workgroup
                                  * of its per-tile compositing kernel stores a slice of zeros behind its own work) -- gsr_backward
                                  * then neither allocates `tmp` nor clears anything. One-shot: a caller that runs a SECOND backward from the same forward state must pass
-                                 * 0 (the first one has accumulated into them); 0 also without GsrStats or under NO_BACKWARD */
+                                 * 0 (the first one has accumulated into them); 0 also without GsrStats. -1: the forward ran with
+                                 * GSR_VIEW_NO_BACKWARD and left no state for a backward */
 } GsrStats;
 
 /* Bumped whenever a struct of this header changes size or meaning (GsrStats grew in 3 and 4, GsrView.reserved became flags in 4). A caller built against another

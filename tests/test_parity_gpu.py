@@ -408,6 +408,35 @@ def test_scan_folded_into_the_scatter_is_bit_identical(gpu, hooks):
         assert torch.equal(outs[0][i], outs[1][i]), ("views", i)
 
 
+def test_inference_forward_keeps_no_backward_state(gpu, hooks):
+    """Under torch.no_grad() (or with no input that requires a gradient) the forward runs with GSR_VIEW_NO_BACKWARD: the same
+    image bits as the differentiable call, without the backward's accumulators, checkpoints and quad masks -- in the serial walk,
+    the pair kernel and the segmented mode (which composites through its records and keeps them)."""
+    sc = O.make_scene(20_000, 2, 6, "trained")
+    t = {k: v.to(gpu).requires_grad_(True) for k, v in sc.items()}
+    for mode, size in (("seq", 320), ("pair", 320), ("seg", 160), (None, 512)):
+        hooks.set("fwd_mode", mode)
+        S = O.make_settings(O.orbit_pose(-8.0, 25.0, 2.0), size, size, sh_degree=2)
+        rast = D.GaussianRasterizer(raster_settings=settings_to(S, gpu))
+        args = dict(means3D=t["means3D"], means2D=torch.zeros(20_000, 3, device=gpu, requires_grad=True), shs=t["shs"],
+                    opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"])
+        for rep in range(2):                                          # (first call of a shape: not speculative; second: speculative)
+            ref = rast(**args)
+            torch.cuda.synchronize()
+            m0 = torch.cuda.memory_allocated()
+            with torch.no_grad():
+                out = rast(**args)
+            torch.cuda.synchronize()
+            assert not out[0].requires_grad and ref[0].requires_grad
+            for i in range(4):
+                assert torch.equal(out[i], ref[i]), (mode, rep, i)
+        # the differentiable call still works afterwards (the prediction state is shared between the two kinds of call)
+        torch.autograd.backward([ref[0], ref[2], ref[3]], [w.to(gpu) for w in weights_for(size, size)])
+        assert all(torch.isfinite(v.grad).all() for v in t.values())
+        for v in t.values():
+            v.grad = None
+
+
 def _render_bits(sc, S, gpu, w):
     ho, hg, st = run_hip(sc, S, gpu, w)
     return ho, hg, st

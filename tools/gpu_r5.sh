@@ -61,7 +61,7 @@ abquick)
 new)
   # the tests of this round's kernel changes, first (fail fast), then the parity subset
   echo "== pytest: round-5 tests"
-  timeout ${QUICK_TIMEOUT:-400} python -m pytest tests/test_parity_gpu.py -m gpu -q -x -p no:cacheprovider --tb=short -rf -k "${NEW_K:-pair or k6_compact or scan_folded or speculative}" > gpurun_out/pytest_new.log 2>&1
+  timeout ${QUICK_TIMEOUT:-400} python -m pytest tests/test_parity_gpu.py -m gpu -q -x -p no:cacheprovider --tb=short -rf -k "${NEW_K:-pair or k6_compact or scan_folded or speculative or inference}" > gpurun_out/pytest_new.log 2>&1
   grep -a "passed\|failed\|FAILED\|Error\|assert" gpurun_out/pytest_new.log | cut -c1-300 | tail -12;;
 quick)
   # the parity subset a variant library must pass before it is adopted (GSR_LIB=... in the environment of the call)
