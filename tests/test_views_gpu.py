@@ -13,9 +13,11 @@ pytestmark = pytest.mark.gpu
 # the last case is BASELINE.json configs[3] at full size: 250k Gaussians, SH degree 0, 512x512, 8 orbit cameras (8 x 1024 tiles,
 # lists of several thousand entries: every sort class below the HBM fallback, both forward kernels chosen per view)
 @pytest.mark.parametrize("deg,N,size,nviews,kind", [(0, 3000, 128, 5, "trained"), (3, 1500, 96, 5, "trained"), (1, 800, 80, 19, "trained"),
-                                                     (0, 250_000, 512, 8, "blob")],
-                         ids=["sh0_3000_128_5v", "sh3_1500_96_5v", "sh1_800_80_19v", "cfg3_250k_512_8v"])
+                                                     (0, 250_000, 512, 8, "blob"), (3, 100_000, 800, 8, "trained")],
+                         ids=["sh0_3000_128_5v", "sh3_1500_96_5v", "sh1_800_80_19v", "cfg3_250k_512_8v", "cfg1x8_100k_sh3_800_8v"])
 def test_batched_views_equal_serial(gpu, deg, N, size, nviews, kind):
+    """(the last case, round 5: SH degree 3 x 8 views at 100k Gaussians / 800^2 -- the size the one-launch K6 with staged SH rows and a
+    second LDS row per Gaussian exists for; its view 0 is also held to the fp64 oracle)"""
     sc = O.make_scene(N, deg, 0, kind)
     azs = [0.0, 70.0, 160.0, -95.0, 33.0] + [20.0 * i + 5 for i in range(nviews - 5)]   # 19 views: two chunks of the chain
     if N >= 100_000:                                       # configs[3]: the orbit of main.py:219-255, radius 2
@@ -64,6 +66,13 @@ def test_batched_views_equal_serial(gpu, deg, N, size, nviews, kind):
     for i in range(B):
         scale = m2[i].grad.abs().max().item() + 1e-12
         assert (m2b.grad[i] - m2[i].grad).abs().max().item() <= 2e-5 * scale
+    if deg == 3 and N >= 100_000:
+        # view 0 of the chain against the fp64 oracle: images, radii, and the one gradient that is per view (means2D)
+        import util
+        S0 = O.make_settings(O.orbit_pose(0.0, 0.0, 2.0), size, size, sh_degree=deg)
+        oo, og, aux = util.run_oracle(sc, S0, [x.cpu() for x in w[0]], torch.float64)
+        util.assert_forward_close([color[0].detach().cpu(), radii[0].cpu(), depth[0].detach().cpu(), alpha[0].detach().cpu()], oo, aux)
+        util.assert_grads_close({"means2D": m2b.grad[0].cpu()}, {"means2D": og["means2D"]}, aux, row_rel_p999=util.ROW_REL_P999_FULL)
 
 
 def test_views_chain_precomputed_colours_and_covariances(gpu):
