@@ -160,6 +160,37 @@ def cpu_baseline(wl, kind, azimuth, budget_s=20.0, procs=None):
                         f"to {t_full:.1f} s"))
 
 
+def naive_gpu(wl, kind, azimuth, dev, reps=2):
+    """BASELINE.md section 3's "naive GPU" middle point: the SAME stock-PyTorch program that serves as the CPU baseline (the oracle:
+    torch ops per Gaussian, numpy binning on the host, a Python loop over the tiles with torch ops and torch's autograd), executed on
+    the MI355X with PyTorch-ROCm's own kernels. Whole frames, fwd+bwd, 1 warm-up + `reps` timed. A baseline, never a checker."""
+    from oracle import gs_oracle as O
+    from dreamgaussian_amd import synthetic as syn
+    O.ALLOW_DEVICE[0] = True
+    try:
+        sc = syn.make_scene(wl["N"], wl["deg"], 0, kind)
+        rs = syn.make_settings(syn.orbit_pose(0.0, azimuth, 2.0), wl["W"], wl["H"], sh_degree=wl["deg"])
+        S = O.Settings(*[x.to(dev) if torch.is_tensor(x) else x for x in rs])
+        g = torch.Generator().manual_seed(1)
+        H, W = wl["H"], wl["W"]
+        grads = [torch.rand(3, H, W, generator=g).to(dev), torch.rand(1, H, W, generator=g).to(dev), torch.rand(1, H, W, generator=g).to(dev)]
+        times = []
+        for it in range(1 + reps):
+            t = {k: v.to(dev).requires_grad_(True) for k, v in sc.items()}
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            c, r, d, a = O.rasterize(t["means3D"], None, t["opacities"], S, shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
+            torch.autograd.backward([c, d, a], grads)
+            torch.cuda.synchronize()
+            if it:
+                times.append(time.perf_counter() - t0)
+        dt = sorted(times)[len(times) // 2]
+        return dict(value=float(f"{H * W / dt / 1e6:.4g}"), unit="Mrays/s", ms_per_frame=round(dt * 1e3, 1), kind="torch oracle on the MI355X",
+                    sample=f"whole frames fwd+bwd, same scene/camera/loss, stock PyTorch-ROCm kernels + torch autograd, binning in numpy on the host; median of {reps}")
+    finally:
+        O.ALLOW_DEVICE[0] = False
+
+
 def spawn_ranks(n):
     """`--gpus n` without a launcher: run torch.distributed.run ourselves (one process per GPU, 127.0.0.1)."""
     import socket
@@ -193,7 +224,13 @@ def run_sds(a, dev, rank, world):
     wimg = torch.rand(world, 5, H, W, generator=torch.Generator().manual_seed(7)).to(dev) if rank == 0 else None
     params = list(t.values())
 
+    wmine = torch.rand(world, 5, H, W, generator=torch.Generator().manual_seed(7))[rank:rank + 1].to(dev)   # (the same weights, this rank's view)
+    pending = [None]
+
     def step():
+        if pending[0] is not None:                       # the previous step's all-reduce: its gradients are released right below
+            pending[0].wait()
+            pending[0] = None
         for v in params:
             v.grad = None
         m2d.grad = None
@@ -201,23 +238,34 @@ def run_sds(a, dev, rank, world):
                                           opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"],
                                           cov3D_precomp=None)
         local = torch.cat([color, depth, alpha], 0).unsqueeze(0)              # [1,5,H,W], differentiable
-        batch = views.gather_images(local.detach(), dst=0, num_views=world)
-        gw = (batch - 0.5) * wimg if rank == 0 else None                     # d(surrogate loss)/d(images) on rank 0
-        g_local = views.scatter_view_grads(gw, local, src=0, num_views=world)
-        torch.autograd.backward([local], [g_local])
-        views.allreduce_grads(params)
+        if a.sds_mode == "gather":
+            batch = views.gather_images(local.detach(), dst=0, num_views=world)
+            gw = (batch - 0.5) * wimg if rank == 0 else None                 # d(surrogate loss)/d(images) on rank 0
+            g_local = views.scatter_view_grads(gw, local, src=0, num_views=world)
+            torch.autograd.backward([local], [g_local])
+            views.allreduce_grads(params)
+        else:                                            # "local": the same loss, every rank differentiating its own view's term
+            torch.autograd.backward([local], [(local.detach() - 0.5) * wmine])
+            pending[0] = views.allreduce_grads(params, async_op=True)
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def drain():
+        if pending[0] is not None:
+            pending[0].wait()
+            pending[0] = None
+
     for _ in range(a.warmup):
         step()
+    drain()
     sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
+    drain()                                              # the last step's all-reduce belongs to the timed region
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -230,7 +278,9 @@ def run_sds(a, dev, rank, world):
     grad_bytes = sum(p.numel() * 4 for p in params)
     return {"workload": f"BASELINE.json configs[3]: {wl['N']} Gaussians, SH degree {wl['deg']}, {W}x{H}, one orbit view per "
                         f"GPU ({world} views), scene '{a.kind}'",
-            "timed": "fwd + RCCL gather(images) + loss grad on rank 0 + scatter(dL/dimage) + bwd + bucketed all-reduce(grads)",
+            "timed": ("fwd + RCCL gather(images) + loss grad on rank 0 + scatter(dL/dimage) + bwd + all-reduce(grads)" if a.sds_mode == "gather" else
+                      "fwd + loss grad of the own view on every rank + bwd + all-reduce(grads), asynchronous: waited for at the top of the next step"),
+            "sds_mode": a.sds_mode,
             "value": round(H * W * world * a.steps / dt / 1e6, 3), "unit": "Mrays/s", "ms_per_step": round(dt / a.steps * 1e3, 4),
             "views_per_step": world, "image_bytes_per_view": 5 * H * W * 4, "allreduce_bytes": grad_bytes,
             "M": st.get("M_ref"), "M_emitted": st.get("M")}
@@ -247,10 +297,17 @@ def main():
     ap.add_argument("--step", default="render", choices=["render", "sds"],
                     help="render = rasterizer fwd+bwd (+ RCCL gather of the images when N>1): the headline metric; "
                          "sds = the multi-view SDS exchange on BASELINE configs[3] (see the module docstring)")
+    ap.add_argument("--sds-mode", default="local", choices=["local", "gather"],
+                    help="--step sds: where the image-space loss is evaluated (dreamgaussian_amd/views.py): local = every rank differentiates its "
+                         "own view's term, the all-reduce of the parameter gradients is the only collective; gather = rank 0 evaluates it "
+                         "for all views (gather of the images, scatter of dL/dimage, all-reduce)")
     ap.add_argument("--order", default="given", choices=["given", "morton"],
                     help="given = the Gaussians in the order the scene generator made them (random in space: the reference's init and "
                          "the headline metric); morton = rows permuted along a Z-order curve first (dreamgaussian_amd.reorder_gaussians)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--naive-gpu", action="store_true",
+                    help="also time the torch oracle ON the MI355X (BASELINE.md section 3's \"naive GPU\" middle point; whole frames: "
+                         "sensible up to 100k Gaussians) and add it to the JSON line as `naive_gpu`")
     ap.add_argument("--force-collectives", action="store_true",
                     help="with --gpus 1: initialise a ONE-rank nccl group and run every collective of the step through RCCL "
                          "(views.force_collectives) instead of short-circuiting them")
@@ -308,7 +365,7 @@ def main():
                    "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": res["ms_per_step"],
                    "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                    "config": {"workload": res["workload"], "parallelism": f"view-parallel x{world}" if world > 1 else ("single GPU, collectives through a 1-rank RCCL group" if a.force_collectives else "single GPU"),
-                              "timed": res["timed"], "allreduce_bytes": res["allreduce_bytes"],
+                              "timed": res["timed"], "sds_mode": res["sds_mode"], "allreduce_bytes": res["allreduce_bytes"],
                               "image_bytes_per_view": res["image_bytes_per_view"], "M": res["M"], "M_emitted": res["M_emitted"]},
                    "roofline": None, "cpu_baseline": None}
             print(json.dumps(out), flush=True)
@@ -481,6 +538,12 @@ def main():
         cpu = cpu_baseline(wl, a.kind, azimuth, a.cpu_budget)
         cpu["value"] = float(f"{cpu['value']:.4g}")
 
+    naive = None
+    if rank == 0 and world == 1 and a.naive_gpu:
+        for v in list(t.values()) + [m2d]:
+            v.grad = None
+        naive = naive_gpu(wl, a.kind, azimuth, dev)
+
     if rank == 0:
         rays = wl["H"] * wl["W"] * world * a.steps * a.views
         out = {
@@ -502,6 +565,8 @@ def main():
         }
         if sds is not None:
             out["sds_step"] = sds
+        if naive is not None:
+            out["naive_gpu"] = naive
         print(json.dumps(out), flush=True)
     if views.gather_fallbacks:
         raise SystemExit(f"bench.py: the gather of the rendered views fell back to all_gather {views.gather_fallbacks} times "

@@ -101,12 +101,21 @@ def gather_rows(idx: torch.Tensor, tensors: Sequence[torch.Tensor]) -> List[torc
 
 
 @torch.no_grad()
-def prune_points(gaussians, mask: torch.Tensor) -> None:
+def prune_points(gaussians, mask: torch.Tensor, zorder: bool = False) -> None:
     """`GaussianModel.prune_points(mask)` (gs_renderer.py:496-511, with `_prune_optimizer` :479-494) on a reference
     GaussianModel instance: removes the rows where `mask` is True from the six parameters, their Adam moments and the
     three accumulators -- one mask compaction (one synchronisation) and one gather launch instead of 21 boolean-mask
-    indexings. Opt-in replacement; the reference's own method keeps working unchanged."""
+    indexings. Opt-in replacement; the reference's own method keeps working unchanged.
+
+    `zorder=True` (round 5): the surviving rows leave in the order of a 3-D Z-order curve through their positions instead of in
+    index order -- the gather moves every row of every tensor anyway, so the spatial order the binning kernels like (the scatter
+    writes a third of the bytes, `profiles/r04_bench_order.jsonl`) costs one sort of N keys per densification interval and no
+    pass of its own: `densify_and_prune` ends in this call (gs_renderer.py:597-609). The model is the same set of Gaussians, each
+    with its own moments and statistics: the reference's result up to a permutation of the rows (tests/test_optim_gpu.py)."""
     idx, _ = compact_mask(~mask)
+    if zorder and int(idx.numel()) > 1:
+        order = morton_order(gaussians._xyz.detach()[idx.long()])
+        idx = idx[order.long()].contiguous()
     slots = _optimizer_slots(gaussians)
     aux = [gaussians.xyz_gradient_accum, gaussians.denom, gaussians.max_radii2D]
     outs = gather_rows(idx, [t for t, _, _, _ in slots] + aux)

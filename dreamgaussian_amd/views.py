@@ -7,6 +7,14 @@ and the images meet on one rank through an RCCL gather over xGMI (direct peer->r
 transfers: each peer owns a link to the root, so the gather is one hop and per-link bound);
 per-Gaussian gradients are summed with one all-reduce per attribute bucket.
 
+Where the loss lives decides what is exchanged (bench.py --step sds --sds-mode ...):
+  * "gather": ONE rank evaluates the image-space loss for all views (a guidance model that exists once): gather of the images,
+    scatter of dL/dimage, all-reduce of the parameter gradients -- three collectives per step;
+  * "local": the loss is a sum over the views and every rank can evaluate its own views' terms (DreamGaussian's known-view MSE,
+    main.py:200-216, and an SDS guidance replicated per rank, the usual data-parallel layout): each rank differentiates its own
+    images, NO image ever crosses a link, the all-reduce of the parameter gradients is the only collective (`allreduce_grads`,
+    `async_op=True`: it travels while the host prepares the optimiser step).
+
 One process per GPU, `torch.distributed` (backend "nccl" = RCCL on ROCm; "gloo" in the CPU
 tests). No rendering arithmetic lives here.
 """
@@ -143,8 +151,32 @@ def scatter_view_grads(grad_all: Optional[torch.Tensor], like: torch.Tensor, src
     return out[:b]
 
 
-def allreduce_grads(params: Iterable[torch.Tensor], group=None, bucket_bytes: int = 64 << 20):
-    """Sum `.grad` of the replicated Gaussian parameters over the ranks.
+class GradSync:
+    """Handle of `allreduce_grads(..., async_op=True)`: the collectives are in flight on the backend's stream; `wait()` makes the
+    CURRENT stream wait for them (no host block under "nccl") and copies bucketed gradients back. Call it before anything reads or
+    frees the gradients -- the optimiser step, or `p.grad = None` at the top of the next iteration."""
+
+    def __init__(self):
+        self._works = []
+        self._copies = []          # (flat bucket, its gradients): copied back in wait()
+
+    def wait(self):
+        for w in self._works:
+            if w is not None:
+                w.wait()
+        for flat, bucket in self._copies:
+            off = 0
+            for g in bucket:
+                n = g.numel()
+                g.copy_(flat[off:off + n].view_as(g))
+                off += n
+        self._works, self._copies = [], []
+
+
+def allreduce_grads(params: Iterable[torch.Tensor], group=None, bucket_bytes: int = 64 << 20, async_op: bool = False):
+    """Sum `.grad` of the replicated Gaussian parameters over the ranks. `async_op=True`: returns a `GradSync` at once (None when
+    there is nothing to do): the caller's next host work -- the optimiser's Python, the next iteration's camera set-up -- runs
+    while the ranks exchange; `wait()` before the gradients are read or released.
 
     The rasterizer's backward carves every gradient out of ONE allocation (rasterizer.py: the parameter gradients first,
     the per-view means2D gradient last) and autograd keeps those views as `.grad`: gradients that tile one storage are
@@ -154,7 +186,8 @@ def allreduce_grads(params: Iterable[torch.Tensor], group=None, bucket_bytes: in
     rings are per-link bound, launch latency dominates small ones."""
     rank, world = _world(group)
     if _single(world):
-        return
+        return None
+    sync = GradSync()
     grads = [p.grad for p in params if p.grad is not None]
     by_storage = {}
     for g in grads:
@@ -174,7 +207,7 @@ def allreduce_grads(params: Iterable[torch.Tensor], group=None, bucket_bytes: in
                 end = max(end, g.storage_offset() + g.numel())
             if tight:
                 span = torch.empty(0, dtype=dtype, device=dev).set_(gs[0].untyped_storage(), lo, (hi - lo,))
-                dist.all_reduce(span, op=dist.ReduceOp.SUM, group=group)
+                sync._works.append(dist.all_reduce(span, op=dist.ReduceOp.SUM, group=group, async_op=True))
                 continue
         rest.extend(gs)
     bucket, size = [], 0
@@ -184,15 +217,11 @@ def allreduce_grads(params: Iterable[torch.Tensor], group=None, bucket_bytes: in
         if not bucket:
             return
         if len(bucket) == 1 and bucket[0].is_contiguous():
-            dist.all_reduce(bucket[0], op=dist.ReduceOp.SUM, group=group)
+            sync._works.append(dist.all_reduce(bucket[0], op=dist.ReduceOp.SUM, group=group, async_op=True))
         else:
             flat = torch.cat([g.reshape(-1) for g in bucket])
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-            off = 0
-            for g in bucket:
-                n = g.numel()
-                g.copy_(flat[off:off + n].view_as(g))
-                off += n
+            sync._works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True))
+            sync._copies.append((flat, bucket))
         bucket, size = [], 0
 
     for g in rest:
@@ -201,3 +230,7 @@ def allreduce_grads(params: Iterable[torch.Tensor], group=None, bucket_bytes: in
         if size >= bucket_bytes:
             flush()
     flush()
+    if async_op:
+        return sync
+    sync.wait()
+    return None

@@ -259,6 +259,9 @@ def build_tile_lists(pre: dict):
     return gid[order], ranges, M
 
 
+ALLOW_DEVICE = [False]      # bench.py --naive-gpu sets it: the oracle as a stock-PyTorch GPU program (a baseline, not a checker)
+
+
 def composite_tile(pix, xy, conic, opac, color, depth, bg):
     """Front-to-back compositing of one sorted list over a set of pixels.
     pix [P,2] pixel centres (integer coords as float); per-Gaussian tensors [n,...]."""
@@ -302,7 +305,7 @@ def composite_tile(pix, xy, conic, opac, color, depth, bg):
     C = (w[:, :, None] * color[:, None, :]).sum(0)   # [P,3]
     D = (w * depth[:, None]).sum(0)
     A = w.sum(0)
-    T_final = T_incl[-1] if T_incl.shape[0] > 0 else torch.ones(pix.shape[0], dtype=xy.dtype)
+    T_final = T_incl[-1] if T_incl.shape[0] > 0 else torch.ones(pix.shape[0], dtype=xy.dtype, device=xy.device)
     return C + T_final[:, None] * bg[None, :], D, A, T_final, n_contrib
 
 
@@ -312,16 +315,16 @@ class _Composite(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xy, conic, opac, color, depth, bg, ids, ranges, H, W, gx, tiles=None):
-        dt = xy.dtype
+        dt, dv = xy.dtype, xy.device
         _t0 = time.perf_counter()
-        out_c = torch.zeros(H, W, 3, dtype=dt)
-        out_d = torch.zeros(H, W, dtype=dt)
-        out_a = torch.zeros(H, W, dtype=dt)
-        out_T = torch.ones(H, W, dtype=dt)
-        out_n = torch.zeros(H, W, dtype=torch.int64)
+        out_c = torch.zeros(H, W, 3, dtype=dt, device=dv)
+        out_d = torch.zeros(H, W, dtype=dt, device=dv)
+        out_a = torch.zeros(H, W, dtype=dt, device=dv)
+        out_T = torch.ones(H, W, dtype=dt, device=dv)
+        out_n = torch.zeros(H, W, dtype=torch.int64, device=dv)
         out_c[:] = bg
-        frag_pix = torch.zeros(H, W, dtype=torch.bool)
-        frag_gauss = torch.zeros(xy.shape[0], dtype=torch.bool)
+        frag_pix = torch.zeros(H, W, dtype=torch.bool, device=dv)
+        frag_gauss = torch.zeros(xy.shape[0], dtype=torch.bool, device=dv)
         tiles = range(len(ranges) - 1) if tiles is None else tiles
         for t in tiles:
             s, e = int(ranges[t]), int(ranges[t + 1])
@@ -329,9 +332,9 @@ class _Composite(torch.autograd.Function):
                 continue
             y0, x0 = (t // gx) * BLOCK, (t % gx) * BLOCK
             y1, x1 = min(y0 + BLOCK, H), min(x0 + BLOCK, W)
-            ys, xs = torch.meshgrid(torch.arange(y0, y1), torch.arange(x0, x1), indexing="ij")
+            ys, xs = torch.meshgrid(torch.arange(y0, y1, device=dv), torch.arange(x0, x1, device=dv), indexing="ij")
             pix = torch.stack([xs.reshape(-1), ys.reshape(-1)], -1).to(dt)
-            g = torch.as_tensor(ids[s:e])
+            g = torch.as_tensor(ids[s:e]).to(dv)
             with torch.no_grad():
                 c, d, a, T, n = composite_tile(pix, xy[g], conic[g], opac[g], color[g], depth[g], bg)
             out_c[y0:y1, x0:x1] = c.reshape(y1 - y0, x1 - x0, 3)
@@ -361,9 +364,9 @@ class _Composite(torch.autograd.Function):
                 continue
             y0, x0 = (t // gx) * BLOCK, (t % gx) * BLOCK
             y1, x1 = min(y0 + BLOCK, H), min(x0 + BLOCK, W)
-            ys, xs = torch.meshgrid(torch.arange(y0, y1), torch.arange(x0, x1), indexing="ij")
+            ys, xs = torch.meshgrid(torch.arange(y0, y1, device=xy.device), torch.arange(x0, x1, device=xy.device), indexing="ij")
             pix = torch.stack([xs.reshape(-1), ys.reshape(-1)], -1).to(xy.dtype)
-            g = torch.as_tensor(ids[s:e])
+            g = torch.as_tensor(ids[s:e]).to(xy.device)
             leaves = [v[g].detach().requires_grad_(True) for v in (xy, conic, opac, color, depth)]
             with torch.enable_grad():
                 c, d, a, _, _ = composite_tile(pix, *leaves, bg)
@@ -385,7 +388,9 @@ def rasterize(means3D, means2D, opacities, S: Settings, shs=None, colors_precomp
     alpha[1,H,W]) in the order the reference unpacks (gs_renderer.py:800).
     `tiles` (optional list of tile ids) restricts compositing to those 16x16 tiles (all other
     pixels keep the background): bench.py's bounded CPU-baseline sample."""
-    assert means3D.device.type == "cpu", "the oracle is a CPU checker"
+    # The oracle is a CPU checker. On a GPU it runs ONLY on request, as the "naive GPU" middle point of BASELINE.md section 3 (the same
+    # stock-PyTorch program on the device: bench.py --naive-gpu) -- never as a checker and never inside the product.
+    assert means3D.device.type == "cpu" or ALLOW_DEVICE[0], "the oracle is a CPU checker (gs_oracle.ALLOW_DEVICE: bench.py --naive-gpu)"
     extent = float(max(int(S.image_height), int(S.image_width)))
     FRAGILE_PX[0] = FRAGILE_PX_PER_PIXEL * extent
     FRAGILE_T_REL[0] = max(1e-4, FRAGILE_T_REL_AT_800 * extent / 800.0)
@@ -393,7 +398,7 @@ def rasterize(means3D, means2D, opacities, S: Settings, shs=None, colors_precomp
                      cov3D_precomp, S)
     ids, ranges, M = build_tile_lists(pre)
     H, W = int(S.image_height), int(S.image_width)
-    bg = S.bg.to(means3D.dtype).cpu()
+    bg = S.bg.to(dtype=means3D.dtype, device=means3D.device)
     color, depth, alpha, T_final, n_contrib = _Composite.apply(
         pre["xy"], pre["conic"], pre["opacity"], pre["color"], pre["depth"], bg,
         ids, ranges, H, W, pre["grid"][0], tiles)

@@ -101,6 +101,44 @@ def test_prune_points_equals_reference_algorithm(gpu):
     a.optimizer.step()
 
 
+def test_prune_points_in_z_order_is_the_reference_result_up_to_a_row_permutation(gpu):
+    """`prune_points(..., zorder=True)`: the same surviving Gaussians, each with its own Adam moments and densification statistics,
+    as the reference's boolean-mask indexing leaves them -- in the order of a Z-order curve through their positions."""
+    N = 5000
+    names = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+    params, opt = _make(N, gpu, D.FusedAdam, seed=11)
+    for p_ in params:
+        p_.grad = torch.ones_like(p_) * 0.1
+    opt.step()
+    ga = torch.Generator().manual_seed(7)
+    gm = types.SimpleNamespace(optimizer=opt, xyz_gradient_accum=torch.rand(N, 1, generator=ga).to(gpu),
+                               denom=torch.rand(N, 1, generator=ga).to(gpu), max_radii2D=torch.rand(N, generator=ga).to(gpu))
+    for n, p_ in zip(names, params):
+        setattr(gm, n, p_)
+    before = {n: getattr(gm, n).detach().clone() for n in names}
+    mom = {n: (opt.state[getattr(gm, n)]["exp_avg"].clone(), opt.state[getattr(gm, n)]["exp_avg_sq"].clone()) for n in names}
+    acc = (gm.xyz_gradient_accum.clone(), gm.denom.clone(), gm.max_radii2D.clone())
+    mask = (torch.rand(N, generator=torch.Generator().manual_seed(6)) < 0.3).to(gpu)
+    D.prune_points(gm, mask, zorder=True)
+    keep = (~mask).nonzero().squeeze(1)
+    # which original row sits where: the positions are distinct random numbers
+    xyz_new = gm._xyz.detach()
+    perm = D.morton_order(before["_xyz"][keep]).long()
+    src = keep[perm]
+    assert xyz_new.shape[0] == keep.numel() and torch.equal(xyz_new, before["_xyz"][src])
+    code_sorted = D.morton_order(xyz_new).long()
+    assert torch.equal(code_sorted, torch.arange(xyz_new.shape[0], device=gpu))      # the result IS in Z-order (stable sort: identity)
+    for n in names:
+        p_ = getattr(gm, n)
+        assert p_.requires_grad and torch.equal(p_.detach(), before[n][src]), n
+        st = gm.optimizer.state[p_]
+        assert torch.equal(st["exp_avg"], mom[n][0][src]) and torch.equal(st["exp_avg_sq"], mom[n][1][src]), n
+    assert torch.equal(gm.xyz_gradient_accum, acc[0][src]) and torch.equal(gm.denom, acc[1][src]) and torch.equal(gm.max_radii2D, acc[2][src])
+    for p_ in (g["params"][0] for g in gm.optimizer.param_groups):
+        p_.grad = torch.ones_like(p_)
+    gm.optimizer.step()
+
+
 def test_gather_rows_with_an_empty_feature_tensor(gpu):
     """`_features_rest` is [N,0,3] at sh_degree 0 (configs/image.yaml): nothing to move, shape preserved."""
     g = torch.Generator().manual_seed(5)

@@ -80,12 +80,22 @@ def _worker(rank, world, port, q):
         total = float(sum(range(1, world + 1)))
         assert pa.grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr()
         assert bool((pa.grad == total).all()) and bool((pb.grad == total).all()) and bool((pv.grad == rank + 1).all())
+        # "local" placement of the loss (round 5): every rank differentiates its own views' terms of the same loss -- no image crosses
+        # a link -- and the all-reduce is asynchronous (a handle, waited for before the gradients are read)
+        sc_l = {k: v.detach().clone().requires_grad_(True) for k, v in O.make_scene(120, 0, 0, "trained").items()}
+        local_l = torch.stack([_render(az, sc_l, W, H) for az in mine])
+        torch.autograd.backward([local_l], [gw[rank::world]])
+        h = views.allreduce_grads(list(sc_l.values()), bucket_bytes=1 << 10, async_op=True)
+        assert isinstance(h, views.GradSync)
+        h.wait()
+        h.wait()                                                                # (idempotent)
+        grads_local = {k: v.grad.clone() for k, v in sc_l.items()}
         if rank == 0:
             q.put(_np(dict(batch=batch, everywhere=everywhere, buf=buf.clone(),
-                           grads={k: v.grad.clone() for k, v in sc.items()})))
+                           grads={k: v.grad.clone() for k, v in sc.items()}, grads_local=grads_local)))
         else:
             assert batch is None
-            q.put(_np(dict(everywhere=everywhere, grads={k: v.grad.clone() for k, v in sc.items()})))
+            q.put(_np(dict(everywhere=everywhere, grads={k: v.grad.clone() for k, v in sc.items()}, grads_local=grads_local)))
     finally:
         dist.barrier()
         dist.destroy_process_group()
@@ -120,6 +130,7 @@ def test_two_rank_view_parallel_equals_serial():
     for k, v in sc.items():
         for r in (r0, r1):
             assert torch.allclose(r["grads"][k], v.grad, rtol=1e-4, atol=1e-6 * v.grad.abs().max().item()), k
+            assert torch.allclose(r["grads_local"][k], v.grad, rtol=1e-4, atol=1e-6 * v.grad.abs().max().item()), ("local", k)
 
 
 def _worker_ragged(rank, world, port, q, azs):

@@ -119,11 +119,21 @@ views)
     timeout 300 python bench.py --workload 250k-512-sh0 --cpu-budget 0 $m 2>gpurun_out/views_err.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['config']['views_mode'], d['value'], 'Mrays/s', d['ms_per_step'], 'ms per 8 views')"
   done;;
 sds)
-  echo "== bench --step sds (1 GPU, no collectives)"; timeout 300 python bench.py --step sds --cpu-budget 0 2>&1 | grep -a "^{" | tee gpurun_out/sds_plain.json | cut -c1-400
-  echo "== bench --step sds --force-collectives (1 GPU, 1-rank RCCL group)"; timeout 300 python bench.py --step sds --cpu-budget 0 --force-collectives 2>&1 | grep -a "^{" | tee gpurun_out/sds_rccl.json | cut -c1-400;;
+  rm -f gpurun_out/sds_one_gpu.jsonl
+  for m in local gather; do
+    echo "== bench --step sds --sds-mode $m (1 GPU, no collectives)"; timeout 300 python bench.py --step sds --sds-mode $m --cpu-budget 0 $SDS_ARGS 2>&1 | grep -a "^{" | tee -a gpurun_out/sds_one_gpu.jsonl | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], 'ms', d['config']['parallelism'])"
+    echo "== bench --step sds --sds-mode $m --force-collectives (1 GPU, 1-rank RCCL group)"; timeout 300 python bench.py --step sds --sds-mode $m --cpu-budget 0 --force-collectives $SDS_ARGS 2>&1 | grep -a "^{" | tee -a gpurun_out/sds_one_gpu.jsonl | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], 'ms', d['config']['parallelism'])"
+  done;;
+sdstrace)
+  # where the exchange's fixed cost sits: kernel + HIP API trace of the forced-collectives step (no counters in this run)
+  for m in gather local; do
+    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --hip-trace --output-format csv -d $R/gpurun_out/sdstrace_$m -o t -- python $R/bench.py --step sds --sds-mode $m --force-collectives --cpu-budget 0 --steps 20 --warmup 5 > $R/gpurun_out/sdstrace_$m.log 2>&1)
+    tail -1 gpurun_out/sdstrace_$m.log | cut -c1-200
+    python tools/sds_trace.py gpurun_out/sdstrace_$m | tee gpurun_out/sds_trace_$m.txt | tail -40
+  done;;
 cpubase)
   for wl in 5k-256-sh0 100k-800-sh3; do
-    echo "== bench $wl with the CPU oracle"; timeout 900 python bench.py --workload $wl --cpu-budget ${CPU_BUDGET:-10} 2> gpurun_out/benchcpu_$wl.err | tee gpurun_out/benchcpu_$wl.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['cpu_baseline'])"
+    echo "== bench $wl with the CPU oracle and the naive-GPU point"; timeout 900 python bench.py --workload $wl --cpu-budget ${CPU_BUDGET:-10} --naive-gpu 2> gpurun_out/benchcpu_$wl.err | tee gpurun_out/benchcpu_$wl.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['cpu_baseline'], d.get('naive_gpu'))"
   done;;
 pmcmorton)
   echo "== rocprofv3 PMC passes, --order morton (1M)"
@@ -132,6 +142,10 @@ pmcmorton)
     (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmcm/pmc_$c -o r05 -- python $R/bench.py --steps 3 --warmup 1 --cpu-budget 0 --no-roofline --order morton > $R/gpurun_out/pmcm/pmc_$c.log 2>&1)
   done
   python tools/pmc_summary.py gpurun_out/pmcm 2>&1 | tee gpurun_out/pmc_morton_summary.txt | cut -c1-300;;
+floor5k)
+  # what an EMPTY autograd.Function with the rasterizer's signature costs per fwd+bwd on this host, beside the library at 5k / 256^2
+  python tools/host_overhead.py 2>&1 | grep -a "ms/step\|floor" | tee gpurun_out/host_floor_5k.txt
+  for i in 1 2 3 4 5 6 7 8 9 10; do python bench.py --workload 5k-256-sh0 --cpu-budget 0 --no-roofline --steps 200 --warmup 20 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('5k-256-sh0 ms_per_step', d['ms_per_step'])"; done | tee -a gpurun_out/host_floor_5k.txt;;
 smoke)
   timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3;;
 *) echo "unknown section $sec";;

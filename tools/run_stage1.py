@@ -103,7 +103,7 @@ def psnr_fixed_view(gui):
     return -10.0 * math.log10(max(mse, 1e-12))
 
 
-def install_optin(gs_renderer):
+def install_optin(gs_renderer, zorder=False):
     """The opt-in replacements either side of the rasterizer, patched onto the reference's
     GaussianModel from OUTSIDE (its files stay unmodified): FusedAdam for the Adam of `training_setup`
     (gs_renderer.py:370), the fused densification statistics (gs_renderer.py:625-627), the one-gather prune
@@ -122,7 +122,7 @@ def install_optin(gs_renderer):
                                   self.denom, self.max_radii2D)
 
     def prune_points(self, mask):
-        D.prune_points(self, mask)
+        D.prune_points(self, mask, zorder=zorder)         # (zorder: the survivors leave along a Z-order curve; densify_and_prune ends here)
 
     def densification_postfix(self, *new_rows):
         D.densification_postfix(self, *new_rows)
@@ -172,7 +172,7 @@ def check_against_oracle(sc, sizes=((256, 0.0, 0.0), (512, -15.0, 130.0)), label
     return rep
 
 
-def run(ref, iters, input_path, profiled, optin=False, keep=None):
+def run(ref, iters, input_path, profiled, optin=False, keep=None, zorder=False):
     from dreamgaussian_amd import _lib
     for m in ("main", "gs_renderer", "sh_utils", "cam_utils", "grid_put"):
         sys.modules.pop(m, None)
@@ -181,7 +181,7 @@ def run(ref, iters, input_path, profiled, optin=False, keep=None):
     import diff_gaussian_rasterization as dgr
     assert gs_renderer.GaussianRasterizer is dgr.GaussianRasterizer, "gs_renderer.py is not bound to this repository's package"
     if optin:
-        install_optin(gs_renderer)                   # the module object is re-imported by every run(): nothing to undo
+        install_optin(gs_renderer, zorder=zorder)    # the module object is re-imported by every run(): nothing to undo
     np.random.seed(0); torch.manual_seed(0); torch.cuda.manual_seed(0)
     opt = make_opt(ref, iters, input_path)
     t_init0 = time.perf_counter()
@@ -276,6 +276,10 @@ def main():
         out["optin_run"]["what"] = ("same trainer, same seed; GaussianModel.training_setup -> dreamgaussian_amd.FusedAdam, "
                                     "add_densification_stats -> the fused kernel, prune_points / densify_and_clone / densify_and_split / "
                                     "densification_postfix -> compact_mask + gather_rows + concat_rows")
+        out["optin_zorder_run"] = run(ref, a.iters, input_path, profiled=False, optin=True, zorder=True)
+        out["optin_zorder_run"]["what"] = ("the opt-in run with prune_points(..., zorder=True): the rows leave every densification interval "
+                                           "along a Z-order curve (at ~10k Gaussians the binning kernels are not where the time is: a check "
+                                           "that it costs nothing here; where it pays: bench.py --order morton at 250k-1M)")
     os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
     json.dump(out, open(a.out, "w"), indent=1)
     print(json.dumps(out, indent=1))
