@@ -47,9 +47,12 @@ WORKLOADS = {                  # BASELINE.json configs (index): N, sh degree, W,
 }
 
 
-def alg_bytes(N, K, V, M, P):
+def alg_bytes(N, K, V, M, P, grads_written_by="preprocess_bwd"):
     """Algorithmic (compulsory) HBM bytes of SURVEY 8(d), split per kernel so that the parts
-    add up to B_alg(fwd+bwd) = N(3 A_in + 16) + 212 V + 24 M + 56 P."""
+    add up to B_alg(fwd+bwd) = N(3 A_in + 16) + 212 V + 24 M + 56 P.
+    `grads_written_by`: the kernel that stores the gradient arrays, N (A_in + 12) bytes of the total. Round 5: for large scenes the
+    compositing kernel of the backward clears them on the side and the per-Gaussian kernel only visits the Gaussians that carry a
+    gradient (gsr_preprocess_bwd_compact): the compulsory write of every gradient element is then render_bwd's, and the line says so."""
     A_in = 44 + 12 * K
     per = {
         "preprocess_fwd": N * (A_in + 4) + 44 * V,      # inputs read, radii + 44 B state written
@@ -57,8 +60,9 @@ def alg_bytes(N, K, V, M, P):
         "tile_sort": 8 * M,                             # ... read back by the sort
         "render_fwd": 44 * V + 28 * P,                  # state read, 20 B out + 8 B aux per pixel
         "render_bwd": 84 * V + 8 * M + 28 * P,          # state read, 40 B 2D grads, lists, pixel grads
-        "preprocess_bwd": N * (2 * A_in + 12) + 40 * V, # inputs re-read, grads written, 2D grads read
+        "preprocess_bwd": N * A_in + 40 * V,            # inputs re-read, 2D grads read
     }
+    per[grads_written_by] += N * (A_in + 12)            # ... and every gradient element written once
     per["total"] = sum(per.values())
     assert per["total"] == N * (3 * A_in + 16) + 212 * V + 24 * M + 56 * P
     return per
@@ -70,6 +74,8 @@ def kernel_family(name: str) -> str:
     walks the one segment in which a pixel stops)."""
     if name.startswith("tile_sort"):
         return "tile_sort"
+    if name == "preprocess_bwd_live":                # gsr_preprocess_bwd_compact: the per-Gaussian backward over the live Gaussians only
+        return "preprocess_bwd"
     return "render_fwd" if name in ("render_combine", "render_fix") else name
 
 
@@ -491,7 +497,12 @@ def main():
             e[1] = max(e[1], n)
             fam_launches[fam] = fam_launches.get(fam, 0) + n / a.steps
         P = wl["H"] * wl["W"]
+        # who stores the gradient arrays: the per-Gaussian backward, or (its "live Gaussians only" variant ran) the compositing kernel
+        # (the line's `frac` keeps SURVEY 8(d)'s split -- the gradient arrays priced with the per-Gaussian backward -- whoever clears them;
+        # what the dominant kernel reaches when the 248 MB it really clears are counted is printed beside it)
+        gw = "render_bwd" if "preprocess_bwd_live" in raw else "preprocess_bwd"
         ab = alg_bytes(wl["N"], K, st["V"], st["M_ref"], P)
+        ab_gw = alg_bytes(wl["N"], K, st["V"], st["M_ref"], P, gw)
         per_step = {k: v[0] / a.steps for k, v in kern.items()}
         dom = max(per_step, key=per_step.get)
         # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate passes,
@@ -518,12 +529,26 @@ def main():
                         alg_bytes_per_launch=ab[dom], instances_priced="M_ref (reference emission rule, SURVEY 8(d))",
                         alg_bytes_per_launch_emitted=ab_emit[dom],
                         frac_emitted=round(ab_emit[dom] / (per_step[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                        gradient_arrays_written_by=gw,
+                        **({"frac_with_the_gradient_arrays_it_clears": round(ab_gw[dom] / (per_step[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+                           if dom == gw == "render_bwd" else {}),
                         avg_launch_ms=round(per_step[dom], 4), launches_per_step=round(fam_launches.get(dom, 1)),
                         kernels={k: round(v, 4) for k, v in kern_raw.items() if kernel_family(k) == dom})
         ach_p = ab["total"] / (dt / a.steps) / 1e9
         path_roof = dict(bound="hbm", achieved=round(ach_p, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                          frac=round(ach_p / HBM_PEAK_GBS, 5), alg_bytes_per_step=ab["total"],
                          gpu_kernel_ms_per_step=round(sum(per_step.values()), 4))
+    # ---- the same K un-instrumented steps once more, now that W + 2K steps have run: the first ~25 steps of a process run on rising
+    # clocks (profiles/r04_warmup_ramp.txt), so the line's `value` (exactly W warm-up + K timed steps, as the contract says) sits on
+    # the ramp; this is what a training loop sees from its 25th iteration on. Reported beside `value`, never instead of it.
+    dt_after = None
+    if rank == 0 and world == 1 and not a.no_roofline:
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        torch.cuda.synchronize()
+        dt_after = time.perf_counter() - t2
     if world > 1:
         dist.barrier()
 
@@ -562,6 +587,7 @@ def main():
             "kernels_ms_per_step": {k: round(v[0] / a.steps, 4) for k, v in sorted(kern.items())},
             "kernels_ms_per_step_raw": {k: round(v, 4) for k, v in sorted(kern_raw.items())} if kern else {},
             "ms_per_step_with_events": None if dt_prof is None else round(dt_prof / a.steps * 1e3, 4),
+            "ms_per_step_after_ramp": None if dt_after is None else round(dt_after / a.steps * 1e3, 4),
         }
         if sds is not None:
             out["sds_step"] = sds

@@ -876,7 +876,7 @@ int backward_impl(const GsrView* views, int B, int32_t N, int32_t K,
         hipLaunchKernelGGL(k6c, dim3(rounds < gcap ? rounds : gcap), dim3(GSR_K6C_NT), lds_c, stream, tab, N, K, means3D, shs, colors_precomp, opacities, scales,
                            rotations, cov3D_precomp, flags8, g2d, live, dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacities,
                            dL_dscales, dL_drotations, dL_dcov3D);
-        LAUNCH_CHECK(view, stream, "preprocess_bwd");
+        LAUNCH_CHECK(view, stream, "preprocess_bwd_live");
     } else if (B > 1 && lds_multi <= 80 * 1024) {
         for (int v = 0; v < B; ++v) tab.v[v] = make_view(views + v);
         if (lds_multi > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k6m, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_multi));
