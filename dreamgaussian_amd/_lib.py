@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSR_LIB") or os.path.join(_HERE, "libgsr.so")
 
 GSR_MAX_VIEWS = 16      # include/gsr.h
-GSR_ABI_VERSION = 4     # include/gsr.h
+GSR_ABI_VERSION = 5     # include/gsr.h
 GSR_VIEW_VIEWMATRIX_T, GSR_VIEW_PROJMATRIX_T, GSR_VIEW_NO_BACKWARD = 1, 2, 4   # GsrView.flags
 
 EXPORTS = ("gsr_forward", "gsr_backward", "gsr_forward_views", "gsr_backward_views", "gsr_mark_visible", "gsr_dist2", "gsr_extract_fields", "gsr_densify_stats",
@@ -30,7 +30,8 @@ class GsrView(C.Structure):
                 ("bg", C.c_void_p), ("viewmatrix", C.c_void_p),
                 ("projmatrix", C.c_void_p), ("campos", C.c_void_p),
                 ("raw_activations", C.c_int32), ("flags", C.c_int32),
-                ("shs_rest", C.c_void_p), ("dL_dshs_rest", C.c_void_p)]
+                ("shs_rest", C.c_void_p), ("dL_dshs_rest", C.c_void_p),
+                ("grad_clear", C.c_void_p), ("grad_clear_floats", C.c_int64)]
 
 
 RESIZE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)

@@ -109,9 +109,9 @@ int once_per_device(F fn) {
 // A/B measurement through an explicit call. Nothing here is read from the process environment: two of them (forward mode, segment
 // length) decide where the per-pixel sums are cut, i.e. the rounding of the results, and that must not depend on who started the
 // process. -1 = the library decides.
-enum { OV_FWD_MODE, OV_SEG_SHIFT, OV_FWD_LISTS, OV_FWD_HINTS, OV_SPECULATE, OV_HIST_MAX, OV_K1_GRID, OV_FWD_GRID, OV_K6_GRID, OV_FWD_LDS_KB, OV_BWD_GRID, OV_K6_COMPACT, OV_SCAN_FOLD, OV_COUNT };
-const char* const kOvNames[OV_COUNT] = {"fwd_mode", "seg_shift", "fwd_lists", "fwd_hints", "speculate", "hist_max", "k1_grid", "fwd_grid", "k6_grid", "fwd_lds_kb", "bwd_grid", "k6_compact", "scan_fold"};
-std::atomic<int> g_ov[OV_COUNT] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
+enum { OV_FWD_MODE, OV_SEG_SHIFT, OV_FWD_LISTS, OV_FWD_HINTS, OV_SPECULATE, OV_HIST_MAX, OV_K1_GRID, OV_FWD_GRID, OV_K6_GRID, OV_FWD_LDS_KB, OV_BWD_GRID, OV_K6_COMPACT, OV_SCAN_FOLD, OV_GRAD_CLEAR, OV_COUNT };
+const char* const kOvNames[OV_COUNT] = {"fwd_mode", "seg_shift", "fwd_lists", "fwd_hints", "speculate", "hist_max", "k1_grid", "fwd_grid", "k6_grid", "fwd_lds_kb", "bwd_grid", "k6_compact", "scan_fold", "grad_clear"};
+std::atomic<int> g_ov[OV_COUNT] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
 inline int ov(int k) { return g_ov[k].load(std::memory_order_relaxed); }
 
 // K1's grid (a persistent grid: every workgroup walks the same number of 256-Gaussian batches; test hook "k1_grid" pins it). The
@@ -421,13 +421,21 @@ int begin_impl(const GsrView* views, int B, int32_t N, int32_t K,
 
 int sort_class(unsigned long long maxc) { return maxc <= 2048 ? 0 : (maxc <= 8192 ? 1 : (maxc <= 16384 ? 2 : 3)); }
 
+// Whether the per-Gaussian backward of this problem visits the live Gaussians only (gsr_preprocess_bwd_compact, backward_impl) -- and
+// with it whether somebody has to clear the gradient arrays on the side. Known from the problem's shape: the forward asks too.
+bool k6_compact_for(const GsrView* view, int B, int32_t N, int32_t K, bool has_shs) {
+    const size_t grad_bytes = (size_t)N * (size_t)(3 * (has_shs ? K : 1) + 14) * 4;
+    return B == 1 && !view->shs_rest && (ov(OV_K6_COMPACT) == 1 || (ov(OV_K6_COMPACT) < 0 && grad_bytes >= ((size_t)64 << 20)));
+}
+
 // Binning, sort and compositing for lists of up to `cap` instances whose longest is assumed <= `maxc`.
 // cap / maxc are either the exact counters (the host has waited for them) or forward_impl's prediction; in the second
 // case every kernel that touches the lists checks the true M and the true longest list and leaves when they do not fit.
 int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float* out_depth, float* out_alpha,
                 char* gbuf, char* ibuf, GsrAlloc bin, int shift,
                 const unsigned long long* per_view /* (M_ref, V) of every view */,
-                unsigned long long cap, unsigned long long maxc, bool prepare_bwd, bool scan_in_scatter, int counter_words, hipStream_t stream) {
+                unsigned long long cap, unsigned long long maxc, bool prepare_bwd, bool scan_in_scatter, int counter_words, hipStream_t stream,
+                ZeroSide side = ZeroSide{nullptr, 0u, 0u} /* GsrView.grad_clear, when the serial walk is to clear it (forward_impl) */) {
     const GsrView* view = views;
     const ViewConst vc = make_view(view);
     const int H = vc.H, W = vc.W;
@@ -542,6 +550,7 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
     float4* zero4 = (float4*)(gbuf + GL.g2d);
     uint32_t zero_n = prepare_bwd ? (uint32_t)(((size_t)B * (size_t)N * GSR_G2D_STRIDE * 4 + (size_t)B * GSR_LIVE_BYTES(N)) / 16) : 0u;   // accumulators + live flags
     const uint32_t zero_per = (zero_n + (uint32_t)TA - 1u) / (uint32_t)TA;       // float4s per workgroup (grid = TA)
+    side.per = (side.n4 + (uint32_t)TA - 1u) / (uint32_t)TA;
     if (sequential) {
         // ---- K5s: the serial walk, one workgroup per tile
         const size_t fwd_lds = fwd_serial_lds_pad(B);
@@ -562,22 +571,22 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
             hipLaunchKernelGGL(gsr_render_fwd_pair, dim3(TA), dim3(512), 0, stream, tile_off, recs, sorted_ids, W, H, vc.gx,
                                out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, order, shift,
                                plan_off, plan_tile, counters + 4, (uint32_t)BL.plan_cap, (unsigned long long)mask_q | no_state_bit, sink_rec,
-                               counters, (uint32_t)M, maxc_cap, vs, zero4, zero_n, zero_per);
-            zero_n = 0u;
+                               counters, (uint32_t)M, maxc_cap, vs, zero4, zero_n, zero_per, side);
+            zero_n = 0u; side.n4 = 0u;
         } else if (mask_q) {
             vs.view_mask = mask_q;
             hipLaunchKernelGGL(gsr_render_fwd_serial<true>, dim3(TA), dim3(256), fwd_lds, stream, tile_off, recs, sorted_ids, W, H, vc.gx,
                                out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, order, shift,
                                plan_off, plan_tile, counters + 4, (uint32_t)BL.plan_cap, (unsigned long long)mask_q | no_state_bit, sink_rec,
-                               counters, (uint32_t)M, maxc_cap, vs, zero4, zero_n, zero_per);
-            zero_n = 0u;
+                               counters, (uint32_t)M, maxc_cap, vs, zero4, zero_n, zero_per, side);
+            zero_n = 0u; side.n4 = 0u;
         }
         if (mask_q != mask_all) {
             vs.view_mask = mask_all & ~mask_q;
             hipLaunchKernelGGL(gsr_render_fwd_serial<false>, dim3(TA), dim3(256), fwd_lds, stream, tile_off, recs, sorted_ids, W, H, vc.gx,
                                out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, order, shift,
                                plan_off, plan_tile, counters + 4, (uint32_t)BL.plan_cap, (unsigned long long)mask_q | no_state_bit, sink_rec,
-                               counters, (uint32_t)M, maxc_cap, vs, zero4, zero_n, zero_per);
+                               counters, (uint32_t)M, maxc_cap, vs, zero4, zero_n, zero_per, side);
         }
         LAUNCH_CHECK(view, stream, "render_fwd");
         return 0;
@@ -663,6 +672,15 @@ int forward_impl(const GsrView* views, int B, int32_t N, int32_t K,
     char* gbuf = (char*)geom.resize(geom.ctx, prepare ? GLs.total : GLs.g2d);      // (no backward: no accumulators at the end of the block)
     char* ibuf = (char*)img.resize(img.ctx, gsr_img_bytes(vcs.H, vcs.W) * (size_t)B);
     if (!gbuf || !ibuf) return fail(-4, "scratch allocation failed%s", "");
+    // GsrView.grad_clear: the array the backward's outputs will be carved from, cleared under the serial walk when the backward would
+    // otherwise clear it under ITS compositing kernel (same rule: k6_compact_for). GsrStats.bwd_prepared = 2 tells the caller.
+    ZeroSide side{nullptr, 0u, 0u};
+    if (prepare && ov(OV_GRAD_CLEAR) != 0 && view->grad_clear && view->grad_clear_floats > 0 && !((uintptr_t)view->grad_clear & 15) && !(view->grad_clear_floats & 3) &&
+        (unsigned long long)view->grad_clear_floats / 4 < 0x7fffffffull && k6_compact_for(view, B, N, K, shs != nullptr) &&
+        fwd_sequential_for(N, GLs.nTiles)) {
+        side.p = reinterpret_cast<float4*>(view->grad_clear);
+        side.n4 = (uint32_t)(view->grad_clear_floats / 4);
+    }
     const bool spec = ov(OV_SPECULATE) != 0 && g_hint.valid && g_hint.N == N && g_hint.H == vcs.H && g_hint.W == vcs.W && g_hint.B == B && N > 0;
     // K2 (scan of the tile counts, statistics, tile order, the counters for the host) inside the scatter's launch: when the forward is
     // enqueued in one go (speculation), the tile counters sit in LDS (no global cursors) and the compositing takes its tiles from
@@ -691,7 +709,7 @@ int forward_impl(const GsrView* views, int B, int32_t N, int32_t K,
         cap = g_hint.M + g_hint.M / 4 + 4096;
         const unsigned long long c = g_hint.maxc + g_hint.maxc / 4 + 64;
         capc = c <= 2048 ? 2048 : (c <= 8192 ? 8192 : (c <= 16384 ? 16384 : ~0ull));
-        rc = finish_impl(views, B, N, out_color, out_depth, out_alpha, gbuf, ibuf, bin, shift, g_hint.per_view, cap, capc, prepare, fold, 8 + 2 * B, stream);
+        rc = finish_impl(views, B, N, out_color, out_depth, out_alpha, gbuf, ibuf, bin, shift, g_hint.per_view, cap, capc, prepare, fold, 8 + 2 * B, stream, side);
         if (rc && fold) {                                 // K2 never ran: nothing will ever arrive in the pinned block
             (void)hipStreamSynchronize(stream);
             return rc;
@@ -712,11 +730,11 @@ int forward_impl(const GsrView* views, int B, int32_t N, int32_t K,
     }
     if (!spec || cap == 0) {
         cap = M;
-        rc = finish_impl(views, B, N, out_color, out_depth, out_alpha, gbuf, ibuf, bin, shift, g_pinned + 8, M, maxc, prepare, false, 8 + 2 * B, stream);
+        rc = finish_impl(views, B, N, out_color, out_depth, out_alpha, gbuf, ibuf, bin, shift, g_pinned + 8, M, maxc, prepare, false, 8 + 2 * B, stream, side);
     }
     if (stats) { stats->num_instances = (int64_t)M; stats->num_instances_ref = (int64_t)M_ref; stats->num_visible = (int64_t)V;
                  stats->max_tile_count = (int64_t)maxc; stats->bin_capacity = (int64_t)cap; stats->seg_shift = shift;
-                 stats->bwd_prepared = (prepare && rc == 0) ? 1 : (prepare ? 0 : -1); }
+                 stats->bwd_prepared = (prepare && rc == 0) ? (side.n4 ? 2 : 1) : (prepare ? 0 : -1); }
     if (rc == 0) {
         g_hint.valid = true; g_hint.N = N; g_hint.H = vcs.H; g_hint.W = vcs.W; g_hint.B = B; g_hint.M = M; g_hint.maxc = maxc;
         for (int v = 0; v < 2 * B; ++v) g_hint.per_view[v] = g_pinned[8 + v];
@@ -780,7 +798,8 @@ int backward_impl(const GsrView* views, int B, int32_t N, int32_t K,
 
     const size_t g2d_view = (size_t)N * GSR_G2D_STRIDE;
     float* g2d = nullptr;
-    if (fwd_stats && fwd_stats->bwd_prepared == 1) {
+    const bool grads_cleared = fwd_stats && fwd_stats->bwd_prepared == 2;   // ... and GsrView.grad_clear with them
+    if (fwd_stats && fwd_stats->bwd_prepared >= 1) {
         g2d = (float*)(const_cast<char*>(gbuf) + GL.g2d);   // cleared by the forward (forward_impl)
     } else {                                              // no GsrStats, GSR_VIEW_NO_BACKWARD, or a second backward of the same forward
         if (!tmp.resize) return fail(-1, "tmp allocator is required%s", "");
@@ -802,8 +821,7 @@ int backward_impl(const GsrView* views, int B, int32_t N, int32_t K,
     // must be large for the streaming kernel's stores to be the bigger evil. Measured round 5, K6 + render_bwd, streaming -> compact:
     // 1M / SH 3 blob (248 MB of gradients, 27 % live) 0.265 -> 0.258 ms, trained-like (6 % live) 0.175 -> 0.134; 100k / SH 3 (25 MB)
     // 0.131 -> 0.139, 250k / SH 0 (17 MB) 0.093 -> 0.098, 5k 0.028 -> 0.032. Test hook "k6_compact": 0 = never, 1 = whenever possible.
-    const size_t grad_bytes = (size_t)N * (size_t)(3 * (shs ? K : 1) + 14) * 4;
-    bool compact = M > 0 && B == 1 && !view->shs_rest && (ov(OV_K6_COMPACT) == 1 || (ov(OV_K6_COMPACT) < 0 && grad_bytes >= ((size_t)64 << 20)));
+    bool compact = M > 0 && k6_compact_for(view, B, N, K, shs != nullptr);
     if (compact) {
         const struct { float* p; size_t n; } arr[GSR_ZERO_MAX] = {
             {dL_dmeans3D, (size_t)N * 3}, {dL_dmeans2D, (size_t)N * 3}, {dL_dopacities, (size_t)N}, {shs ? dL_dshs : nullptr, (size_t)N * 3 * K},
@@ -812,12 +830,15 @@ int backward_impl(const GsrView* views, int B, int32_t N, int32_t K,
         for (int r = 0; r < GSR_ZERO_MAX; ++r) {
             if (!arr[r].p) continue;
             if ((uintptr_t)arr[r].p & 15) compact = false;        // (the float4 slices)
+            // bwd_prepared == 2: the forward cleared view->grad_clear; every output must lie inside it (the contract of that field)
+            if (grads_cleared && (arr[r].p < view->grad_clear || arr[r].p + arr[r].n > view->grad_clear + view->grad_clear_floats))
+                return fail(-1, "bwd_prepared = 2 but a gradient output lies outside GsrView.grad_clear%s", "");
             zr.p[zr.count] = arr[r].p; zr.n4[zr.count] = (uint32_t)(arr[r].n / 4); zr.tail[zr.count] = (uint32_t)(arr[r].n & 3);
             total4 += arr[r].n / 4; ++zr.count;
         }
         if (total4 >= 0x7fffffffull) compact = false;
         zr.total4 = (uint32_t)total4;
-        if (!compact) memset(&zr, 0, sizeof(zr));
+        if (!compact || grads_cleared) memset(&zr, 0, sizeof(zr));   // (nothing to clear here: the forward's compositing kernel did it)
     }
     prof_begin(stream);
     if (M > 0) {

@@ -85,6 +85,14 @@ struct ZeroRegions {
     int count;
 };
 
+// ONE caller-owned array the forward's per-tile compositing kernel clears on the side (GsrView.grad_clear: what the backward's
+// gradient outputs are carved from): workgroup k stores zeros to slice k of n4 float4s, `per` each (host: ceil(n4 / grid)).
+struct ZeroSide {
+    float4* p;
+    uint32_t n4;
+    uint32_t per;
+};
+
 struct ViewConst {           // by-value kernel argument (scalar registers)
     int W, H, gx, gy;
     float tanfovx, tanfovy, focal_x, focal_y;

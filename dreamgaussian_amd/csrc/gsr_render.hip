@@ -325,6 +325,20 @@ __device__ __forceinline__ void clear_slice(float4* __restrict__ zero4, uint32_t
     const uint32_t lo = blockIdx.x * per, hi = min(lo + per, zero_n);
     for (uint32_t i = lo + threadIdx.x; i < hi; i += THREADS) zero4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
+// ... and the array the backward's gradient outputs will be carved from (GsrView.grad_clear; 248 MB at 1M Gaussians / SH 3): written
+// once here, read by nobody before the per-Gaussian backward overwrites the live rows -- non-temporal stores. Round 5: these zeros
+// were stored under gsr_render_bwd_q2 first (+26 us there: it is bound by vector-instruction issue at four waves per SIMD and the
+// stores take issue slots from waves that want them); the serial walk has two thirds of its workgroups idle-tiled and its busy waves
+// wait for memory most of the time.
+template <uint32_t THREADS = 256u>
+__device__ __forceinline__ void clear_side(ZeroSide zs) {
+    if (zs.n4 == 0u) return;
+    typedef float gsr_v4f __attribute__((ext_vector_type(4)));
+    const gsr_v4f z = {0.f, 0.f, 0.f, 0.f};
+    gsr_v4f* __restrict__ dst = reinterpret_cast<gsr_v4f*>(zs.p);
+    const uint32_t lo = min(blockIdx.x * zs.per, zs.n4), hi = min(lo + zs.per, zs.n4);
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += THREADS) __builtin_nontemporal_store(z, dst + i);
+}
 
 // =========================================================================================
 // K5s: forward, the serial walk -- for views that fill the chip on their own (fwd_sequential_for in gsr_api.hip).
@@ -348,7 +362,7 @@ gsr_render_fwd_serial(const uint32_t* __restrict__ tile_off, const SplatRec* __r
                       uint32_t* __restrict__ plan_off, uint4* __restrict__ plan_items,
                       unsigned long long* __restrict__ plan_total, uint32_t plan_cap, unsigned long long qmask_views, uint32_t sink_rec,
                       const unsigned long long* __restrict__ counters, uint32_t capacity, uint32_t maxc_cap, ViewSplit vs,
-                      float4* __restrict__ zero4, uint32_t zero_n, uint32_t zero_per) {
+                      float4* __restrict__ zero4, uint32_t zero_n, uint32_t zero_per, ZeroSide zs) {
     if (counters[2] > (unsigned long long)capacity || counters[3] > (unsigned long long)maxc_cap) return;
     __shared__ float4 stage[4][3][GSR_RB + 2];
     __shared__ __attribute__((aligned(8))) uint8_t qlist[QUAD ? 4 : 1][4][80];
@@ -360,7 +374,7 @@ gsr_render_fwd_serial(const uint32_t* __restrict__ tile_off, const SplatRec* __r
     if (blockIdx.x == 0 && threadIdx.x == 0) plan_total[GSR_CNT_QMASK - GSR_CNT_PLAN] = qmask_views;   // the views whose records carry quad masks
     const int tg = (int)order[blockIdx.x];                // heaviest tiles first
     const int view = tg / vs.tiles_per_view;
-    if (!((vs.view_mask >> view) & 1u)) { clear_slice(zero4, zero_n, zero_per); return; }   // (workgroup-uniform) this view composites with the other instantiation
+    if (!((vs.view_mask >> view) & 1u)) { clear_slice(zero4, zero_n, zero_per); clear_side(zs); return; }   // (workgroup-uniform) this view composites with the other instantiation
     const int tile = tg - view * vs.tiles_per_view;
     const float* __restrict__ bg = vs.bg[view];
     {
@@ -557,13 +571,14 @@ gsr_render_fwd_serial(const uint32_t* __restrict__ tile_off, const SplatRec* __r
                 plan_items[base + q] = make_uint4((uint32_t)tg, tile_seg[tg] + q, start, q | ((min(1u << seg_shift, tile_n - (q << seg_shift)) - 1u) << 24));
     }
     clear_slice(zero4, zero_n, zero_per);
+    clear_side(zs);
 }
 template __global__ void gsr_render_fwd_serial<false>(const uint32_t*, const SplatRec*, const uint32_t*, int, int, int, float*, float*, float*, float*,
                                                       uint32_t*, float*, float*, const uint32_t*, const uint32_t*, int, uint32_t*, uint4*,
-                                                      unsigned long long*, uint32_t, unsigned long long, uint32_t, const unsigned long long*, uint32_t, uint32_t, ViewSplit, float4*, uint32_t, uint32_t);
+                                                      unsigned long long*, uint32_t, unsigned long long, uint32_t, const unsigned long long*, uint32_t, uint32_t, ViewSplit, float4*, uint32_t, uint32_t, ZeroSide);
 template __global__ void gsr_render_fwd_serial<true>(const uint32_t*, const SplatRec*, const uint32_t*, int, int, int, float*, float*, float*, float*,
                                                      uint32_t*, float*, float*, const uint32_t*, const uint32_t*, int, uint32_t*, uint4*,
-                                                     unsigned long long*, uint32_t, unsigned long long, uint32_t, const unsigned long long*, uint32_t, uint32_t, ViewSplit, float4*, uint32_t, uint32_t);
+                                                     unsigned long long*, uint32_t, unsigned long long, uint32_t, const unsigned long long*, uint32_t, uint32_t, ViewSplit, float4*, uint32_t, uint32_t, ZeroSide);
 
 // =========================================================================================
 // K5p: the serial walk with TWO waves per 8x8 block -- the host's choice for ONE view of 1 024 .. 2 047 tiles (finish_impl in
@@ -606,7 +621,7 @@ gsr_render_fwd_pair(const uint32_t* __restrict__ tile_off, const SplatRec* __res
                     uint32_t* __restrict__ plan_off, uint4* __restrict__ plan_items,
                     unsigned long long* __restrict__ plan_total, uint32_t plan_cap, unsigned long long qmask_views, uint32_t sink_rec,
                     const unsigned long long* __restrict__ counters, uint32_t capacity, uint32_t maxc_cap, ViewSplit vs,
-                    float4* __restrict__ zero4, uint32_t zero_n, uint32_t zero_per) {
+                    float4* __restrict__ zero4, uint32_t zero_n, uint32_t zero_per, ZeroSide zs) {
     if (counters[2] > (unsigned long long)capacity || counters[3] > (unsigned long long)maxc_cap) return;
     __shared__ float4 stage[4][2][3][GSR_RB + 2];                            // [block][buffer][a | b | c][slot]; slot 64 = the all-zero record
     __shared__ __attribute__((aligned(8))) uint8_t qlist[4][2][4][80];
@@ -618,7 +633,7 @@ gsr_render_fwd_pair(const uint32_t* __restrict__ tile_off, const SplatRec* __res
     if (blockIdx.x == 0 && threadIdx.x == 0) plan_total[GSR_CNT_QMASK - GSR_CNT_PLAN] = qmask_views;
     const int tg = (int)order[blockIdx.x];                // heaviest tiles first
     const int view = tg / vs.tiles_per_view;
-    if (!((vs.view_mask >> view) & 1u)) { clear_slice<512>(zero4, zero_n, zero_per); return; }
+    if (!((vs.view_mask >> view) & 1u)) { clear_slice<512>(zero4, zero_n, zero_per); clear_side<512>(zs); return; }
     const int tile = tg - view * vs.tiles_per_view;
     const float* __restrict__ bg = vs.bg[view];
     {
@@ -823,6 +838,7 @@ gsr_render_fwd_pair(const uint32_t* __restrict__ tile_off, const SplatRec* __res
                 plan_items[base + q] = make_uint4((uint32_t)tg, tile_seg[tg] + q, start, q | ((min(1u << seg_shift, tile_n - (q << seg_shift)) - 1u) << 24));
     }
     clear_slice<512>(zero4, zero_n, zero_per);
+    clear_side<512>(zs);
 }
 
 // The exact walk of list positions [lo, hi) of a tile for the lanes with done == false (lane = pixel, row-major 8x8 block at

@@ -103,6 +103,14 @@ def carve_gradients(N: int, widths, device):
     return flat, offs
 
 
+def _gradient_widths(K, k_rest, has_sh, has_col, has_sr, has_cov):
+    """Floats per Gaussian of each gradient, in the order they are carved: the parameter gradients first, the per-view means2D
+    gradient last -- views.allreduce_grads reduces the span of the parameter gradients in place and must not touch the screen-space one."""
+    k_sh = K - k_rest
+    return [3, 1, 3 * k_sh if has_sh else 0, 3 if has_col else 0, 3 if has_sr else 0, 4 if has_sr else 0,
+            6 if has_cov else 0, 3 * k_rest, 3]
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
@@ -142,10 +150,22 @@ class _RasterizeGaussians(torch.autograd.Function):
             # inference -- torch.no_grad() around the call (`grad_mode`, taken by the wrappers below BEFORE .apply: inside forward() grad
             # mode is always off, and needs_input_grad mirrors requires_grad whatever the mode), or no input that requires a gradient:
             # the backward's accumulators are not prepared
-            view, keep = _view_struct(rs, dev, ctx.raw, no_backward=not (grad_mode and any(ctx.needs_input_grad)))
+            want_bwd = bool(grad_mode and any(ctx.needs_input_grad))
+            view, keep = _view_struct(rs, dev, ctx.raw, no_backward=not want_bwd)
             if rest is not None:
                 view.shs_rest = rest.data_ptr()
                 keep.append(rest)
+            # the backward's gradients are carved out of ONE allocation; it is made HERE so that the forward's compositing kernel can
+            # clear it on the side where the backward would otherwise have to (GsrView.grad_clear: large scenes, whose per-Gaussian
+            # backward then writes the rows of the live Gaussians only). stats.bwd_prepared == 2 says it did; the block is handed to
+            # the first backward either way (cleared or not: the streaming per-Gaussian backward writes every element)
+            grad_flat = None
+            if want_bwd and N > 0:
+                widths = _gradient_widths(K, 0 if rest is None else int(rest.shape[1]), shc is not None, col is not None,
+                                          sc is not None, cov is not None)
+                grad_flat = carve_gradients(N, widths, dev)
+                view.grad_clear = grad_flat[0].data_ptr()
+                view.grad_clear_floats = grad_flat[0].numel()
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             rc = lib.gsr_forward(C.byref(view), N, K, _lib.ptr(m3), _lib.ptr(shc), _lib.ptr(col),
                                  _lib.ptr(op), _lib.ptr(sc), _lib.ptr(rot), _lib.ptr(cov),
@@ -155,11 +175,12 @@ class _RasterizeGaussians(torch.autograd.Function):
         _lib.check(rc, "gsr_forward")
         _last_stats.update(M=stats.num_instances, M_ref=stats.num_instances_ref,
                            V=stats.num_visible, max_tile=stats.max_tile_count, N=N, H=H, W=W, K=K,
-                           seg_shift=stats.seg_shift)
+                           seg_shift=stats.seg_shift, bwd_prepared=stats.bwd_prepared)
         ctx.raster_settings = rs
         ctx.view = (view, keep)            # the backward reuses the struct (and keeps its device constants alive)
         ctx.dims = (N, K)
         ctx.fwd_stats = stats
+        ctx.grad_flat = grad_flat          # (flat, offsets): taken by the first backward
         ctx.present = (shc is not None, col is not None, sc is not None, cov is not None)
         ctx.k_rest = 0 if rest is None else int(rest.shape[1])
         ctx.rest_shape = None if rest is None else sh_rest.shape
@@ -196,11 +217,14 @@ class _RasterizeGaussians(torch.autograd.Function):
         # one allocation for all gradients, each carved out at a 256-byte boundary
         k_rest = ctx.k_rest                              # split SH: dL/dfeatures_dc and dL/dfeatures_rest are separate tensors
         k_sh = K - k_rest
-        # layout: the parameter gradients first, the per-view means2D gradient last -- views.allreduce_grads reduces the span of
-        # the parameter gradients in place and must not touch the screen-space one
-        widths = [3, 1, 3 * k_sh if has_sh else 0, 3 if has_col else 0, 3 if has_sr else 0, 4 if has_sr else 0,
-                  6 if has_cov else 0, 3 * k_rest, 3]
-        flat, offs = carve_gradients(N, widths, dev)
+        widths = _gradient_widths(K, k_rest, has_sh, has_col, has_sr, has_cov)
+        if ctx.grad_flat is not None:      # the forward's allocation (cleared there when fwd_stats.bwd_prepared == 2); one-shot like bwd_prepared
+            flat, offs = ctx.grad_flat
+            ctx.grad_flat = None
+        else:                              # a second backward of this forward (retain_graph), or N == 0
+            flat, offs = carve_gradients(N, widths, dev)
+            if ctx.fwd_stats.bwd_prepared == 2:
+                ctx.fwd_stats.bwd_prepared = 1
         part = lambda i, *shape: flat[offs[i]:offs[i] + N * widths[i]].view(*shape)
         d_m3, d_op, d_m2 = part(0, N, 3), part(1, N, 1), part(8, N, 3)
         d_sh = part(2, N, k_sh, 3) if has_sh else None

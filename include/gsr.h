@@ -67,6 +67,14 @@ typedef struct GsrView {
      * the [N,1,3] part and dL_dshs_rest (required) the [N,K-1,3] part. NULL = the drop-in layout. */
     const float* shs_rest;
     float* dL_dshs_rest;
+    /* Optional (gsr_forward only; NULL / 0 = off): ONE caller-owned fp32 array of grad_clear_floats elements (16-byte aligned, a
+     * multiple of 4 elements) that gsr_backward's gradient outputs will be carved from. Where the backward would otherwise clear its
+     * outputs under its compositing kernel (the "live Gaussians only" per-Gaussian backward of large scenes: one view, concatenated
+     * SH layout, >= 64 MB of gradients) the FORWARD's per-tile compositing kernel stores the zeros instead, a slice per workgroup
+     * behind its own work -- it leaves HBM idle for longer. GsrStats.bwd_prepared comes back 2 when that happened; the backward is
+     * then handed the SAME view struct and outputs that lie inside the array, and clears nothing. */
+    float* grad_clear;
+    int64_t grad_clear_floats;
 } GsrView;
 
 /* GsrView.flags */
@@ -99,13 +107,14 @@ typedef struct GsrStats {
     int64_t bwd_prepared;       /* 1: the forward has cleared the backward's per-Gaussian accumulators inside `geom` (every workgroup
                                  * of its per-tile compositing kernel stores a slice of zeros behind its own work) -- gsr_backward
                                  * then neither allocates `tmp` nor clears anything. One-shot: a caller that runs a SECOND backward from the same forward state must pass
-                                 * 0 (the first one has accumulated into them); 0 also without GsrStats. -1: the forward ran with
-                                 * GSR_VIEW_NO_BACKWARD and left no state for a backward */
+                                 * 0 (the first one has accumulated into them); 0 also without GsrStats. 2: as 1, and the forward has also cleared
+                                 * GsrView.grad_clear (the array the backward's outputs are carved from; same one-shot rule). -1: the
+                                 * forward ran with GSR_VIEW_NO_BACKWARD and left no state for a backward */
 } GsrStats;
 
-/* Bumped whenever a struct of this header changes size or meaning (GsrStats grew in 3 and 4, GsrView.reserved became flags in 4). A caller built against another
+/* Bumped whenever a struct of this header changes size or meaning (GsrStats grew in 3 and 4, GsrView.reserved became flags in 4, GsrView grew in 5). A caller built against another
  * value must not call the library: dreamgaussian_amd/_lib.py checks gsr_abi_version() at load. */
-#define GSR_ABI_VERSION 4
+#define GSR_ABI_VERSION 5
 int gsr_abi_version(void);
 
 /* TEST HOOK -- not part of the drop-in surface. Forces one of the choices the library otherwise makes from the problem shape
@@ -127,6 +136,7 @@ int gsr_abi_version(void);
  *                  allows; the library picks 1 from 64 MB of gradient arrays on
  *   "scan_fold"    0 = the scan of the tile counts (K2) always runs as a kernel of its own, 1 = inside the scatter's launch whenever
  *                  the forward is speculative and composites from the tile order (the library: from 2M predicted instances on)
+ *   "grad_clear"   0 = the forward ignores GsrView.grad_clear (the backward's compositing kernel clears its outputs, as in ABI 4)
  *   "bwd_grid"     caps the grid of the backward's compositing kernel (TIMING experiments only: work beyond the cap is dropped)
  * Returns 0, or -1 for an unknown name. dreamgaussian_amd/_testing.py wraps it. */
 int gsr_testing_override(const char* name, int32_t value);

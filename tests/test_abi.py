@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layout_matches_header():
     from dreamgaussian_amd import _lib
-    assert ctypes.sizeof(_lib.GsrView) == 8 * 4 + 4 * 8 + 2 * 4 + 2 * 8
+    assert ctypes.sizeof(_lib.GsrView) == 8 * 4 + 4 * 8 + 2 * 4 + 2 * 8 + 8 + 8
     assert ctypes.sizeof(_lib.GsrAlloc) == 16
     assert ctypes.sizeof(_lib.GsrStats) == 56      # seven int64 (bwd_prepared: ABI 4)
 

@@ -554,6 +554,60 @@ def test_k6_compact_matches_lane_per_gaussian(gpu, hooks, case):
             assert int(zd.sum()) > 0 and int((~zd).sum()) > 0          # both kinds of rows exist, or the test is empty
 
 
+@pytest.mark.parametrize("mode", ["seq", "pair"])
+def test_gradient_arrays_cleared_by_the_forward(gpu, hooks, mode):
+    """Round 5 (ABI 5, GsrView.grad_clear): the ONE allocation the backward's gradients are carved from is made in the forward and
+    cleared by the serial walk's workgroups on the side (GsrStats.bwd_prepared == 2) wherever the live-Gaussians-only per-Gaussian
+    backward would otherwise have its compositing kernel clear it. Same gradients as with the backward clearing (test hook
+    grad_clear = 0) up to the order of render_bwd's atomics, exact zeros in the same rows, also on recycled memory full of NaNs; a
+    second backward of the same forward (retain_graph) clears for itself and gives the same numbers."""
+    N, deg, W, H = 30_000, 3, 320, 256
+    sc = O.make_scene(N, deg, 5, "blob")
+    sc["opacities"][: N // 2] = 0.95                     # plenty of hidden rows
+    S = O.make_settings(O.orbit_pose(10.0, -30.0, 2.0), W, H, sh_degree=deg)
+    w = weights_for(H, W)
+    hooks.set("fwd_mode", mode)
+    hooks.set("k6_compact", 1)
+    hooks.set("grad_clear", 0)
+    _, gd, st = run_hip(sc, S, gpu, w)
+    assert st["bwd_prepared"] == 1
+    hooks.set("grad_clear", None)
+    junk = [torch.full((N * 64 + 4096,), float("nan"), device=gpu) for _ in range(3)]
+    del junk
+    floors = grad_floors(sc, gd)
+    for rep in range(2):
+        _, gs, st = run_hip(sc, S, gpu, w)
+        assert st["bwd_prepared"] == 2, st
+        for k_ in gs:
+            assert torch.isfinite(gs[k_]).all(), (rep, k_)
+            scale = max(gd[k_].abs().max().item(), floors.get(k_, 0.0)) + 1e-30
+            assert (gs[k_] - gd[k_]).abs().max().item() <= 2e-5 * scale, (rep, k_)
+        zd = torch.stack([(gd[k_].reshape(N, -1) == 0).all(1) for k_ in gd]).all(0)
+        zs = torch.stack([(gs[k_].reshape(N, -1) == 0).all(1) for k_ in gs]).all(0)
+        assert torch.equal(zd, zs) and int(zd.sum()) > 0 and int((~zd).sum()) > 0
+    # retain_graph: the second backward must not reuse the block the first one returned its gradients in
+    t = {k: v.detach().to(gpu).requires_grad_(True) for k, v in sc.items()}
+    m2d = torch.zeros(N, 3, device=gpu, requires_grad=True)
+    out = D.GaussianRasterizer(raster_settings=settings_to(S, gpu))(means3D=t["means3D"], means2D=m2d, shs=t["shs"], colors_precomp=None,
+                                                                    opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"], cov3D_precomp=None)
+    wg = [x.to(gpu) for x in w]
+    torch.autograd.backward([out[0], out[2], out[3]], wg, retain_graph=True)
+    first = {k: v.grad.clone() for k, v in t.items()}
+    for v in t.values():
+        v.grad = None
+    junk = [torch.full((N * 64 + 4096,), float("nan"), device=gpu) for _ in range(3)]
+    del junk
+    torch.autograd.backward([out[0], out[2], out[3]], wg)
+    for k_, v in t.items():
+        assert torch.isfinite(v.grad).all(), k_
+        scale = max(first[k_].abs().max().item(), floors.get(k_, 0.0)) + 1e-30
+        assert (v.grad - first[k_]).abs().max().item() <= 2e-5 * scale, k_
+    # (rows, not attributes: one attribute may cancel to zero by arithmetic and the two runs' atomics add in different orders)
+    z1 = torch.stack([(first[k_].reshape(N, -1) == 0).all(1) for k_ in t]).all(0)
+    z2 = torch.stack([(t[k_].grad.reshape(N, -1) == 0).all(1) for k_ in t]).all(0)
+    assert torch.equal(z1, z2) and int(z1.sum()) > 0
+
+
 @pytest.mark.parametrize("mode", ["seg", "seq"])
 @pytest.mark.parametrize("shift", [6, 7, 8])
 def test_segment_lengths_match_oracle(gpu, hooks, shift, mode):
