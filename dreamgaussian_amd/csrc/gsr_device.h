@@ -93,6 +93,21 @@ struct ZeroSide {
     uint32_t per;
 };
 
+// The array the backward's gradient outputs will be carved from (GsrView.grad_clear; 248 MB at 1M Gaussians / SH 3): written
+// once here, read by nobody before the per-Gaussian backward overwrites the live rows -- non-temporal stores. Round 5: these zeros
+// were stored under gsr_render_bwd_q2 first (+26 us there: it is bound by vector-instruction issue at four waves per SIMD and the
+// stores take issue slots from waves that want them); the serial walk has two thirds of its workgroups idle-tiled and its busy waves
+// wait for memory most of the time.
+template <uint32_t THREADS = 256u>
+__device__ __forceinline__ void clear_side(ZeroSide zs) {
+    if (zs.n4 == 0u) return;
+    typedef float gsr_v4f __attribute__((ext_vector_type(4)));
+    const gsr_v4f z = {0.f, 0.f, 0.f, 0.f};
+    gsr_v4f* __restrict__ dst = reinterpret_cast<gsr_v4f*>(zs.p);
+    const uint32_t lo = min(blockIdx.x * zs.per, zs.n4), hi = min(lo + zs.per, zs.n4);
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += THREADS) __builtin_nontemporal_store(z, dst + i);
+}
+
 struct ViewConst {           // by-value kernel argument (scalar registers)
     int W, H, gx, gy;
     float tanfovx, tanfovy, focal_x, focal_y;
