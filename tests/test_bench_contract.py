@@ -52,14 +52,17 @@ def test_committed_traffic_file_uses_the_calibrated_read_factors():
     from dreamgaussian_amd import build
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
     doc = json.load(open(path))
-    if doc["source_digest"] != build.kernel_digest():
-        import pytest
-        pytest.skip("profiles/pmc_traffic.json was collected with other kernel sources: bench.py reports traffic null until "
-                    "the PMC passes are re-collected (tools/gpu_r3.sh pmc)")
+    # a stale file FAILS here (round-4 review: it used to skip, and the driver's bench line lost its `roofline.traffic`): whoever edits
+    # a kernel re-collects the PMC passes in the same GPU call (`bash tools/gpu_r5.sh pmc`) and commits profiles/pmc_traffic.json
+    assert doc["source_digest"] == build.kernel_digest(), \
+        "profiles/pmc_traffic.json was collected with other kernel sources: bench.py would report roofline.traffic = null; " \
+        "re-collect with `bash tools/gpu_r5.sh pmc` on the GPU box and commit the file"
     rb = doc["1M-800-sh3/blob"]["render_bwd"]
     assert rb["read_factor"] == 1.0 and abs(rb["hbm_bytes"] - (rb["read_bytes_raw"] + rb["write_bytes"])) < 1.0
-    k6 = doc["1M-800-sh3/blob"]["preprocess_bwd<false, false>"]
-    assert k6["read_factor"] == 2.0
+    k1 = doc["1M-800-sh3/blob"]["preprocess_fwd<false>"]
+    assert k1["read_factor"] == 2.0                       # a streaming kernel: coalesced reads are counted at half
+    k6 = doc["1M-800-sh3/blob"]["preprocess_bwd_compact<false>"]
+    assert k6["read_factor"] == 1.0                       # gathers of the live Gaussians' rows
 
 
 def test_order_morton_permutes_the_render_inputs():

@@ -64,7 +64,8 @@ def main():
                 # coalesced reads (4 or 16 B per lane) are counted at 1/2; random 64-byte record gathers at >= 1 (the counter
                 # tallies 64-B requests and a record read as 3-4 loads draws 1.8-2.1 of them); writes at 1 (streaming) and at
                 # their 32-byte sectors (scattered 8-byte stores)
-                gather = any(t in fam for t in ("render_fwd", "render_bwd"))
+                # (gsr_preprocess_bwd_compact gathers the rows of the live Gaussians: 4..192-byte accesses at random rows)
+                gather = any(t in fam for t in ("render_fwd", "render_bwd", "preprocess_bwd_compact"))
                 f = 1.0 if gather else 2.0
                 traffic[fam] = {"read_bytes_raw": rd_raw, "read_bytes_x2": 2 * rd_raw, "write_bytes": wr, "read_factor": f,
                                 "hbm_bytes": f * rd_raw + wr}
