@@ -51,8 +51,9 @@ def alg_bytes(N, K, V, M, P, grads_written_by="preprocess_bwd"):
     """Algorithmic (compulsory) HBM bytes of SURVEY 8(d), split per kernel so that the parts
     add up to B_alg(fwd+bwd) = N(3 A_in + 16) + 212 V + 24 M + 56 P.
     `grads_written_by`: the kernel that stores the gradient arrays, N (A_in + 12) bytes of the total. Round 5: for large scenes the
-    compositing kernel of the backward clears them on the side and the per-Gaussian kernel only visits the Gaussians that carry a
-    gradient (gsr_preprocess_bwd_compact): the compulsory write of every gradient element is then render_bwd's, and the line says so."""
+    per-Gaussian backward only visits the Gaussians that carry a gradient (gsr_preprocess_bwd_compact) and a compositing kernel -- the
+    forward's, through GsrView.grad_clear, or the backward's -- stores the zeros of all the others on the side: the compulsory write
+    of every gradient element is then that kernel's (main() prints both attributions)."""
     A_in = 44 + 12 * K
     per = {
         "preprocess_fwd": N * (A_in + 4) + 44 * V,      # inputs read, radii + 44 B state written
@@ -497,10 +498,13 @@ def main():
             e[1] = max(e[1], n)
             fam_launches[fam] = fam_launches.get(fam, 0) + n / a.steps
         P = wl["H"] * wl["W"]
-        # who stores the gradient arrays: the per-Gaussian backward, or (its "live Gaussians only" variant ran) the compositing kernel
-        # (the line's `frac` keeps SURVEY 8(d)'s split -- the gradient arrays priced with the per-Gaussian backward -- whoever clears them;
-        # what the dominant kernel reaches when the 248 MB it really clears are counted is printed beside it)
-        gw = "render_bwd" if "preprocess_bwd_live" in raw else "preprocess_bwd"
+        # who stores the zeros of the gradient arrays: the per-Gaussian backward itself (it streams every Gaussian), or -- its "live
+        # Gaussians only" variant ran -- the forward's compositing kernel (GsrStats.bwd_prepared == 2: GsrView.grad_clear) / the
+        # backward's. The line's `frac` keeps SURVEY 8(d)'s split (the gradient arrays priced with the per-Gaussian backward) whoever
+        # clears them; when the DOMINANT kernel is the one that clears, its figure with those 248 MB counted is printed beside it.
+        gw = "preprocess_bwd"
+        if "preprocess_bwd_live" in raw:
+            gw = "render_fwd" if st.get("bwd_prepared") == 2 else "render_bwd"
         ab = alg_bytes(wl["N"], K, st["V"], st["M_ref"], P)
         ab_gw = alg_bytes(wl["N"], K, st["V"], st["M_ref"], P, gw)
         per_step = {k: v[0] / a.steps for k, v in kern.items()}
@@ -529,9 +533,9 @@ def main():
                         alg_bytes_per_launch=ab[dom], instances_priced="M_ref (reference emission rule, SURVEY 8(d))",
                         alg_bytes_per_launch_emitted=ab_emit[dom],
                         frac_emitted=round(ab_emit[dom] / (per_step[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                        gradient_arrays_written_by=gw,
+                        gradient_arrays_cleared_by=gw,
                         **({"frac_with_the_gradient_arrays_it_clears": round(ab_gw[dom] / (per_step[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
-                           if dom == gw == "render_bwd" else {}),
+                           if dom == gw else {}),
                         avg_launch_ms=round(per_step[dom], 4), launches_per_step=round(fam_launches.get(dom, 1)),
                         kernels={k: round(v, 4) for k, v in kern_raw.items() if kernel_family(k) == dom})
         ach_p = ab["total"] / (dt / a.steps) / 1e9
