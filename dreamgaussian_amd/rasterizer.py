@@ -210,8 +210,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = ctx.raster_settings
         dev = radii.device                 # (m3 is an empty placeholder when N == 0)
         H, W = int(rs.image_height), int(rs.image_width)
+        # (every avoided tensor op is ~1 us of host time, and at DreamGaussian's sizes the step is host-bound: an incoming gradient
+        # that is already fp32 and contiguous is taken as it is, a gradient view is ONE as_strided, a reshape to the shape it has is skipped)
         z = lambda g, shape: (torch.zeros(shape, dtype=torch.float32, device=dev) if g is None
-                              else g.to(torch.float32).contiguous())
+                              else (g if g.dtype is torch.float32 and g.is_contiguous() else g.to(torch.float32).contiguous()))
         gc, gd, ga = z(grad_color, (3, H, W)), z(grad_depth, (1, H, W)), z(grad_alpha, (1, H, W))
         # K6 writes every element of every gradient (exact zeros for culled Gaussians): no memset
         # one allocation for all gradients, each carved out at a 256-byte boundary
@@ -225,7 +227,10 @@ class _RasterizeGaussians(torch.autograd.Function):
             flat, offs = carve_gradients(N, widths, dev)
             if ctx.fwd_stats.bwd_prepared == 2:
                 ctx.fwd_stats.bwd_prepared = 1
-        part = lambda i, *shape: flat[offs[i]:offs[i] + N * widths[i]].view(*shape)
+        def part(i, *shape):                             # gradient i: N x widths[i] floats at offs[i], contiguous
+            if len(shape) == 2:
+                return flat.as_strided(shape, (shape[1], 1), offs[i])
+            return flat.as_strided(shape, (shape[1] * shape[2], shape[2], 1), offs[i])
         d_m3, d_op, d_m2 = part(0, N, 3), part(1, N, 1), part(8, N, 3)
         d_sh = part(2, N, k_sh, 3) if has_sh else None
         d_rest = part(7, N, k_rest, 3) if k_rest else None
@@ -251,7 +256,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             ctx.fwd_stats.bwd_prepared = 0     # one-shot: a second backward of this forward (retain_graph) clears its own accumulators
             _lib.check(rc, "gsr_backward")
         s = ctx.shapes
-        rs_ = lambda g, shape: None if g is None or shape is None else g.reshape(shape)
+        rs_ = lambda g, shape: None if g is None or shape is None else (g if g.shape == shape else g.reshape(shape))
         return (rs_(d_m3, s[0]), rs_(d_m2, s[1]) if tuple(s[1]) == (N, 3) else None, rs_(d_sh, s[2]),
                 rs_(d_col, s[3]), rs_(d_op, s[4]), rs_(d_sc, s[5]), rs_(d_rot, s[6]), rs_(d_cov, s[7]),
                 None, None, rs_(d_rest, ctx.rest_shape), None)
