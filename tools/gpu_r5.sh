@@ -70,9 +70,9 @@ quick)
       -k "${QUICK_K:-forward_backward_match_oracle or committed_golden or depth_ties or segment_lengths or stage1_trained or cfg1_100k_blob or (test_fuzz and not large)}" > gpurun_out/pytest_abquick.log 2>&1
   grep -a "passed\|failed\|FAILED\|Error\|assert\|s call" gpurun_out/pytest_abquick.log | cut -c1-300 | tail -24;;
 pair)
-  # the experimental two-waves-per-block forward (gsr_render_fwd_pair, test hook fwd_mode = 3): parity gate first, then the A/B
-  echo "== pytest -k pair (GSR_TEST_EXPERIMENTAL=1)"
-  GSR_TEST_EXPERIMENTAL=1 timeout 300 python -m pytest tests/test_parity_gpu.py -m gpu -q -x -p no:cacheprovider --tb=short -rf -k pair > gpurun_out/pytest_pair.log 2>&1
+  # the two-waves-per-block forward (gsr_render_fwd_pair, test hook fwd_mode = 3): bit-identity test first, then the A/B against the serial walk
+  echo "== pytest -k pair"
+  timeout 300 python -m pytest tests/test_parity_gpu.py -m gpu -q -x -p no:cacheprovider --tb=short -rf -k pair > gpurun_out/pytest_pair.log 2>&1
   tail -15 gpurun_out/pytest_pair.log | cut -c1-300
   if grep -q " passed" gpurun_out/pytest_pair.log && ! grep -q "failed" gpurun_out/pytest_pair.log; then
     for wl in 1M-800-sh3 1M-800-sh3:trained 100k-800-sh3 250k-512-sh0; do
