@@ -54,10 +54,24 @@ def _f32c(t: Optional[torch.Tensor], device) -> Optional[torch.Tensor]:
         return None
     if t.device != device:
         raise RuntimeError(f"all rasterizer inputs must be on {device}, got {t.device}")
-    t = t.detach()
     if t.dtype is torch.float32 and t.is_contiguous():
-        return t
-    return t.to(torch.float32).contiguous()
+        return t                                          # (no detach(): grad mode is off inside forward(), and a tensor op is ~1 us of host)
+    return t.detach().to(torch.float32).contiguous()
+
+
+class _NoGuard:
+    def __enter__(self): return None
+    def __exit__(self, *a): return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def _on_device(dev):
+    """`with torch.cuda.device(dev)` only when dev is not the current device already: the guard is ~4 us of Python per use, and the
+    step of a small scene is host-bound."""
+    idx = dev.index
+    return _NO_GUARD if (idx is None or torch.cuda.current_device() == idx) else torch.cuda.device(dev)
 
 
 def _view_struct(rs: GaussianRasterizationSettings, device, raw: bool = False, no_backward: bool = False):
@@ -146,7 +160,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         radii = torch.empty(N, dtype=torch.int32, device=dev)     # every element written by K1
         geom, binb, img = _lib.Scratch(dev), _lib.Scratch(dev), _lib.Scratch(dev)
         stats = _lib.GsrStats()
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             # inference -- torch.no_grad() around the call (`grad_mode`, taken by the wrappers below BEFORE .apply: inside forward() grad
             # mode is always off, and needs_input_grad mirrors requires_grad whatever the mode), or no input that requires a gradient:
             # the backward's accumulators are not prepared
@@ -240,7 +254,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         d_cov = part(6, N, 6) if has_cov else None
         if N > 0:
             tmp = _lib.Scratch(dev)
-            with torch.cuda.device(dev):
+            with _on_device(dev):
                 view, keep = ctx.view
                 if d_rest is not None:
                     view.dL_dshs_rest = d_rest.data_ptr()
