@@ -565,7 +565,10 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
         // at 2 500 tiles it does nothing (1M / 800^2 0.1404 -> 0.1385, trained-like 0.1032 -> 0.1033: three waves per SIMD already, and
         // the blender's and the tester's halves of a round are about equally long) and the plain walk stays. Same bits either way
         // (tests/test_parity_gpu.py::test_pair_forward_is_bit_identical_to_the_serial_walk). Test hook "fwd_mode": 1 = never, 3 = always.
-        const bool pair = ov(OV_FWD_MODE) == 3 || (ov(OV_FWD_MODE) < 0 && B == 1 && TA < 2048);
+        // ... and for a single view whose launch also stores the backward's gradient block (side.n4, forward_impl): with 248 MB of
+        // zeros leaving under it the walk's gathers queue behind them and twice the waves hide more of that -- 1M / 800^2, same box,
+        // serial -> pair: 0.1522 -> 0.1459 ms (step 0.5575 -> 0.5519); trained-like 0.1100 -> 0.1102.
+        const bool pair = ov(OV_FWD_MODE) == 3 || (ov(OV_FWD_MODE) < 0 && B == 1 && (TA < 2048 || side.n4 > 0u));
         if (mask_q && pair) {
             vs.view_mask = mask_q;
             hipLaunchKernelGGL(gsr_render_fwd_pair, dim3(TA), dim3(512), 0, stream, tile_off, recs, sorted_ids, W, H, vc.gx,

@@ -121,8 +121,8 @@ int gsr_abi_version(void);
  * (process-wide; value -1 = the library decides again). Nothing is read from the process environment: "fwd_mode" and "seg_shift"
  * decide where the per-pixel sums are cut, i.e. the rounding of the results.
  *   "fwd_mode"     1 = serial walk (gsr_render_fwd_serial), 2 = depth-segmented forward (K5a/b/c), 3 = serial walk with a tester
- *                  and a blender wave per 8x8 block (gsr_render_fwd_pair: the library's choice for ONE view of 1 024 .. 2 047 tiles;
- *                  the same bits as 1)
+ *                  and a blender wave per 8x8 block (gsr_render_fwd_pair: the library's choice for ONE view of 1 024 .. 2 047 tiles, or of
+ *                  any size when its launch also clears GsrView.grad_clear; the same bits as 1)
  *   "seg_shift"    6..8: log2 of the depth-segment length
  *   "fwd_lists"    1 = 8x8 block lists, 2 = quad lists in the forward compositing
  *   "fwd_hints"    1 = off, 2 = every segment behind a tile's first skipped (the chaining kernel walks them all)
