@@ -525,8 +525,13 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
             prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<8192, 1024, 2048>), dim3(TA), dim3(1024), lds_m, stream, tile_off, entries, sorted_ids, 0u, 8192u, counters, (uint32_t)M, (const uint2*)(gbuf + GL.order_span));
             LAUNCH_CHECK(view, stream, "tile_sort_medium");
         }
+        // The tiles come longest list first (order_span), so the lists of more than L entries sit at the first <= M / (L + 1) positions:
+        // the launch of the 16 384 class is that small (M here is the capacity the lists were laid out for: more instances than that and every kernel
+        // leaves; the speculative forward launches the 16 384 class whenever the
+        // previous frame's longest list x 1.25 exceeds 8 192 -- 2 500 workgroups of 128 KiB that all leave at once cost 5-7 us at 1M).
+        const unsigned grid_l = (unsigned)((unsigned long long)TA < M / 8193ull + 1ull ? (unsigned long long)TA : M / 8193ull + 1ull);
         if (maxc > 8192) {
-            prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<16384, 1024, 2048>), dim3(TA), dim3(1024), lds_l, stream, tile_off, entries, sorted_ids, 8192u, 16384u, counters, (uint32_t)M, (const uint2*)(gbuf + GL.order_span));
+            prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<16384, 1024, 2048>), dim3(grid_l), dim3(1024), lds_l, stream, tile_off, entries, sorted_ids, 8192u, 16384u, counters, (uint32_t)M, (const uint2*)(gbuf + GL.order_span));
             LAUNCH_CHECK(view, stream, "tile_sort_large");
         }
         if (maxc > 16384) {
