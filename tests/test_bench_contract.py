@@ -82,3 +82,31 @@ def test_order_morton_permutes_the_render_inputs():
     # and main() routes a.order into it for the render step
     src = open(bench.__file__).read()
     assert src.count("build_inputs(wl, a.kind, dev, azimuth, a.order)") == 2
+
+
+def test_alg_bytes_attribution_keeps_the_total():
+    """Whoever stores the zeros of the gradient arrays (the per-Gaussian backward, or -- round 5 -- a compositing kernel on the side),
+    the compulsory bytes of SURVEY 8(d) add up to the same total, and the default split is the survey's."""
+    N, K, V, M, P = 1_000_000, 16, 1_000_000, 4_221_565, 640_000
+    base = bench.alg_bytes(N, K, V, M, P)
+    assert base["render_bwd"] == 84 * V + 8 * M + 28 * P == 135_692_520        # what BENCH_r0N's roofline.frac is computed from
+    for who in ("render_fwd", "render_bwd", "preprocess_bwd"):
+        ab = bench.alg_bytes(N, K, V, M, P, who)
+        assert ab["total"] == base["total"]
+        assert ab[who] - (base[who] - (N * (44 + 12 * K + 12) if who == "preprocess_bwd" else 0)) == N * (44 + 12 * K + 12)
+
+
+def test_issue_budget_classes():
+    """tools/issue_budget.py: the issue class of a vector instruction as profiles/r04_valu_rates.txt groups them."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("issue_budget", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "issue_budget.py"))
+    ib = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ib)
+    c = ib.classify
+    assert c("v_fmac_f32_e32 v61, v62, v59") == "plain" and c("v_lshl_add_u32 v70, v111, 4, v3") == "plain"
+    assert c("v_lshl_add_u32 v70, v111, 4, s73") == "second"                    # an SGPR source
+    assert c("v_med3_f32 v112, v84, 0, v103") == "second" and c("v_cmp_le_f32_e64 s[8:9], s76, v58") == "second"
+    assert c("v_cndmask_b32_e32 v84, 0, v58, vcc") == "second"
+    assert c("v_exp_f32 v58, v61") == "trans" and c("v_rcp_f32 v119, v114") == "trans"
+    assert c("v_mov_b32_dpp v82, v68 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1") == "dpp"
+    assert c("ds_read_b128 v[26:29], v52 offset:1056") == "lds" and c("s_waitcnt lgkmcnt(0)") == "wait" and c("s_and_b64 s[8:9], vcc, s[8:9]") == "salu"
