@@ -11,7 +11,8 @@ densify_and_clone / densify_and_split / morton_order / reorder_gaussians (densif
 indexings and `torch.cat`s).
 """
 from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer,
-                         rasterize_gaussians, rasterize_gaussians_raw, rasterize_gaussians_split, last_stats)
+                         rasterize_gaussians, rasterize_gaussians_raw, rasterize_gaussians_split, last_stats,
+                         set_async_forward)
 from .knn import distCUDA2
 from .batched import rasterize_views
 from .fields import extract_fields
@@ -20,5 +21,5 @@ from .densify import (add_densification_stats, compact_mask, gather_rows, prune_
 from .optim import FusedAdam
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_gaussians_raw", "rasterize_gaussians_split",
-           "last_stats", "distCUDA2", "rasterize_views", "extract_fields", "add_densification_stats", "compact_mask", "gather_rows", "prune_points",
+           "last_stats", "set_async_forward", "distCUDA2", "rasterize_views", "extract_fields", "add_densification_stats", "compact_mask", "gather_rows", "prune_points",
            "densification_postfix", "densify_and_clone", "densify_and_split", "morton_order", "reorder_gaussians", "FusedAdam"]

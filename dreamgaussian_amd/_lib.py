@@ -13,10 +13,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSR_LIB") or os.path.join(_HERE, "libgsr.so")
 
 GSR_MAX_VIEWS = 16      # include/gsr.h
-GSR_ABI_VERSION = 5     # include/gsr.h
-GSR_VIEW_VIEWMATRIX_T, GSR_VIEW_PROJMATRIX_T, GSR_VIEW_NO_BACKWARD = 1, 2, 4   # GsrView.flags
+GSR_ABI_VERSION = 6     # include/gsr.h
+GSR_VIEW_VIEWMATRIX_T, GSR_VIEW_PROJMATRIX_T, GSR_VIEW_NO_BACKWARD, GSR_VIEW_ASYNC_STATS = 1, 2, 4, 8   # GsrView.flags
 
-EXPORTS = ("gsr_forward", "gsr_backward", "gsr_forward_views", "gsr_backward_views", "gsr_mark_visible", "gsr_dist2", "gsr_extract_fields", "gsr_densify_stats",
+EXPORTS = ("gsr_forward", "gsr_forward_complete", "gsr_backward", "gsr_forward_views", "gsr_backward_views", "gsr_mark_visible", "gsr_dist2", "gsr_extract_fields", "gsr_densify_stats",
            "gsr_adam_step", "gsr_mask_compact", "gsr_gather_rows", "gsr_concat_rows",
            "gsr_profile_enable", "gsr_profile_read", "gsr_profile_reset",
            "gsr_geom_bytes", "gsr_img_bytes", "gsr_last_error", "gsr_version", "gsr_abi_version", "gsr_testing_override")
@@ -57,7 +57,7 @@ class GsrConcatTensor(C.Structure):
 class GsrStats(C.Structure):
     _fields_ = [("num_instances", C.c_int64), ("num_instances_ref", C.c_int64),
                 ("num_visible", C.c_int64), ("max_tile_count", C.c_int64), ("bin_capacity", C.c_int64),
-                ("seg_shift", C.c_int64), ("bwd_prepared", C.c_int64)]
+                ("seg_shift", C.c_int64), ("bwd_prepared", C.c_int64), ("speculated", C.c_int64), ("pending", C.c_int64)]
 
 
 _lock = threading.Lock()
@@ -90,6 +90,8 @@ def load() -> C.CDLL:
         lib.gsr_forward.restype = C.c_int
         lib.gsr_forward.argtypes = [C.POINTER(GsrView), i32, i32] + [p] * 7 + [p] * 4 + \
             [GsrAlloc, GsrAlloc, GsrAlloc, C.POINTER(GsrStats), vp]
+        lib.gsr_forward_complete.restype = C.c_int
+        lib.gsr_forward_complete.argtypes = [C.POINTER(GsrStats)]
         lib.gsr_backward.restype = C.c_int
         lib.gsr_backward.argtypes = [C.POINTER(GsrView), i32, i32] + [p] * 7 + [p] + [p] * 3 + \
             [p] * 3 + [C.POINTER(GsrStats)] + [p] * 8 + [GsrAlloc, vp]

@@ -90,9 +90,8 @@ class _RasterizeViews(torch.autograd.Function):
         m3, shc, col, op, sc, rot, cov, radii, geom, binb, img = ctx.saved_tensors[:11]
         has_sh, has_col, has_sr, has_cov = ctx.present
         dev = radii.device
-        z = lambda g, shape: (torch.zeros(shape, dtype=torch.float32, device=dev) if g is None
-                              else g.to(torch.float32).contiguous())
-        gc, gd, ga = z(g_color, (B, 3, H, W)), z(g_depth, (B, 1, H, W)), z(g_alpha, (B, 1, H, W))
+        z = lambda g: None if g is None else g.to(torch.float32).contiguous()     # (None -> NULL = zeros: include/gsr.h, ABI 6)
+        gc, gd, ga = z(g_color), z(g_depth), z(g_alpha)
         f = lambda *s: (torch.empty if N > 0 else torch.zeros)(*s, dtype=torch.float32, device=dev)
         d_m3, d_m2, d_op = f(N, 3), f(B, N, 3), f(N, 1)
         d_sh = f(N, K, 3) if has_sh else None

@@ -27,9 +27,54 @@ constexpr int kCounterWords = 8 + 2 * GSR_MAX_VIEWS;  // device counters the hos
 constexpr int kWalkCounter = kCounterWords;            // device only: walk items handed from the chaining kernel to the fix-up kernel
 constexpr int kZeroedFlag = kCounterWords + 4;          // device only: K1's "tile counts / cursors / counters are cleared" tag of the launch (gsr_preprocess.hip)
 constexpr int kCounterSlots = kCounterWords + 6;        // u64 words of the counter block
-struct FwdHint { bool valid = false; int N = 0, H = 0, W = 0, B = 0; unsigned long long M = 0, maxc = 0; unsigned long long per_view[2 * GSR_MAX_VIEWS] = {}; };
-thread_local FwdHint g_hint;                            // this thread's previous gsr_forward: predicts the next one's list sizes
+// What this thread's earlier gsr_forward calls of one problem shape left behind: predicts the next one's list sizes. A TABLE keyed by
+// (N, H, W, views), least recently used slot replaced: DreamGaussian's own loop renders the 256^2 known view and then a 128^2 / 256^2 /
+// 512^2 novel view EVERY iteration (main.py:198-216, :211) -- with one slot (rounds 2-5) every forward of the 70 % of iterations whose
+// two resolutions differ found the other shape's hint and took the wait-first path.
+struct FwdHint {
+    bool valid = false; int N = 0, H = 0, W = 0, B = 0;
+    unsigned long long M = 0, maxc = 0;                 // the most recent call
+    unsigned long long M_hi = 0, maxc_hi = 0;           // the largest of the recent calls, decaying (what an asynchronous forward sizes from)
+    unsigned long long per_view[2 * GSR_MAX_VIEWS] = {};
+    unsigned long long stamp = 0;
+};
+constexpr int kHintSlots = 8;
+thread_local FwdHint g_hints[kHintSlots];
+thread_local unsigned long long g_hint_clock = 0;
+FwdHint* hint_find(int N, int H, int W, int B) {
+    for (auto& h : g_hints) if (h.valid && h.N == N && h.H == H && h.W == W && h.B == B) return &h;
+    return nullptr;
+}
+void hint_update(int N, int H, int W, int B, unsigned long long M, unsigned long long maxc, const unsigned long long* per_view) {
+    FwdHint* h = hint_find(N, H, W, B);
+    if (!h) {                                           // an empty slot, else the least recently used one
+        h = &g_hints[0];
+        for (auto& c : g_hints) { if (!c.valid) { h = &c; break; } if (c.stamp < h->stamp) h = &c; }
+        *h = FwdHint();
+        h->valid = true; h->N = N; h->H = H; h->W = W; h->B = B;
+    }
+    h->M = M; h->maxc = maxc;
+    h->M_hi = M > h->M_hi - h->M_hi / 8 ? M : h->M_hi - h->M_hi / 8;              // max(this call, 7/8 of the running maximum)
+    h->maxc_hi = maxc > h->maxc_hi - h->maxc_hi / 8 ? maxc : h->maxc_hi - h->maxc_hi / 8;
+    for (int v = 0; v < 2 * B; ++v) h->per_view[v] = per_view[v];
+    h->stamp = ++g_hint_clock;
+}
+void hint_drop(int N, int H, int W, int B) { if (FwdHint* h = hint_find(N, H, W, B)) h->valid = false; }
 constexpr unsigned long long kFlagSentinel = 0xffffffffffffffffull;
+
+// An ASYNCHRONOUS forward (GSR_VIEW_ASYNC_STATS) returns before its counters have arrived. They land in this thread's pinned block;
+// whoever needs them next -- the thread's next gsr_forward (it re-arms the block), gsr_forward_complete -- waits for them then, checks
+// the speculation and files the statistics here.
+struct PendingFwd {
+    bool on = false; long long serial = 0;
+    int N = 0, H = 0, W = 0, B = 0;
+    unsigned long long cap = 0, capc = 0;
+    hipStream_t stream = nullptr;
+};
+struct CompletedFwd { long long serial = 0; int rc = 0; unsigned long long M_ref = 0, V = 0, M = 0, maxc = 0; };
+thread_local PendingFwd g_pending;
+thread_local CompletedFwd g_completed;
+thread_local long long g_async_serial = 0;
 
 int fail(int code, const char* fmt, const char* a = "", long long b = 0) {
     snprintf(g_err, sizeof(g_err), fmt, a, b);
@@ -435,7 +480,8 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
                 char* gbuf, char* ibuf, GsrAlloc bin, int shift,
                 const unsigned long long* per_view /* (M_ref, V) of every view */,
                 unsigned long long cap, unsigned long long maxc, bool prepare_bwd, bool scan_in_scatter, int counter_words, hipStream_t stream,
-                ZeroSide side = ZeroSide{nullptr, 0u, 0u} /* GsrView.grad_clear, when the serial walk is to clear it (forward_impl) */) {
+                ZeroSide side = ZeroSide{nullptr, 0u, 0u} /* GsrView.grad_clear, when the serial walk is to clear it (forward_impl) */,
+                bool poison = false /* an asynchronous forward: lists that do not fit `cap` / `maxc` leave NaN images, not unwritten ones */) {
     const GsrView* view = views;
     const ViewConst vc = make_view(view);
     const int H = vc.H, W = vc.W;
@@ -465,7 +511,7 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
     const bool keep_state = prepare_bwd || !sequential;
     const BinLayout BL = bin_layout((size_t)M, TA, shift, keep_state);
     if (BL.items >= 0x7fffffffull) return fail(-5, "too many depth segments (%s%lld)", "", (long long)BL.items);
-    const unsigned long long no_state_bit = keep_state ? 0ull : (1ull << 63);
+    const unsigned long long no_state_bit = (keep_state ? 0ull : (1ull << 63)) | (poison ? (1ull << 62) : 0ull);
     const uint32_t sink_rec = keep_state ? (uint32_t)BL.items : 0u;     // the first of the three spare records: the serial walk's store sink
     char* bbuf = (char*)bin.resize(bin.ctx, BL.total);
     if (!bbuf) return fail(-4, "bin scratch allocation failed%s", "");
@@ -628,7 +674,7 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
     uint2* walk_items = (uint2*)(bbuf + BL.walk_items);
     hipLaunchKernelGGL(gsr_render_fwd_combine, dim3(TA), dim3(256), 0, stream, tile_off, recs, sorted_ids, W, H, vc.gx,
                        out_color, out_depth, out_alpha, final_T, n_contrib, totals, ckpt, tile_seg, order, shift,
-                       plan_off, plan_tile, counters + 4, (uint32_t)BL.plan_cap, walk_items, counters + kWalkCounter, counters, (uint32_t)M, maxc_cap, vs, zero4, zero_n, zero_per);
+                       plan_off, plan_tile, counters + 4, (uint32_t)BL.plan_cap, walk_items, counters + kWalkCounter, counters, (uint32_t)M, maxc_cap, vs, zero4, zero_n, zero_per, poison ? 1 : 0);
     LAUNCH_CHECK(view, stream, "render_combine");
     if (M > 0) {   // ---- K5c: the pixels that stop inside a segment, one wave per (block, segment) item
         const unsigned grid_f = (unsigned)(TA < 2048 ? (TA < 64 ? 64 : TA) : 2048);
@@ -654,6 +700,32 @@ int wait_counters(volatile unsigned long long* pinned, hipStream_t stream) {
     return 0;
 }
 
+// The counters of this thread's pending asynchronous forward: waited for, checked against what its tail was launched for, filed in
+// g_completed, and the shape's hint brought up to date. -6: the lists did not fit (the forward's outputs are NaN-filled).
+int complete_pending() {
+    const PendingFwd p = g_pending;
+    g_pending.on = false;
+    CompletedFwd c;
+    c.serial = p.serial;
+    int rc = wait_counters(g_pinned, p.stream);
+    if (rc == 0) {
+        c.M_ref = g_pinned[0]; c.V = g_pinned[1]; c.M = g_pinned[2]; c.maxc = g_pinned[3];
+        if (c.M_ref >= (1ull << 62)) {
+            (void)hipStreamSynchronize(p.stream);
+            hint_drop(p.N, p.H, p.W, p.B);
+            rc = fail(-2, "the per-Gaussian kernel never saw the tile counters cleared (device error)%s", "");
+        } else {
+            hint_update(p.N, p.H, p.W, p.B, c.M, c.maxc, g_pinned + 8);     // (also after an overflow: the next call then sizes from the true counts)
+            if (c.M > p.cap || sort_class(c.maxc) > sort_class(p.capc))
+                rc = fail(-6, "an asynchronous forward (GSR_VIEW_ASYNC_STATS) found more tile instances than its speculative capacity (%s%lld): "
+                              "its images are NaN-filled and its backward yields zeros; repeat the step", "", (long long)c.M);
+        }
+    }
+    c.rc = rc;
+    g_completed = c;
+    return rc;
+}
+
 int forward_impl(const GsrView* views, int B, int32_t N, int32_t K,
                  const float* means3D, const float* shs, const float* colors_precomp,
                  const float* opacities, const float* scales, const float* rotations,
@@ -669,6 +741,9 @@ int forward_impl(const GsrView* views, int B, int32_t N, int32_t K,
     if (!geom.resize || !bin.resize || !img.resize) return fail(-1, "scratch allocators are required%s", "");
     // the one host round trip of the forward: how many (tile,Gaussian) instances to allocate
     if (!g_pinned) HIP_TRY(hipHostMalloc((void**)&g_pinned, (kCounterWords + 1) * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
+    // the previous asynchronous forward of this thread: its counters must have landed before the pinned block is re-armed (the GPU
+    // has long passed that point: this is the check, not a wait) -- and ITS failure is reported here, before anything new is enqueued
+    if (g_pending.on) { if (int rcp = complete_pending()) return rcp; }
     const ViewConst vcs = make_view(view);
     const GeomLayout GLs = geom_layout(N, vcs.H, vcs.W, B);
     const int shift = seg_shift_for(N, GLs.nTiles);
@@ -689,7 +764,15 @@ int forward_impl(const GsrView* views, int B, int32_t N, int32_t K,
         side.p = reinterpret_cast<float4*>(view->grad_clear);
         side.n4 = (uint32_t)(view->grad_clear_floats / 4);
     }
-    const bool spec = ov(OV_SPECULATE) != 0 && g_hint.valid && g_hint.N == N && g_hint.H == vcs.H && g_hint.W == vcs.W && g_hint.B == B && N > 0;
+    // (a COPY of the table entry: the table is updated further down)
+    FwdHint hintv;
+    if (const FwdHint* hp = (ov(OV_SPECULATE) != 0 && N > 0) ? hint_find(N, vcs.H, vcs.W, B) : nullptr) hintv = *hp;
+    const FwdHint& g_hint = hintv;
+    const bool spec = g_hint.valid;
+    // GSR_VIEW_ASYNC_STATS: a speculative forward returns as soon as everything is enqueued -- no wait for K2's counters in the steady
+    // state. The capacity then comes from the LARGEST of the recent calls of the shape + 50 % (a list that still does not
+    // fit leaves NaN images and error -6 at the thread's next call: gsr.h).
+    const bool async = spec && stats != nullptr && (view->flags & GSR_VIEW_ASYNC_STATS) != 0;
     // K2 (scan of the tile counts, statistics, tile order, the counters for the host) inside the scatter's launch: when the forward is
     // enqueued in one go (speculation), the tile counters sit in LDS (no global cursors) and the compositing takes its tiles from
     // `order` (the depth-major item list of the segmented mode is written BY the scatter FROM K2's results). Test hook "scan_fold" = 0: never.
@@ -714,13 +797,23 @@ int forward_impl(const GsrView* views, int B, int32_t N, int32_t K,
     unsigned long long cap = 0, capc = 0;
     int rc = 0;
     if (spec) {
-        cap = g_hint.M + g_hint.M / 4 + 4096;
-        const unsigned long long c = g_hint.maxc + g_hint.maxc / 4 + 64;
+        cap = async ? g_hint.M_hi + g_hint.M_hi / 2 + 4096 : g_hint.M + g_hint.M / 4 + 4096;
+        const unsigned long long c = async ? g_hint.maxc_hi + g_hint.maxc_hi / 2 + 64 : g_hint.maxc + g_hint.maxc / 4 + 64;
         capc = c <= 2048 ? 2048 : (c <= 8192 ? 8192 : (c <= 16384 ? 16384 : ~0ull));
-        rc = finish_impl(views, B, N, out_color, out_depth, out_alpha, gbuf, ibuf, bin, shift, g_hint.per_view, cap, capc, prepare, fold, 8 + 2 * B, stream, side);
+        rc = finish_impl(views, B, N, out_color, out_depth, out_alpha, gbuf, ibuf, bin, shift, g_hint.per_view, cap, capc, prepare, fold, 8 + 2 * B, stream, side, async);
         if (rc && fold) {                                 // K2 never ran: nothing will ever arrive in the pinned block
             (void)hipStreamSynchronize(stream);
             return rc;
+        }
+        if (async && rc == 0) {                           // the counters are waited for by whoever needs them next (complete_pending)
+            g_pending.on = true; g_pending.serial = ++g_async_serial;
+            g_pending.N = N; g_pending.H = vcs.H; g_pending.W = vcs.W; g_pending.B = B;
+            g_pending.cap = cap; g_pending.capc = capc; g_pending.stream = stream;
+            stats->num_instances = -1; stats->num_instances_ref = -1; stats->num_visible = -1; stats->max_tile_count = -1;
+            stats->bin_capacity = (int64_t)cap; stats->seg_shift = shift;
+            stats->bwd_prepared = prepare ? (side.n4 ? 2 : 1) : -1;
+            stats->speculated = 1; stats->pending = g_pending.serial;
+            return 0;
         }
     }
     if (int rcw = wait_counters(g_pinned, stream)) return rcw;    // also on a failed tail: nothing may stay pending on the pinned block
@@ -728,13 +821,15 @@ int forward_impl(const GsrView* views, int B, int32_t N, int32_t K,
     const unsigned long long M_ref = g_pinned[0], V = g_pinned[1], M = g_pinned[2], maxc = g_pinned[3];
     if (M_ref >= (1ull << 62)) {                          // a workgroup of K1 gave up waiting for the cleared tile counters (gsr_preprocess.hip)
         (void)hipStreamSynchronize(stream);
-        g_hint.valid = false;
+        hint_drop(N, vcs.H, vcs.W, B);
         return fail(-2, "the per-Gaussian kernel never saw the tile counters cleared (device error)%s", "");
     }
+    bool speculated = spec;                               // the tail enqueued before the wait is the one that counts
     if (spec && (M > cap || sort_class(maxc) > sort_class(capc))) {
         // misprediction: the kernels above left without writing; clear what the scatter accumulates into
         HIP_TRY(hipMemsetAsync(gbuf + GLs.cursor, 0, GLs.counters - GLs.cursor, stream));
         cap = 0;
+        speculated = false;
     }
     if (!spec || cap == 0) {
         cap = M;
@@ -742,11 +837,9 @@ int forward_impl(const GsrView* views, int B, int32_t N, int32_t K,
     }
     if (stats) { stats->num_instances = (int64_t)M; stats->num_instances_ref = (int64_t)M_ref; stats->num_visible = (int64_t)V;
                  stats->max_tile_count = (int64_t)maxc; stats->bin_capacity = (int64_t)cap; stats->seg_shift = shift;
-                 stats->bwd_prepared = (prepare && rc == 0) ? (side.n4 ? 2 : 1) : (prepare ? 0 : -1); }
-    if (rc == 0) {
-        g_hint.valid = true; g_hint.N = N; g_hint.H = vcs.H; g_hint.W = vcs.W; g_hint.B = B; g_hint.M = M; g_hint.maxc = maxc;
-        for (int v = 0; v < 2 * B; ++v) g_hint.per_view[v] = g_pinned[8 + v];
-    }
+                 stats->bwd_prepared = (prepare && rc == 0) ? (side.n4 ? 2 : 1) : (prepare ? 0 : -1);
+                 stats->speculated = speculated ? 1 : 0; stats->pending = 0; }
+    if (rc == 0) hint_update(N, vcs.H, vcs.W, B, M, maxc, g_pinned + 8);
     return rc;
 }
 
@@ -766,7 +859,6 @@ int backward_impl(const GsrView* views, int B, int32_t N, int32_t K,
     if (int rc = check_inputs(N, K, view, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp)) return rc;
     if (N == 0) return 0;
     if (!geom || !bin || !img || !radii) return fail(-1, "forward state (geom/bin/img/radii) is required%s", "");
-    if (!dL_dcolor || !dL_ddepth || !dL_dalpha) return fail(-1, "incoming gradients are required%s", "");
     if (!dL_dmeans3D || !dL_dmeans2D || !dL_dopacities) return fail(-1, "dL_dmeans3D/dL_dmeans2D/dL_dopacities are required%s", "");
     if (shs && !dL_dshs) return fail(-1, "dL_dshs is required with shs%s", "");
     if (view->shs_rest && (!shs || !view->dL_dshs_rest || K < 2)) return fail(-1, "split SH input needs shs (features_dc), K >= 2 and GsrView.dL_dshs_rest%s", "");
@@ -790,7 +882,8 @@ int backward_impl(const GsrView* views, int B, int32_t N, int32_t K,
     int shift = 6;
     if (fwd_stats) {
         if (fwd_stats->bwd_prepared < 0) return fail(-1, "the forward ran with GSR_VIEW_NO_BACKWARD: it left no state for gsr_backward%s", "");
-        M = (unsigned long long)(fwd_stats->num_instances > 0 ? fwd_stats->bin_capacity : 0);
+        // (an asynchronous forward's statistics are still pending: the capacity -- known when it was enqueued -- is all that is needed)
+        M = (unsigned long long)((fwd_stats->num_instances > 0 || fwd_stats->pending != 0) ? fwd_stats->bin_capacity : 0);
         shift = (int)fwd_stats->seg_shift;
         if (shift < 6 || shift > 8) return fail(-1, "fwd_stats is not the GsrStats of a gsr_forward of this library version%s", "");
     } else {
@@ -848,6 +941,13 @@ int backward_impl(const GsrView* views, int B, int32_t N, int32_t K,
         zr.total4 = (uint32_t)total4;
         if (!compact || grads_cleared) memset(&zr, 0, sizeof(zr));   // (nothing to clear here: the forward's compositing kernel did it)
     }
+    // A NULL incoming gradient stands for zeros (ABI 6: DreamGaussian's stage 1 never differentiates depth, main.py:198-275 -- the
+    // wrapper used to build a zero image per backward for it). The kernel's loads stay unconditional: they go to a plane of the
+    // forward's own per-pixel scratch (`totals`: 5 planes per view, the colour gradient's 3 fit) and the value is masked.
+    uint32_t gnull = 0u;
+    if (!dL_dcolor) { dL_dcolor = totals; gnull |= 1u; }
+    if (!dL_ddepth) { dL_ddepth = totals; gnull |= 2u; }
+    if (!dL_dalpha) { dL_dalpha = totals; gnull |= 4u; }
     prof_begin(stream);
     if (M > 0) {
         const BinLayout BL = bin_layout((size_t)M, TA, shift);
@@ -866,7 +966,7 @@ int backward_impl(const GsrView* views, int B, int32_t N, int32_t K,
         const size_t dyn = ((size_t)GSR_Q2_ROW * 8) << shift;
         hipLaunchKernelGGL(gsr_render_bwd_q2, dim3(grid), dim3(256), dyn, stream, tile_off, recs, sorted_ids, W, H, vc.gx,
                            final_T, n_contrib, totals, ckpt, tile_seg, dL_dcolor, dL_ddepth, dL_dalpha, g2d, shift,
-                           plan_tile, plan_off, plan_total, vs, zr, live);
+                           plan_tile, plan_off, plan_total, vs, zr, live, gnull);
     }
     LAUNCH_CHECK(view, stream, "render_bwd");
 
@@ -938,6 +1038,19 @@ extern "C" int gsr_forward(const GsrView* view, int32_t N, int32_t K,
                            GsrStats* stats, gsr_stream_t stream) {
     return forward_impl(view, 1, N, K, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                         out_color, out_depth, out_alpha, radii, geom, bin, img, stats, stream);
+}
+
+extern "C" int gsr_forward_complete(GsrStats* stats) {
+    if (!stats) return fail(-1, "stats is NULL%s", "");
+    if (stats->pending == 0) return 0;
+    if (g_pending.on && g_pending.serial == stats->pending) (void)complete_pending();
+    if (g_completed.serial != stats->pending)
+        return fail(-1, "gsr_forward_complete: not the most recent asynchronous forward of the calling thread%s", "");
+    stats->num_instances = (int64_t)g_completed.M; stats->num_instances_ref = (int64_t)g_completed.M_ref;
+    stats->num_visible = (int64_t)g_completed.V; stats->max_tile_count = (int64_t)g_completed.maxc;
+    stats->pending = 0;
+    if (g_completed.rc == -6) stats->speculated = 0;
+    return g_completed.rc;
 }
 
 extern "C" int gsr_backward(const GsrView* view, int32_t N, int32_t K,

@@ -1073,6 +1073,7 @@ template __global__ void gsr_preprocess_bwd<true, false>(ViewTab, int, int, int,
 #define GSR_K6C_ROUND (GSR_K6C_NT * GSR_K6C_PER)
 #define GSR_K6C_RING (GSR_K6C_NT + GSR_K6C_ROUND)         // ring of live indices: < NT waiting + one round of phase A (1.5 KiB: with
                                                           // the 25 KiB of staged rows at 16 coefficients six workgroups share a CU)
+static_assert(GSR_K6C_NT == 128 && GSR_K6C_PER == 2, "phase A of gsr_preprocess_bwd_compact: four quarters of 32 lanes x 2 flags");
 __device__ __forceinline__ uint32_t k6c_slot(uint32_t head, uint32_t off) { const uint32_t p = head + off; return p >= GSR_K6C_RING ? p - GSR_K6C_RING : p; }   // head, off < RING
 template <bool RAW>
 __global__ void __launch_bounds__(GSR_K6C_NT, 4)      // <= 128 VGPRs (0.0688 -> 0.0614 ms at 1M against three waves per SIMD and 130 VGPRs)
@@ -1095,28 +1096,41 @@ gsr_preprocess_bwd_compact(ViewTab tab /* the view: tab.v[0] */, int N, int K,
     const bool stage = use_sh && (K > 1);
     const ViewConst vc = tab.v[0];
     __shared__ __attribute__((aligned(16))) float camf[36];
-    __shared__ uint32_t ring[GSR_K6C_RING];               // indices of live Gaussians, in index order
+    __shared__ uint32_t ring[GSR_K6C_RING];               // indices of live Gaussians
     __shared__ uint32_t wcnt[NT / 64];
     if (threadIdx.x < 35) camf[threadIdx.x] = threadIdx.x < 16 ? vc.view[cam_index(threadIdx.x, vc.mat_t & 1)]
                                               : (threadIdx.x < 32 ? vc.proj[cam_index(threadIdx.x - 16, vc.mat_t & 2)] : vc.campos[threadIdx.x - 32]);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t head = 0, qn = 0;                            // (uniform) ring[head ...], wrapping: qn entries waiting
-    const int stride = gridDim.x * GSR_K6C_ROUND;
-    int base = blockIdx.x * GSR_K6C_ROUND;
+    // Which Gaussians a workgroup looks at: 64 consecutive ones (32 lanes x 2 flags) per QUARTER of a round, the quarters of all
+    // workgroups interleaved -- sub-chunk s = (4 round + quarter) * grid + workgroup. Rounds 2-5 handed out 256 consecutive Gaussians per
+    // round (2.5 rounds per workgroup at 1M): in a random order every chunk holds its 27 % of live ones, in Z-order (reorder_gaussians)
+    // a chunk is all live or all dead and the workgroups' loads spread 0 .. 3x -- the kernel got SLOWER under the order that helps
+    // every other kernel (0.0665 -> 0.0697 ms blob, 0.0275 -> 0.0416 trained-like, profiles/r05_bench_order.jsonl). A quarter keeps 64
+    // neighbours together (they share the lines of their 12- and 4-byte inputs); a draw from ONE atomic counter was measured 3x slower.
+    const int G = (int)gridDim.x;
+    const int nsub = (N + 63) >> 6;
+    int r4 = 0;                                           // (uniform) 4 * rounds of phase A taken so far
     // the first round's flags travel while the camera is staged; every later round's are requested a round ahead
     // (GSR_K6C_PER = 2 flags = one aligned 16-bit load per lane: the array is padded to a multiple of 16 bytes)
     const unsigned short* live16 = reinterpret_cast<const unsigned short*>(live);
     const int npairs = (int)(GSR_LIVE_BYTES(N) / 2);
-    uint32_t next_flags = live16[min((base >> 1) + (int)threadIdx.x, npairs - 1)];
+    const int quarter = (int)(threadIdx.x >> 5), l31 = (int)(threadIdx.x & 31);
+    auto pair_of = [&](int r4_) -> int {                  // this lane's pair of flags in the round that starts at quarter r4_ (may lie past the end)
+        const long long sub = (long long)(r4_ + quarter) * G + (int)blockIdx.x;
+        return sub < (long long)nsub ? (int)sub * 32 + l31 : npairs;
+    };
+    uint32_t next_flags = live16[min(pair_of(0), npairs - 1)];
     lds_barrier();
     for (;;) {
-        const bool more = base < N && qn < NT;            // (uniform) a round of phase A only when phase B has nothing full to do
+        const bool more = (long long)r4 * G + (int)blockIdx.x < (long long)nsub && qn < NT;   // (uniform) a round of phase A only when phase B has nothing full to do
         if (more) {
             // ---- phase A: this round's flags -> ring entries (lane = GSR_K6C_PER consecutive Gaussians)
             uint32_t f = next_flags;
-            if ((base >> 1) + (int)threadIdx.x >= npairs) f = 0u;    // (pairs past the end; bytes past N inside the padding are never set)
-            next_flags = live16[min(((base + stride) >> 1) + (int)threadIdx.x, npairs - 1)];
-            const int i0 = base + (int)threadIdx.x * GSR_K6C_PER;
+            const int pr = pair_of(r4);
+            if (pr >= npairs) f = 0u;                     // (quarters / pairs past the end; bytes past N inside the padding are never set)
+            next_flags = live16[min(pair_of(r4 + 4), npairs - 1)];
+            const int i0 = pr * GSR_K6C_PER;
             const bool l0 = (f & 0xffu) != 0u, l1 = (f >> 8) != 0u;
             const uint32_t c = (uint32_t)l0 + (uint32_t)l1;
             uint32_t incl = c;                            // inclusive scan of the counts over the wave
@@ -1131,9 +1145,9 @@ gsr_preprocess_bwd_compact(ViewTab tab /* the view: tab.v[0] */, int N, int K,
             if (l1) ring[k6c_slot(head, qn + off)] = (uint32_t)(i0 + 1);
             lds_barrier();                                // the ring's new entries (and wcnt free again)
             qn += tot;
-            base += stride;
+            r4 += 4;
         }
-        const bool last = base >= N;                      // (uniform) nothing left to look at: the rest of the ring goes out as it is
+        const bool last = (long long)r4 * G + (int)blockIdx.x >= (long long)nsub;   // (uniform) nothing left to look at: the rest of the ring goes out as it is
         const uint32_t take = qn >= NT ? NT : (last ? qn : 0u);    // a full round of entries, or the rest at the very end
         if (take == 0u) { if (last) break; continue; }
         // ---- phase B: `take` queue entries, lane = entry

@@ -321,6 +321,20 @@ template __global__ void gsr_render_fwd_seg<true>(const uint4*, const uint32_t*,
 // clears them: workgroup k of the launch stores zeros to slice k of `zero_n` float4s BEHIND its own work -- the compositing leaves
 // HBM idle, the workgroups finish spread over the kernel's length, and the 10 us fill in front of gsr_render_bwd_q2 (and its launch)
 // is gone. zero_n = 0: nothing to clear (GSR_VIEW_NO_BACKWARD, or the other instantiation's launch does it).
+// An ASYNCHRONOUS forward (GSR_VIEW_ASYNC_STATS) whose lists turned out not to fit what it was launched for: nobody repeats the tail
+// (the host has returned long ago), so the per-tile kernel leaves NaN images instead of unwritten memory -- workgroup k fills tile k
+// of the launch (any bijection will do: `order` may be stale) -- and the host reports -6 at the thread's next call.
+__device__ __forceinline__ void poison_tile(const ViewSplit& vs, int W, int H, int gx, float* __restrict__ out_color,
+                                            float* __restrict__ out_depth, float* __restrict__ out_alpha) {
+    if (threadIdx.x >= 256u) return;
+    const int tg = (int)blockIdx.x, view = tg / vs.tiles_per_view, tile = tg - view * vs.tiles_per_view;
+    const int px = (tile % gx) * GSR_TILE + (int)(threadIdx.x & 15u), py = (tile / gx) * GSR_TILE + (int)(threadIdx.x >> 4);
+    if (px >= W || py >= H) return;
+    const size_t HW = (size_t)W * H, pix = (size_t)py * W + px;
+    const float nan = __uint_as_float(0x7fc00000u);
+    out_color[view * 3 * HW + pix] = nan; out_color[view * 3 * HW + HW + pix] = nan; out_color[view * 3 * HW + 2 * HW + pix] = nan;
+    out_depth[view * HW + pix] = nan; out_alpha[view * HW + pix] = nan;
+}
 template <uint32_t THREADS = 256u>      // (the workgroup's size: a constant, not blockDim -- no implicit-argument load in front of the stores)
 __device__ __forceinline__ void clear_slice(float4* __restrict__ zero4, uint32_t zero_n, uint32_t per /* float4s per workgroup (host: ceil(zero_n / grid)) */) {
     if (zero_n == 0u) return;
@@ -350,7 +364,10 @@ gsr_render_fwd_serial(const uint32_t* __restrict__ tile_off, const SplatRec* __r
                       unsigned long long* __restrict__ plan_total, uint32_t plan_cap, unsigned long long qmask_views, uint32_t sink_rec,
                       const unsigned long long* __restrict__ counters, uint32_t capacity, uint32_t maxc_cap, ViewSplit vs,
                       float4* __restrict__ zero4, uint32_t zero_n, uint32_t zero_per, ZeroSide zs) {
-    if (counters[2] > (unsigned long long)capacity || counters[3] > (unsigned long long)maxc_cap) return;
+    if (counters[2] > (unsigned long long)capacity || counters[3] > (unsigned long long)maxc_cap) {
+        if ((qmask_views >> 62) & 1ull) poison_tile(vs, W, H, gx, out_color, out_depth, out_alpha);     // (bit 62: an asynchronous forward)
+        return;
+    }
     __shared__ float4 stage[4][3][GSR_RB + 2];
     __shared__ __attribute__((aligned(8))) uint8_t qlist[QUAD ? 4 : 1][4][80];
     __shared__ uint32_t wl[4];
@@ -358,7 +375,7 @@ gsr_render_fwd_serial(const uint32_t* __restrict__ tile_off, const SplatRec* __r
     // bit 63 of qmask_views: no backward follows this forward (GSR_VIEW_NO_BACKWARD) -- no checkpoints, no quad masks (118 MB of
     // stores at 1M Gaussians), and gsr_backward refuses the state
     const bool keep_state = (qmask_views >> 63) == 0ull;
-    if (blockIdx.x == 0 && threadIdx.x == 0) plan_total[GSR_CNT_QMASK - GSR_CNT_PLAN] = qmask_views;   // the views whose records carry quad masks
+    if (blockIdx.x == 0 && threadIdx.x == 0) plan_total[GSR_CNT_QMASK - GSR_CNT_PLAN] = qmask_views & ~(1ull << 62);   // the views whose records carry quad masks (| bit 63)
     const int tg = (int)order[blockIdx.x];                // heaviest tiles first
     const int view = tg / vs.tiles_per_view;
     if (!((vs.view_mask >> view) & 1u)) { clear_slice(zero4, zero_n, zero_per); clear_side(zs); return; }   // (workgroup-uniform) this view composites with the other instantiation
@@ -586,6 +603,26 @@ template __global__ void gsr_render_fwd_serial<true>(const uint32_t*, const Spla
 // the quad masks left for the backward may carry the stale-gate entries above (its own per-pixel tests drop them).
 // Spins are bounded: a lost hand-shake ends the walk early (wrong pixels, caught by the tests) instead of hanging the GPU.
 // =========================================================================================
+// Wave priorities inside the pair kernel (s_setprio, 0..3). The BLENDER of a block is the chain the kernel's length is made of; its
+// tester has slack (it is at most a round ahead and waits for a free buffer). Round 6, same box, 1M Gaussians / 800^2: blender 3 /
+// tester 0 takes the forward compositing from 0.1464 to 0.1310 ms -- the blenders issue whenever they can, the testers of all blocks
+// fill the slots the blenders leave. (Priorities among the waves of the SERIAL walk, where every wave is a chain, did nothing in
+// round 4: 0.1536 / 0.1536.)
+#ifndef GSR_PAIR_PRIO_B
+#define GSR_PAIR_PRIO_B 3
+#endif
+#ifndef GSR_PAIR_PRIO_T
+#define GSR_PAIR_PRIO_T 0
+#endif
+#ifndef GSR_PAIR_PRIO_TAIL
+#define GSR_PAIR_PRIO_TAIL 0      // priority of the blender behind its walk (outputs, work items, the slices of zeros)
+#endif
+#ifndef GSR_PAIR_PRIO_DEPTH
+#define GSR_PAIR_PRIO_DEPTH 0     // experiment: n > 0 = both waves of a block rise one level every n rounds (blender from 1, tester from 0)
+#endif
+#ifndef GSR_PAIR_WAVES_PER_EU
+#define GSR_PAIR_WAVES_PER_EU 6
+#endif
 #define GSR_PAIR_END 0xffu
 #define GSR_PAIR_STOP 0xffffffffu
 #define GSR_PAIR_SPINS (1 << 20)
@@ -597,7 +634,7 @@ __device__ __forceinline__ void lds_flag_store(uint32_t* p, uint32_t v, int lane
     if (lane == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-__global__ void __launch_bounds__(512, 6)      // <= 80 VGPRs: three workgroups of eight waves per CU
+__global__ void __launch_bounds__(512, GSR_PAIR_WAVES_PER_EU)      // 6: <= 80 VGPRs, three workgroups of eight waves per CU
 gsr_render_fwd_pair(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict__ recs,
                     const uint32_t* __restrict__ ids, int W, int H, int gx,
                     float* __restrict__ out_color, float* __restrict__ out_depth,
@@ -609,7 +646,10 @@ gsr_render_fwd_pair(const uint32_t* __restrict__ tile_off, const SplatRec* __res
                     unsigned long long* __restrict__ plan_total, uint32_t plan_cap, unsigned long long qmask_views, uint32_t sink_rec,
                     const unsigned long long* __restrict__ counters, uint32_t capacity, uint32_t maxc_cap, ViewSplit vs,
                     float4* __restrict__ zero4, uint32_t zero_n, uint32_t zero_per, ZeroSide zs) {
-    if (counters[2] > (unsigned long long)capacity || counters[3] > (unsigned long long)maxc_cap) return;
+    if (counters[2] > (unsigned long long)capacity || counters[3] > (unsigned long long)maxc_cap) {
+        if ((qmask_views >> 62) & 1ull) poison_tile(vs, W, H, gx, out_color, out_depth, out_alpha);
+        return;
+    }
     __shared__ float4 stage[4][2][3][GSR_RB + 2];                            // [block][buffer][a | b | c][slot]; slot 64 = the all-zero record
     __shared__ __attribute__((aligned(8))) uint8_t qlist[4][2][4][80];
     __shared__ uint32_t ready[4][2], freed[4][2];
@@ -617,7 +657,7 @@ gsr_render_fwd_pair(const uint32_t* __restrict__ tile_off, const SplatRec* __res
     __shared__ uint32_t wl[4];
     __shared__ uint32_t plan_base;
     const bool keep_state = (qmask_views >> 63) == 0ull;  // (as in gsr_render_fwd_serial)
-    if (blockIdx.x == 0 && threadIdx.x == 0) plan_total[GSR_CNT_QMASK - GSR_CNT_PLAN] = qmask_views;
+    if (blockIdx.x == 0 && threadIdx.x == 0) plan_total[GSR_CNT_QMASK - GSR_CNT_PLAN] = qmask_views & ~(1ull << 62);
     const int tg = (int)order[blockIdx.x];                // heaviest tiles first
     const int view = tg / vs.tiles_per_view;
     if (!((vs.view_mask >> view) & 1u)) { clear_slice<512>(zero4, zero_n, zero_per); clear_side<512>(zs); return; }
@@ -658,6 +698,7 @@ gsr_render_fwd_pair(const uint32_t* __restrict__ tile_off, const SplatRec* __res
     float* const sinkf = rec_base + (size_t)sink_rec * GSR_CKPT_FLOATS + (blk * 64 + lane);
     unsigned long long* const sink64 = reinterpret_cast<unsigned long long*>(rec_base + (size_t)sink_rec * GSR_CKPT_FLOATS + GSR_REC_HINT) + lane;
     if (n > 0u && tester) {
+        if (GSR_PAIR_PRIO_T) __builtin_amdgcn_s_setprio(GSR_PAIR_PRIO_T);
         // ---- the tester: two register sets take turns (round r tests set r & 1, requested a round ago, and requests round r + 1's
         // records and round r + 2's list entries); it is never more than one round ahead of the blender, so its own latencies hide
         // behind the wait for a free buffer
@@ -680,6 +721,7 @@ gsr_render_fwd_pair(const uint32_t* __restrict__ tile_off, const SplatRec* __res
         auto test_round = [&](const uint32_t r, float4 ra, float4 rb, float4 rc, float4& da, float4& db, float4& dc) -> bool {
             const uint32_t rel = r * GSR_RB;
             const int buf = (int)(r & 1u);
+            if (GSR_PAIR_PRIO_DEPTH) { if (r == (uint32_t)GSR_PAIR_PRIO_DEPTH) __builtin_amdgcn_s_setprio(1); if (r == 2u * (uint32_t)GSR_PAIR_PRIO_DEPTH) __builtin_amdgcn_s_setprio(2); }
             if (rel >= n) {                                 // behind the end of the list
                 if (r >= 2u && !wait_free(&freed[blk][buf], r - 1u)) return false;
                 lds_flag_store(&ready[blk][buf], ((r + 1u) << 8) | GSR_PAIR_END, lane);
@@ -739,10 +781,12 @@ gsr_render_fwd_pair(const uint32_t* __restrict__ tile_off, const SplatRec* __res
         }
     } else if (n > 0u) {
         // ---- the blender
+        __builtin_amdgcn_s_setprio(GSR_PAIR_PRIO_DEPTH ? 1 : GSR_PAIR_PRIO_B);
 #pragma unroll 1
         for (uint32_t r = 0;; ++r) {
             const uint32_t rel = r * GSR_RB;
             const int buf = (int)(r & 1u);
+            if (GSR_PAIR_PRIO_DEPTH) { if (r == (uint32_t)GSR_PAIR_PRIO_DEPTH) __builtin_amdgcn_s_setprio(2); if (r == 2u * (uint32_t)GSR_PAIR_PRIO_DEPTH) __builtin_amdgcn_s_setprio(3); }
             uint32_t code = lds_flag_load(&ready[blk][buf]);
 #pragma unroll 1
             for (int spin = 0; (code >> 8) != r + 1u && spin < GSR_PAIR_SPINS; ++spin) { __builtin_amdgcn_s_sleep(1); code = lds_flag_load(&ready[blk][buf]); }
@@ -791,6 +835,7 @@ gsr_render_fwd_pair(const uint32_t* __restrict__ tile_off, const SplatRec* __res
             }
         }
     }
+    __builtin_amdgcn_s_setprio(GSR_PAIR_PRIO_TAIL);
     if (inside && !tester) {
         const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
         final_T[pix] = T;
@@ -891,8 +936,11 @@ gsr_render_fwd_combine(const uint32_t* __restrict__ tile_off, const SplatRec* __
                        unsigned long long* __restrict__ plan_total, uint32_t plan_cap,
                        uint2* __restrict__ walk_items, unsigned long long* __restrict__ walk_total,
                        const unsigned long long* __restrict__ counters, uint32_t capacity, uint32_t maxc_cap, ViewSplit vs,
-                       float4* __restrict__ zero4, uint32_t zero_n, uint32_t zero_per) {
-    if (counters[2] > (unsigned long long)capacity || counters[3] > (unsigned long long)maxc_cap) return;
+                       float4* __restrict__ zero4, uint32_t zero_n, uint32_t zero_per, int poison /* an asynchronous forward */) {
+    if (counters[2] > (unsigned long long)capacity || counters[3] > (unsigned long long)maxc_cap) {
+        if (poison) poison_tile(vs, W, H, gx, out_color, out_depth, out_alpha);
+        return;
+    }
     __shared__ float4 stage[4][3][GSR_RB + 2];
     __shared__ uint32_t wl[4];
     __shared__ uint32_t plan_base;
@@ -1143,7 +1191,8 @@ gsr_render_fwd_fix(const uint2* __restrict__ walk_items, const unsigned long lon
     const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha,                     \
     float* __restrict__ g2d, int seg_shift, const uint4* __restrict__ plan_items,                 \
     const uint32_t* __restrict__ plan_off, const unsigned long long* __restrict__ plan_total,     \
-    ViewSplit vs, ZeroRegions zr, uint8_t* __restrict__ live /* [views][GSR_LIVE_BYTES(N)], cleared with g2d */
+    ViewSplit vs, ZeroRegions zr, uint8_t* __restrict__ live /* [views][GSR_LIVE_BYTES(N)], cleared with g2d */,               \
+    uint32_t gnull /* bit 0 / 1 / 2: the caller passed no dL_dcolor / dL_ddepth / dL_dalpha (zeros; the pointer is a readable dummy) */
 
 // -----------------------------------------------------------------------------------------
 // K5b: quad lists + two passes + fixed-point accumulation.
@@ -1322,7 +1371,8 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
     // a pixel outside the image: transmittance 1, no contributor, zero incoming gradients
     const float T_final = inside ? l_T : 1.f;
     const uint32_t last_contrib = inside ? l_last : 0u;
-    const float gC0 = inside ? l_g0 : 0.f, gC1 = inside ? l_g1 : 0.f, gC2 = inside ? l_g2 : 0.f, gD = inside ? l_gD : 0.f, gA = inside ? l_gA : 0.f;
+    const bool use_c = inside && !(gnull & 1u), use_d = inside && !(gnull & 2u), use_a = inside && !(gnull & 4u);
+    const float gC0 = use_c ? l_g0 : 0.f, gC1 = use_c ? l_g1 : 0.f, gC2 = use_c ? l_g2 : 0.f, gD = use_d ? l_gD : 0.f, gA = use_a ? l_gA : 0.f;
     const float Cg_total = inside ? l_t0 * gC0 + l_t1 * gC1 + l_t2 * gC2 + l_t3 * gD + l_t4 * gA : 0.f;
     const float ck0 = seg > 0u ? l_c0 : 1.f, ck1 = l_c1, ck2 = l_c2, ck3 = l_c3, ck4 = l_c4, ck5 = l_c5;    // (ck1..5 only read when seg > 0)
     // (scalar loads: requested in front of the barrier, not behind it)

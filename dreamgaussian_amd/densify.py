@@ -154,10 +154,16 @@ def _rebind(gaussians, slots, outs):
 
 
 @torch.no_grad()
-def densification_postfix(gaussians, new_xyz, new_features_dc, new_features_rest, new_opacities, new_scaling, new_rotation) -> None:
+def densification_postfix(gaussians, new_xyz, new_features_dc, new_features_rest, new_opacities, new_scaling, new_rotation,
+                          zorder: bool = False) -> None:
     """`GaussianModel.densification_postfix` with `cat_tensors_to_optimizer` (gs_renderer.py:513-552) on a reference
     GaussianModel instance: the six parameters extended by the new rows, their Adam moments by zeros, the three
-    accumulators reset to zeros of the new length -- ONE launch (`gsr_concat_rows`) instead of 18 `torch.cat` + 12 `zeros_like`."""
+    accumulators reset to zeros of the new length -- ONE launch (`gsr_concat_rows`) instead of 18 `torch.cat` + 12 `zeros_like`.
+
+    `zorder=True` (round 6): the extended model is left along the 3-D Z-order curve of its positions (`reorder_gaussians`: one sort
+    of N keys and one gather launch behind the concatenation), so that a trainer that keeps its Gaussians on the curve
+    (`prune_points(zorder=True)`) does not leave it when it clones or splits. The same set of Gaussians, each with its own moments:
+    the reference's result up to a permutation of the rows (tests/test_optim_gpu.py)."""
     new = {"xyz": new_xyz, "f_dc": new_features_dc, "f_rest": new_features_rest, "opacity": new_opacities,
            "scaling": new_scaling, "rotation": new_rotation}
     slots = _optimizer_slots(gaussians)
@@ -191,18 +197,20 @@ def densification_postfix(gaussians, new_xyz, new_features_dc, new_features_rest
                 _lib.check(lib.gsr_concat_rows(len(chunk), chunk, n_old, n_new, stream), "gsr_concat_rows")
     _rebind(gaussians, slots, outs)
     gaussians.xyz_gradient_accum, gaussians.denom, gaussians.max_radii2D = acc
+    if zorder and n_old + n_new > 1:
+        reorder_gaussians(gaussians)
 
 
 @torch.no_grad()
-def densify_and_clone(gaussians, grads: torch.Tensor, grad_threshold: float, scene_extent: float) -> None:
+def densify_and_clone(gaussians, grads: torch.Tensor, grad_threshold: float, scene_extent: float, zorder: bool = False) -> None:
     """`GaussianModel.densify_and_clone` (gs_renderer.py:582-595): the selection as the reference writes it, then ONE mask
-    compaction, one gather of the six parameters' selected rows and the one-launch postfix."""
+    compaction, one gather of the six parameters' selected rows and the one-launch postfix (`zorder`: see there)."""
     sel = torch.logical_and(torch.norm(grads, dim=-1) >= grad_threshold,
                             torch.max(gaussians.get_scaling, dim=1).values <= gaussians.percent_dense * scene_extent)
     idx, count = compact_mask(sel)
     rows = gather_rows(idx, [gaussians._xyz, gaussians._features_dc, gaussians._features_rest, gaussians._opacity,
                              gaussians._scaling, gaussians._rotation])
-    densification_postfix(gaussians, *rows)
+    densification_postfix(gaussians, *rows, zorder=zorder)
 
 
 @torch.no_grad()
@@ -218,11 +226,13 @@ def quaternion_to_matrix(r: torch.Tensor) -> torch.Tensor:
 
 
 @torch.no_grad()
-def densify_and_split(gaussians, grads: torch.Tensor, grad_threshold: float, scene_extent: float, N: int = 2, build_rotation=None) -> None:
+def densify_and_split(gaussians, grads: torch.Tensor, grad_threshold: float, scene_extent: float, N: int = 2, build_rotation=None,
+                      zorder: bool = False) -> None:
     """`GaussianModel.densify_and_split` (gs_renderer.py:554-580): selection and the random offsets as the reference computes
     them (same torch calls, same RNG stream), the rows through one compaction + one gather, then the one-launch postfix and
     the one-gather prune of the split originals. `build_rotation` = gs_renderer.build_rotation (quaternion -> matrix; default: the
-    same convention, `quaternion_to_matrix`)."""
+    same convention, `quaternion_to_matrix`). `zorder=True`: the prune that ends the call leaves the rows along the Z-order curve
+    (its gather moves every row anyway: no pass of its own)."""
     n_init = int(gaussians.get_xyz.shape[0])
     dev = gaussians._xyz.device
     padded = torch.zeros(n_init, device=dev)
@@ -239,7 +249,7 @@ def densify_and_split(gaussians, grads: torch.Tensor, grad_threshold: float, sce
     new_xyz = torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + xyz.repeat(N, 1)
     new_scaling = gaussians.scaling_inverse_activation(scaling.repeat(N, 1) / (0.8 * N))
     densification_postfix(gaussians, new_xyz, f_dc.repeat(N, 1, 1), f_rest.repeat(N, 1, 1), opac.repeat(N, 1), new_scaling, rot.repeat(N, 1))
-    prune_points(gaussians, torch.cat((sel, torch.zeros(N * count, device=dev, dtype=torch.bool))))
+    prune_points(gaussians, torch.cat((sel, torch.zeros(N * count, device=dev, dtype=torch.bool))), zorder=zorder)
 
 
 def _spread3(v: torch.Tensor) -> torch.Tensor:

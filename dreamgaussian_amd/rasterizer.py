@@ -38,14 +38,34 @@ class GaussianRasterizationSettings(NamedTuple):
 
 
 _last_stats = {}
+_last_pending = None       # (GsrStats, dict) of an asynchronous forward whose counts have not been collected yet (last_stats() does)
+# OPT-IN: gsr_forward returns without waiting for its instance counters when it could size its scratch from earlier calls of the same
+# shape (GSR_VIEW_ASYNC_STATS, include/gsr.h): the ~25 us of host wait per forward overlap with the caller's Python. The price is the
+# failure mode written down there (an overflow of the speculative capacity leaves NaN images and raises at the thread's NEXT forward).
+_async_forward = False
 # The backward normally hands the forward's GsrStats back to gsr_backward (no host round trip). Setting this
 # to False exercises the ABI's other documented mode (fwd_stats == NULL: the library reads the counters back
 # from the device, blocking) -- used by tests/test_parity_gpu.py.
 _pass_fwd_stats = True
 
 
+def set_async_forward(on: bool) -> bool:
+    """Opt into (or out of) the forward that does not wait for its instance counters (GSR_VIEW_ASYNC_STATS); returns the old setting."""
+    global _async_forward
+    old, _async_forward = _async_forward, bool(on)
+    return old
+
+
 def last_stats() -> dict:
-    """Scene statistics of the most recent forward (V, M of SURVEY 8(d))."""
+    """Scene statistics of the most recent forward (V, M of SURVEY 8(d)). After an asynchronous forward this collects its counts
+    (blocking until they have arrived; call it from the thread that rendered)."""
+    global _last_pending
+    if _last_pending is not None:
+        stats, _last_pending = _last_pending, None
+        rc = _lib.load().gsr_forward_complete(C.byref(stats))
+        _last_stats.update(M=stats.num_instances, M_ref=stats.num_instances_ref, V=stats.num_visible, max_tile=stats.max_tile_count,
+                           speculated=stats.speculated, pending=0)
+        _lib.check(rc, "gsr_forward_complete")
     return dict(_last_stats)
 
 
@@ -76,7 +96,7 @@ def _on_device(dev):
 
 def _view_struct(rs: GaussianRasterizationSettings, device, raw: bool = False, no_backward: bool = False):
     keep = []
-    flags = _lib.GSR_VIEW_NO_BACKWARD if no_backward else 0
+    flags = (_lib.GSR_VIEW_NO_BACKWARD if no_backward else 0) | (_lib.GSR_VIEW_ASYNC_STATS if _async_forward else 0)
     for x, tbit in ((rs.bg, 0), (rs.viewmatrix, _lib.GSR_VIEW_VIEWMATRIX_T), (rs.projmatrix, _lib.GSR_VIEW_PROJMATRIX_T), (rs.campos, 0)):
         ok = type(x) is torch.Tensor and x.dtype is torch.float32 and x.device == device
         if ok and x.is_contiguous():
@@ -187,9 +207,11 @@ class _RasterizeGaussians(torch.autograd.Function):
                                  geom.alloc, binb.alloc, img.alloc, C.byref(stats), stream)
         geom_t, bin_t, img_t = geom.release(), binb.release(), img.release()
         _lib.check(rc, "gsr_forward")
+        global _last_pending
+        _last_pending = stats if stats.pending else None   # (an asynchronous forward: the counts are -1 until last_stats() collects them)
         _last_stats.update(M=stats.num_instances, M_ref=stats.num_instances_ref,
                            V=stats.num_visible, max_tile=stats.max_tile_count, N=N, H=H, W=W, K=K,
-                           seg_shift=stats.seg_shift, bwd_prepared=stats.bwd_prepared)
+                           seg_shift=stats.seg_shift, bwd_prepared=stats.bwd_prepared, speculated=stats.speculated, pending=stats.pending)
         ctx.raster_settings = rs
         ctx.view = (view, keep)            # the backward reuses the struct (and keeps its device constants alive)
         ctx.dims = (N, K)
@@ -226,9 +248,11 @@ class _RasterizeGaussians(torch.autograd.Function):
         H, W = int(rs.image_height), int(rs.image_width)
         # (every avoided tensor op is ~1 us of host time, and at DreamGaussian's sizes the step is host-bound: an incoming gradient
         # that is already fp32 and contiguous is taken as it is, a gradient view is ONE as_strided, a reshape to the shape it has is skipped)
-        z = lambda g, shape: (torch.zeros(shape, dtype=torch.float32, device=dev) if g is None
-                              else (g if g.dtype is torch.float32 and g.is_contiguous() else g.to(torch.float32).contiguous()))
-        gc, gd, ga = z(grad_color, (3, H, W)), z(grad_depth, (1, H, W)), z(grad_alpha, (1, H, W))
+        # an output the loss never used arrives as None (set_materialize_grads(False)) and goes to the library as NULL = zeros (ABI 6):
+        # no zero image, no fill kernel -- stage 1 never differentiates depth (main.py:198-275)
+        z = lambda g: (None if g is None
+                       else (g if g.dtype is torch.float32 and g.is_contiguous() else g.to(torch.float32).contiguous()))
+        gc, gd, ga = z(grad_color), z(grad_depth), z(grad_alpha)
         # K6 writes every element of every gradient (exact zeros for culled Gaussians): no memset
         # one allocation for all gradients, each carved out at a 256-byte boundary
         k_rest = ctx.k_rest                              # split SH: dL/dfeatures_dc and dL/dfeatures_rest are separate tensors

@@ -85,6 +85,14 @@ typedef struct GsrView {
 #define GSR_VIEW_NO_BACKWARD 4   /* no gsr_backward will follow this forward (inference): the backward's accumulators are neither allocated nor
                                   * cleared and the serial-walk forward keeps neither checkpoints nor quad masks (118 MB of stores and 0.4 GB of
                                   * scratch at 1M Gaussians / 800^2). GsrStats.bwd_prepared = -1; gsr_backward on such a state returns -1 */
+#define GSR_VIEW_ASYNC_STATS 8   /* OPT-IN (ABI 6): a gsr_forward that could size its list scratch from earlier calls of the same shape returns as soon as
+                                  * its kernels are enqueued -- the host does not wait for the instance counters (no synchronisation in
+                                  * the steady state). GsrStats then comes back with pending != 0, bin_capacity / seg_shift / bwd_prepared final (all
+                                  * gsr_backward needs) and the four counts = -1 until gsr_forward_complete(stats) -- or the thread's next gsr_forward --
+                                  * has collected them. The capacity is taken from the LARGEST of the shape's recent calls + 50 % (instead of the last
+                                  * call + 25 %). Should the lists still not fit, nobody is left to repeat the tail: the images of that call are filled
+                                  * with NaN, its backward yields zero gradients, and the thread's next gsr_forward (or gsr_forward_complete) returns -6
+                                  * without doing anything else. First call of a shape, "speculate" = 0 or stats == NULL: the blocking path as before. */
 
 /* Scratch allocator: resize(ctx, bytes) must return a device pointer, 256-byte aligned, to
  * at least `bytes` bytes that stay alive until the matching backward has run. */
@@ -110,11 +118,20 @@ typedef struct GsrStats {
                                  * 0 (the first one has accumulated into them); 0 also without GsrStats. 2: as 1, and the forward has also cleared
                                  * GsrView.grad_clear (the array the backward's outputs are carved from; same one-shot rule). -1: the
                                  * forward ran with GSR_VIEW_NO_BACKWARD and left no state for a backward */
+    int64_t speculated;         /* 1: the list scratch and the sort classes came from the thread's earlier calls of the same (N, H, W, views) -- an
+                                 * 8-entry table, least recently used shape replaced -- and binning / sort / compositing ran without waiting for the host;
+                                 * 0: first call of the shape, a prediction that turned out too small (tail repeated), or "speculate" = 0 */
+    int64_t pending;            /* != 0: an asynchronous forward (GSR_VIEW_ASYNC_STATS) whose counts have not been collected: gsr_forward_complete */
 } GsrStats;
 
-/* Bumped whenever a struct of this header changes size or meaning (GsrStats grew in 3 and 4, GsrView.reserved became flags in 4, GsrView grew in 5). A caller built against another
+/* Collects the counts of the calling thread's asynchronous forward `stats` came from (blocking until its counters have arrived; a no-op
+ * when stats->pending == 0). Must run on the thread that called gsr_forward, before that thread's forward after next. Returns 0, or -6
+ * when the forward's lists did not fit its speculative capacity (see GSR_VIEW_ASYNC_STATS). */
+int gsr_forward_complete(GsrStats* stats);
+
+/* Bumped whenever a struct of this header changes size or meaning (GsrStats grew in 3 and 4, GsrView.reserved became flags in 4, GsrView grew in 5; 6: GsrStats grew by `speculated` / `pending`, gsr_backward takes NULL incoming gradients, gsr_forward_complete). A caller built against another
  * value must not call the library: dreamgaussian_amd/_lib.py checks gsr_abi_version() at load. */
-#define GSR_ABI_VERSION 5
+#define GSR_ABI_VERSION 6
 int gsr_abi_version(void);
 
 /* TEST HOOK -- not part of the drop-in surface. Forces one of the choices the library otherwise makes from the problem shape
@@ -165,7 +182,8 @@ int gsr_forward(const GsrView* view, int32_t N, int32_t K,
                 GsrStats* stats, gsr_stream_t stream);
 
 /* Backward. Same inputs as the forward plus the incoming gradients
- *   dL_dcolor [3,H,W]  dL_ddepth [H,W]  dL_dalpha [H,W]
+ *   dL_dcolor [3,H,W]  dL_ddepth [H,W]  dL_dalpha [H,W]     (each may be NULL = zeros, ABI 6: DreamGaussian's stage 1 never differentiates
+ *   depth, main.py:198-275 -- no zero image has to be built for it)
  * and the three scratch buffers of the matching forward, plus (optional, [host]) the GsrStats
  * that forward returned -- without it the backward reads the two counters it needs back from
  * the device (one blocking copy). Outputs (dense, exact zeros for

@@ -320,3 +320,66 @@ def test_reorder_gaussians_moves_every_row_and_renders_the_same_model(gpu):
     for p in (grp["params"][0] for grp in opt.param_groups):        # the optimiser keeps stepping on the new tensors
         p.grad = torch.ones_like(p)
     opt.step()
+
+
+def test_clone_split_postfix_in_z_order_equal_the_plain_result_up_to_a_row_permutation(gpu):
+    """`densification_postfix` / `densify_and_clone` / `densify_and_split` with `zorder=True` (round 6): the same Gaussians, each with
+    its own Adam moments and (reset) accumulators, as the plain calls -- which equal the reference's sequence bit for bit (test above) --
+    leave them; only the order of the rows differs, and it IS the Z-order of the positions."""
+    N = 3000
+    names = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+
+    def build():
+        params, opt = _make(N, gpu, D.FusedAdam, seed=11)
+        with torch.no_grad():
+            params[4].mul_(0.5).sub_(4.0)
+        for p in params:
+            p.grad = torch.ones_like(p) * 0.1
+        opt.step()
+        m = _Model()
+        m.optimizer = opt
+        ga = torch.Generator().manual_seed(7)
+        m.xyz_gradient_accum, m.denom, m.max_radii2D = torch.rand(N, 1, generator=ga).to(gpu), torch.rand(N, 1, generator=ga).to(gpu), torch.rand(N, generator=ga).to(gpu)
+        for n, p in zip(names, params):
+            setattr(m, n, p)
+        return m
+
+    def same_up_to_order(a, b, what):
+        # b is the plain result; a must be b[perm] with perm = the Z-order of b's positions (distinct random positions: the key is unique)
+        perm = D.morton_order(b._xyz.detach()).long()
+        assert a._xyz.shape == b._xyz.shape, what
+        assert torch.equal(D.morton_order(a._xyz.detach()).long(), torch.arange(a._xyz.shape[0], device=gpu)), what    # a IS on the curve
+        for ga_, gb_, n in zip(a.optimizer.param_groups, b.optimizer.param_groups, names):
+            pa, pb = ga_["params"][0], gb_["params"][0]
+            assert pa is getattr(a, n) and pa.requires_grad, (what, n)
+            assert torch.equal(pa.detach(), pb.detach()[perm]), (what, n)
+            assert torch.equal(a.optimizer.state[pa]["exp_avg"], b.optimizer.state[pb]["exp_avg"][perm]), (what, n)
+            assert torch.equal(a.optimizer.state[pa]["exp_avg_sq"], b.optimizer.state[pb]["exp_avg_sq"][perm]), (what, n)
+        assert torch.equal(a.xyz_gradient_accum, b.xyz_gradient_accum[perm]) and torch.equal(a.denom, b.denom[perm]) and torch.equal(a.max_radii2D, b.max_radii2D[perm]), what
+
+    grads = torch.rand(N, 1, generator=torch.Generator().manual_seed(3)).to(gpu)
+    thr, extent = 0.4, 2.0
+    # ---- postfix on its own
+    a, b = build(), build()
+    g = torch.Generator().manual_seed(21)
+    new = [torch.rand(40, 3, generator=g), torch.rand(40, 1, 3, generator=g), torch.rand(40, 15, 3, generator=g), torch.rand(40, 1, generator=g),
+           torch.rand(40, 3, generator=g), torch.rand(40, 4, generator=g)]
+    new = [t.to(gpu) for t in new]
+    new[2] = new[2][:, :a._features_rest.shape[1]].contiguous()
+    D.densification_postfix(a, *new, zorder=True)
+    D.densification_postfix(b, *new)
+    same_up_to_order(a, b, "postfix")
+    # ---- clone, then split (the same random draw on both sides: the selection is made before anything is permuted)
+    a, b = build(), build()
+    D.densify_and_clone(a, grads, thr, extent, zorder=True)
+    D.densify_and_clone(b, grads, thr, extent)
+    same_up_to_order(a, b, "clone")
+    a, b = build(), build()
+    torch.manual_seed(5); torch.cuda.manual_seed(5)
+    D.densify_and_split(a, grads, thr, extent, N=2, build_rotation=_build_rotation, zorder=True)
+    torch.manual_seed(5); torch.cuda.manual_seed(5)
+    D.densify_and_split(b, grads, thr, extent, N=2, build_rotation=_build_rotation)
+    same_up_to_order(a, b, "split")
+    for p in (g_["params"][0] for g_ in a.optimizer.param_groups):   # the optimiser keeps stepping on the new tensors
+        p.grad = torch.ones_like(p)
+    a.optimizer.step()

@@ -1,0 +1,35 @@
+#!/bin/bash
+# gpurun driver (round 6): sections chosen by arguments; shared sections live in tools/gpu_r5.sh. Outputs -> gpurun_out/.
+#   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/gpu_r6.sh hostpath ab'
+R=$(pwd)
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+line() { python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], json.dumps(d['kernels_ms_per_step']))"; }
+for sec in "$@"; do
+case $sec in
+hostpath)
+  echo "== pytest: host path (ABI 6) + K6c"
+  timeout ${QUICK_TIMEOUT:-600} python -m pytest tests/test_hostpath_gpu.py tests/test_parity_gpu.py -m gpu -q -x -p no:cacheprovider --tb=short -rf \
+      -k "${NEW_K:-hostpath or k6_compact or speculative or gradient_arrays_cleared or backward_without_forward_stats or forward_backward_match_oracle}" > gpurun_out/pytest_hostpath.log 2>&1
+  grep -a "passed\|failed\|FAILED\|Error\|assert" gpurun_out/pytest_hostpath.log | cut -c1-300 | tail -20;;
+ab)
+  # same-box A/B of library builds: AB_LIBS="none _exp/libgsr_x.so", AB_WL="1M-800-sh3 1M-800-sh3:trained", AB_REP (default 2)
+  for rep in $(seq 1 ${AB_REP:-2}); do for wl in ${AB_WL:-1M-800-sh3}; do
+    kind=blob; [ "${wl#*:}" != "$wl" ] && kind=${wl#*:}
+    for l in $AB_LIBS; do
+      echo "== [$l] $wl"
+      if [ $l = none ]; then python bench.py --workload ${wl%%:*} --kind $kind --cpu-budget 0 --steps 60 --warmup 10 $BENCH_ARGS 2>>gpurun_out/ab_err.log | tee -a gpurun_out/ab.jsonl | line
+      else GSR_LIB=$R/$l python bench.py --workload ${wl%%:*} --kind $kind --cpu-budget 0 --steps 60 --warmup 10 $BENCH_ARGS 2>>gpurun_out/ab_err.log | tee -a gpurun_out/ab.jsonl | line; fi
+    done
+  done; done;;
+order)
+  rm -f gpurun_out/bench_order.jsonl
+  for wl in ${ORDER_WL:-1M-800-sh3 1M-800-sh3:trained}; do
+    kind=blob; [ "${wl#*:}" != "$wl" ] && kind=${wl#*:}
+    for o in given morton; do
+      echo "== bench $wl --order $o"; timeout 300 python bench.py --workload ${wl%%:*} --kind $kind --order $o --cpu-budget 0 --steps 60 --warmup 10 2>> gpurun_out/bench_order.err | tee -a gpurun_out/bench_order.jsonl | line
+    done
+  done;;
+*) bash tools/gpu_r5.sh $sec;;
+esac
+done
