@@ -221,7 +221,7 @@ def run_sds(a, dev, rank, world):
     import torch.distributed as dist
     import dreamgaussian_amd as D
     from dreamgaussian_amd import views
-    wl = WORKLOADS["250k-512-sh0"]
+    wl = WORKLOADS[getattr(a, "sds_workload", None) or "250k-512-sh0"]
     azimuth = 360.0 * rank / max(world, 1)
     sc, _, rs, _ = build_inputs(wl, a.kind, dev, azimuth, a.order)
     t = {k: v.to(dev).requires_grad_(True) for k, v in sc.items()}
@@ -230,6 +230,16 @@ def run_sds(a, dev, rank, world):
     H, W = wl["H"], wl["W"]
     wimg = torch.rand(world, 5, H, W, generator=torch.Generator().manual_seed(7)).to(dev) if rank == 0 else None
     params = list(t.values())
+    # --reduce sharded: reduce-scatter of the gradient span, the Adam step on this rank's 1/N slice, all-gather of the parameters
+    # (views.ShardedAdam; lr = 0: the scene stays the benchmark's); --reduce live: only the rows some rank has a gradient for
+    # (views.allreduce_live_rows); --sds-adam: the dense / live modes also take the (full) Adam step inside the timed region
+    reduce_mode = getattr(a, "reduce", "dense")
+    opt = sharded = None
+    if reduce_mode == "sharded" or getattr(a, "sds_adam", False):
+        opt = D.FusedAdam([{"params": [p], "lr": 0.0} for p in params], lr=0.0, eps=1e-15)
+        if reduce_mode == "sharded":
+            sharded = views.ShardedAdam(opt)
+    live_stat = [0, 0]
 
     wmine = torch.rand(world, 5, H, W, generator=torch.Generator().manual_seed(7))[rank:rank + 1].to(dev)   # (the same weights, this rank's view)
     pending = [None]
@@ -253,7 +263,17 @@ def run_sds(a, dev, rank, world):
             views.allreduce_grads(params)
         else:                                            # "local": the same loss, every rank differentiating its own view's term
             torch.autograd.backward([local], [(local.detach() - 0.5) * wmine])
-            pending[0] = views.allreduce_grads(params, async_op=True)
+            if sharded is not None:
+                sharded.step()
+            elif reduce_mode == "live":
+                live_stat[0], live_stat[1] = views.allreduce_live_rows(params, probe=[0, 2])     # positions and opacities decide
+                if opt is not None:
+                    opt.step()
+            else:
+                pending[0] = views.allreduce_grads(params, async_op=True)
+                if opt is not None:
+                    pending[0] and pending[0].wait(); pending[0] = None
+                    opt.step()
 
     def sync():
         if world > 1:
@@ -286,8 +306,12 @@ def run_sds(a, dev, rank, world):
     return {"workload": f"BASELINE.json configs[3]: {wl['N']} Gaussians, SH degree {wl['deg']}, {W}x{H}, one orbit view per "
                         f"GPU ({world} views), scene '{a.kind}'",
             "timed": ("fwd + RCCL gather(images) + loss grad on rank 0 + scatter(dL/dimage) + bwd + all-reduce(grads)" if a.sds_mode == "gather" else
-                      "fwd + loss grad of the own view on every rank + bwd + all-reduce(grads), asynchronous: waited for at the top of the next step"),
-            "sds_mode": a.sds_mode,
+                      {"dense": "fwd + loss grad of the own view on every rank + bwd + all-reduce(grads), asynchronous: waited for at the top of the next step",
+                       "sharded": "fwd + loss grad of the own view + bwd + reduce-scatter(grads) + Adam on the own 1/N slice + all-gather(parameters)",
+                       "live": "fwd + loss grad of the own view + bwd + all-reduce(live flags, N bytes) + all-reduce(the union's rows)"}[reduce_mode]
+                      + (" + Adam step (all rows, every rank)" if opt is not None and sharded is None else "")),
+            "sds_mode": a.sds_mode, "reduce": reduce_mode if a.sds_mode == "local" else "dense",
+            **({"live_rows": live_stat[0], "rows": live_stat[1]} if reduce_mode == "live" else {}),
             "value": round(H * W * world * a.steps / dt / 1e6, 3), "unit": "Mrays/s", "ms_per_step": round(dt / a.steps * 1e3, 4),
             "views_per_step": world, "image_bytes_per_view": 5 * H * W * 4, "allreduce_bytes": grad_bytes,
             "M": st.get("M_ref"), "M_emitted": st.get("M")}
@@ -304,10 +328,16 @@ def main():
     ap.add_argument("--step", default="render", choices=["render", "sds"],
                     help="render = rasterizer fwd+bwd (+ RCCL gather of the images when N>1): the headline metric; "
                          "sds = the multi-view SDS exchange on BASELINE configs[3] (see the module docstring)")
-    ap.add_argument("--sds-mode", default="local", choices=["local", "gather"],
+    ap.add_argument("--sds-mode", default="gather", choices=["local", "gather"],
                     help="--step sds: where the image-space loss is evaluated (dreamgaussian_amd/views.py): local = every rank differentiates its "
                          "own view's term, the all-reduce of the parameter gradients is the only collective; gather = rank 0 evaluates it "
                          "for all views (gather of the images, scatter of dL/dimage, all-reduce)")
+    ap.add_argument("--reduce", default="dense", choices=["dense", "sharded", "live"],
+                    help="--step sds --sds-mode local: how the parameter gradients meet (dreamgaussian_amd/views.py): dense = one all-reduce over "
+                         "their span; sharded = reduce-scatter + Adam on the own slice + all-gather of the parameters (ShardedAdam); live = "
+                         "all-reduce of the rows that carry a gradient on some rank only (allreduce_live_rows)")
+    ap.add_argument("--sds-adam", action="store_true", help="--step sds: the dense / live modes also take the Adam step inside the timed region")
+    ap.add_argument("--sds-workload", default=None, choices=sorted(WORKLOADS), help="--step sds on another scene than BASELINE configs[3] (e.g. 1M-800-sh3: 62 MB of gradients)")
     ap.add_argument("--order", default="given", choices=["given", "morton"],
                     help="given = the Gaussians in the order the scene generator made them (random in space: the reference's init and "
                          "the headline metric); morton = rows permuted along a Z-order curve first (dreamgaussian_amd.reorder_gaussians)")
@@ -372,7 +402,7 @@ def main():
                    "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": res["ms_per_step"],
                    "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                    "config": {"workload": res["workload"], "parallelism": f"view-parallel x{world}" if world > 1 else ("single GPU, collectives through a 1-rank RCCL group" if a.force_collectives else "single GPU"),
-                              "timed": res["timed"], "sds_mode": res["sds_mode"], "allreduce_bytes": res["allreduce_bytes"],
+                              "timed": res["timed"], "sds_mode": res["sds_mode"], "reduce": res.get("reduce"), "live_rows": res.get("live_rows"), "allreduce_bytes": res["allreduce_bytes"],
                               "image_bytes_per_view": res["image_bytes_per_view"], "M": res["M"], "M_emitted": res["M_emitted"]},
                    "roofline": None, "cpu_baseline": None}
             print(json.dumps(out), flush=True)
@@ -556,11 +586,16 @@ def main():
     if world > 1:
         dist.barrier()
 
-    sds = None
+    sds = sds_local = None
     if world > 1 and a.views == 1 and a.activations == "none":
         for v in list(t.values()) + [m2d]:         # release the headline scene before the second measurement
             v.grad = None
+        # both placements of the loss, each under its own name (round-5 advisor: one default that changed between rounds made the
+        # rounds' sds_step figures incomparable)
+        a.sds_mode = "gather"
         sds = run_sds(a, dev, rank, world)
+        a.sds_mode = "local"
+        sds_local = run_sds(a, dev, rank, world)
 
     cpu = None
     if rank == 0 and world == 1 and a.cpu_budget > 0:
@@ -595,6 +630,7 @@ def main():
         }
         if sds is not None:
             out["sds_step"] = sds
+            out["sds_step_local"] = sds_local
         if naive is not None:
             out["naive_gpu"] = naive
         print(json.dumps(out), flush=True)

@@ -606,13 +606,17 @@ template __global__ void gsr_render_fwd_serial<true>(const uint32_t*, const Spla
 // Wave priorities inside the pair kernel (s_setprio, 0..3). The BLENDER of a block is the chain the kernel's length is made of; its
 // tester has slack (it is at most a round ahead and waits for a free buffer). Round 6, same box, 1M Gaussians / 800^2: blender 3 /
 // tester 0 takes the forward compositing from 0.1464 to 0.1310 ms -- the blenders issue whenever they can, the testers of all blocks
-// fill the slots the blenders leave. (Priorities among the waves of the SERIAL walk, where every wave is a chain, did nothing in
+// fill the slots the blenders leave --, tester 1 (above the finished blocks' output / zero stores, which run at 0) to 0.1277; blender 2 = blender 3;
+// keeping 3 through the tail 0.1331; levels that rise with the depth walked 0.134-0.138; four workgroups per CU (<= 64 VGPRs) 0.155. (Priorities among the waves of the SERIAL walk, where every wave is a chain, did nothing in
 // round 4: 0.1536 / 0.1536.)
 #ifndef GSR_PAIR_PRIO_B
 #define GSR_PAIR_PRIO_B 3
 #endif
 #ifndef GSR_PAIR_PRIO_T
-#define GSR_PAIR_PRIO_T 0
+#define GSR_PAIR_PRIO_T 1
+#endif
+#ifndef GSR_PAIR_PRIO_ADAPT
+#define GSR_PAIR_PRIO_ADAPT 0     // experiment: a tester that finds its buffer free at once (its blender is waiting for IT) takes the blender's level for the round
 #endif
 #ifndef GSR_PAIR_PRIO_TAIL
 #define GSR_PAIR_PRIO_TAIL 0      // priority of the blender behind its walk (outputs, work items, the slices of zeros)
@@ -750,6 +754,9 @@ gsr_render_fwd_pair(const uint32_t* __restrict__ tile_off, const SplatRec* __res
                 *((lane < 4 && keep_state) ? mp + lane : sink64) = lane == 0 ? m0 : (lane == 1 ? m1 : (lane == 2 ? m2 : m3));
             }
             // the buffer is free once the blender has left round r - 2
+            if (GSR_PAIR_PRIO_ADAPT && r >= 2u) {
+                if (lds_flag_load(&freed[blk][buf]) == r - 1u) __builtin_amdgcn_s_setprio(GSR_PAIR_PRIO_B); else __builtin_amdgcn_s_setprio(GSR_PAIR_PRIO_T);
+            }
             if (r >= 2u) { if (!wait_free(&freed[blk][buf], r - 1u)) return false; }
             else if (lds_flag_load(&freed[blk][buf]) == GSR_PAIR_STOP) return false;
             alive = __hip_atomic_load(&alive_pub[blk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // gate of the NEXT round's quads (a superset of the pixels alive then)

@@ -75,7 +75,7 @@ def test_absent_incoming_gradients_are_zeros(gpu, use):
     _, gb = _render(sc, S, gpu, wz, (True, True, True))
     for k in ga:
         scale = gb[k].abs().max().item() + 1e-30
-        assert (ga[k] - gb[k]).abs().max().item() <= 2e-6 * scale, k
+        assert (ga[k] - gb[k]).abs().max().item() <= 1e-5 * scale, k
         assert torch.isfinite(ga[k]).all()
 
 
@@ -118,7 +118,7 @@ def test_async_forward_matches_the_blocking_one(gpu):
                 assert torch.equal(a, b)
             for k in g:
                 scale = g_ref[k].abs().max().item() + 1e-30
-                assert (g[k] - g_ref[k]).abs().max().item() <= 2e-6 * scale, k
+                assert (g[k] - g_ref[k]).abs().max().item() <= 1e-5 * scale, k
     finally:
         D.set_async_forward(old)
 
@@ -182,4 +182,4 @@ def test_two_threads_two_streams(gpu):
             assert torch.equal(a, b)
         for k in g:
             scale = g_ref[k].abs().max().item() + 1e-30
-            assert (g[k] - g_ref[k]).abs().max().item() <= 2e-6 * scale, (i, k)
+            assert (g[k] - g_ref[k]).abs().max().item() <= 1e-5 * scale, (i, k)     # (the order of the float atomics differs from run to run)

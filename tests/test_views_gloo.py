@@ -315,3 +315,98 @@ def test_gather_fallback_is_counted_and_refused_under_nccl(monkeypatch):
     with pytest.raises(RuntimeError, match="no gather"):
         views.gather_views_async(c, d, a, buf)
     monkeypatch.setattr(views, "gather_fallbacks", before)
+
+
+def _worker_sharded(rank, world, port, q):
+    """ShardedAdam (reduce-scatter -> Adam on the own slice -> all-gather of the parameters) and allreduce_live_rows against the
+    replicated path (dense all-reduce + torch.optim.Adam on every rank), on the split-entry gradient layout at SH degree 3 and on
+    gradients that do not share a storage."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dreamgaussian_amd import views
+        from dreamgaussian_amd.rasterizer import carve_gradients
+        N = 203
+        widths = [3, 1, 3, 0, 3, 4, 0, 45, 3]
+        names = ["xyz", "opacity", "f_dc", None, "scaling", "rotation", None, "f_rest", "means2D"]
+        lrs = {"xyz": 1e-3, "opacity": 5e-2, "f_dc": 1e-2, "scaling": 5e-3, "rotation": 5e-3, "f_rest": 5e-4}
+        out = {}
+        for layout in ("span", "separate"):
+            g0 = torch.Generator().manual_seed(100)
+            init = {nm: torch.randn(N, widths[i], generator=g0) for i, nm in enumerate(names) if nm not in (None, "means2D")}
+            pa = {nm: torch.nn.Parameter(v.clone()) for nm, v in init.items()}      # sharded path
+            pb = {nm: torch.nn.Parameter(v.clone()) for nm, v in init.items()}      # replicated path
+            oa = torch.optim.Adam([{"params": [pa[nm]], "lr": lrs[nm], "name": nm} for nm in pa], lr=0.0, eps=1e-15)
+            ob = torch.optim.Adam([{"params": [pb[nm]], "lr": lrs[nm], "name": nm} for nm in pb], lr=0.0, eps=1e-15)
+            sh = views.ShardedAdam(oa)
+            for it in range(3):
+                gr = torch.Generator().manual_seed(1000 * it + rank)           # every rank its own gradients
+                vals = {nm: torch.randn(N, widths[names.index(nm)], generator=gr) for nm in pa}
+                if layout == "span":
+                    flat, offs = carve_gradients(N, widths, "cpu")
+                    flat.fill_(float("nan"))                                   # padding: never read into a result
+                    for i, nm in enumerate(names):
+                        if nm is None:
+                            continue
+                        g = flat[offs[i]:offs[i] + N * widths[i]].view(N, widths[i])
+                        if nm == "means2D":
+                            g.fill_(7.0)
+                        else:
+                            g.copy_(vals[nm]); pa[nm].grad = g
+                else:
+                    for nm in pa:
+                        pa[nm].grad = vals[nm].clone()
+                for nm in pb:
+                    pb[nm].grad = vals[nm].clone()
+                views.allreduce_grads(list(pb.values()))
+                ob.step()
+                sh.step()
+                if layout == "span":
+                    out["means2D_untouched"] = bool((flat[offs[8]:offs[8] + 3 * N] == 7.0).all())
+            sh.gather_state()
+            ok = True
+            for nm in pa:
+                # (equal up to the order of the fp32 sums: reduce-scatter and all-reduce add the ranks' gradients in different orders)
+                ok = ok and torch.allclose(pa[nm].detach(), pb[nm].detach(), rtol=2e-6, atol=2e-6 * lrs[nm] * 3 + 1e-7)
+                for key in ("exp_avg", "exp_avg_sq"):
+                    ref = ob.state[pb[nm]][key]
+                    ok = ok and torch.allclose(oa.state[pa[nm]][key], ref, rtol=2e-6, atol=2e-6 * float(ref.abs().max()))
+                ok = ok and float(oa.state[pa[nm]]["step"]) == 3.0
+            out["sharded_" + layout] = ok
+            out["moved_" + layout] = all(not torch.equal(pa[nm].detach(), init[nm]) for nm in pa)
+        # ---- live rows: a quarter of the Gaussians carries a gradient on each rank
+        g0 = torch.Generator().manual_seed(7)
+        ps = [torch.nn.Parameter(torch.zeros(N, w)) for w in (3, 1, 48)]
+        qs = [torch.nn.Parameter(torch.zeros(N, w)) for w in (3, 1, 48)]
+        gr = torch.Generator().manual_seed(50 + rank)
+        live = torch.rand(N, generator=gr) < 0.25
+        for p, qq in zip(ps, qs):
+            g = torch.randn(p.shape, generator=gr) * live[:, None]
+            p.grad, qq.grad = g.clone(), g.clone()
+        U, n = views.allreduce_live_rows(ps, probe=[0, 1])
+        views.allreduce_grads(qs)
+        out["live_equal"] = all(torch.allclose(p.grad, qq.grad, rtol=1e-6, atol=1e-7) for p, qq in zip(ps, qs))
+        out["live_fraction_sane"] = 0 < U < n == N
+        q.put(dict(rank=rank, U=U, **out))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_adam_and_live_row_exchange_equal_the_replicated_path(world):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_sharded, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len({r["U"] for r in res}) == 1                 # every rank exchanged the same union
+    for r in res:
+        assert all(v for k, v in r.items() if k not in ("rank", "U")), sorted((k, v) for k, v in r.items() if not v)

@@ -30,6 +30,13 @@ order)
       echo "== bench $wl --order $o"; timeout 300 python bench.py --workload ${wl%%:*} --kind $kind --order $o --cpu-budget 0 --steps 60 --warmup 10 2>> gpurun_out/bench_order.err | tee -a gpurun_out/bench_order.jsonl | line
     done
   done;;
+reduce)
+  # the gradient exchange of the "local" SDS step through a ONE-rank RCCL group: dense all-reduce / sharded Adam / live rows, at
+  # BASELINE configs[3] and at 1M / SH 3 (62 MB of gradients)
+  rm -f gpurun_out/sds_reduce.jsonl
+  for wl in 250k-512-sh0 1M-800-sh3; do for m in "--reduce dense" "--reduce dense --sds-adam" "--reduce sharded" "--reduce live" "--reduce live --sds-adam"; do
+    echo "== sds local $wl $m"; timeout 300 python bench.py --step sds --sds-mode local --sds-workload $wl $m --force-collectives --cpu-budget 0 --steps 40 --warmup 10 2>>gpurun_out/sds_reduce.err | grep -a "^{" | tee -a gpurun_out/sds_reduce.jsonl | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], 'ms', d['config'].get('reduce'), d['config'].get('live_rows'))"
+  done; done;;
 *) bash tools/gpu_r5.sh $sec;;
 esac
 done
