@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("GSR_LIB") or os.path.join(_HERE, "libgsr.so")
 
 GSR_MAX_VIEWS = 16      # include/gsr.h
 GSR_ABI_VERSION = 6     # include/gsr.h
-GSR_VIEW_VIEWMATRIX_T, GSR_VIEW_PROJMATRIX_T, GSR_VIEW_NO_BACKWARD, GSR_VIEW_ASYNC_STATS = 1, 2, 4, 8   # GsrView.flags
+GSR_VIEW_VIEWMATRIX_T, GSR_VIEW_PROJMATRIX_T, GSR_VIEW_NO_BACKWARD, GSR_VIEW_ASYNC_STATS, GSR_VIEW_DETERMINISTIC = 1, 2, 4, 8, 16   # GsrView.flags
 
 EXPORTS = ("gsr_forward", "gsr_forward_complete", "gsr_backward", "gsr_forward_views", "gsr_backward_views", "gsr_mark_visible", "gsr_dist2", "gsr_extract_fields", "gsr_densify_stats",
            "gsr_adam_step", "gsr_mask_compact", "gsr_gather_rows", "gsr_concat_rows",

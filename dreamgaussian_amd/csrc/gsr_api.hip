@@ -900,17 +900,26 @@ int backward_impl(const GsrView* views, int B, int32_t N, int32_t K,
     const size_t g2d_view = (size_t)N * GSR_G2D_STRIDE;
     float* g2d = nullptr;
     const bool grads_cleared = fwd_stats && fwd_stats->bwd_prepared == 2;   // ... and GsrView.grad_clear with them
-    if (fwd_stats && fwd_stats->bwd_prepared >= 1) {
-        g2d = (float*)(const_cast<char*>(gbuf) + GL.g2d);   // cleared by the forward (forward_impl)
-    } else {                                              // no GsrStats, GSR_VIEW_NO_BACKWARD, or a second backward of the same forward
+    // GSR_VIEW_DETERMINISTIC: the compositing kernel's sums meet in 64-bit fixed point ([views][N][10] u64 + the two words of
+    // gsr_grad_absmax, from `tmp`, cleared here) and gsr_g2d_from_fixed turns them into the float accumulators: bit-identical
+    // gradients from run to run (gsr_render.hip)
+    const bool det = M > 0 && (view->flags & GSR_VIEW_DETERMINISTIC) != 0;
+    const size_t det_bytes = det ? align_up((size_t)B * (size_t)N * GSR_Q2_ROW * 8 + 256) : 0;
+    const bool own_acc = !(fwd_stats && fwd_stats->bwd_prepared >= 1);   // no GsrStats, or a second backward of the same forward
+    const size_t acc_bytes = g2d_view * 4 * (size_t)B + (size_t)B * GSR_LIVE_BYTES(N);   // accumulators | live flags
+    char* tbuf = nullptr;
+    if (own_acc || det) {
         if (!tmp.resize) return fail(-1, "tmp allocator is required%s", "");
-        const size_t acc_bytes = g2d_view * 4 * (size_t)B + (size_t)B * GSR_LIVE_BYTES(N);   // accumulators | live flags
-        g2d = (float*)tmp.resize(tmp.ctx, align_up(acc_bytes));
-        if (!g2d) return fail(-4, "tmp scratch allocation failed%s", "");
+        tbuf = (char*)tmp.resize(tmp.ctx, det_bytes + (own_acc ? align_up(acc_bytes) : 0));
+        if (!tbuf) return fail(-4, "tmp scratch allocation failed%s", "");
         prof_begin(stream);
-        HIP_TRY(hipMemsetAsync(g2d, 0, acc_bytes, stream));
+        HIP_TRY(hipMemsetAsync(tbuf, 0, det_bytes + (own_acc ? acc_bytes : 0), stream));
         prof_end(stream, "memset_bwd");
     }
+    unsigned long long* det64 = det ? (unsigned long long*)(tbuf + 256) : nullptr;
+    uint32_t* det_gmax = det ? (uint32_t*)tbuf : nullptr;
+    if (!own_acc) g2d = (float*)(const_cast<char*>(gbuf) + GL.g2d);   // cleared by the forward (forward_impl)
+    else g2d = (float*)(tbuf + det_bytes);
     uint8_t* live = (uint8_t*)(g2d + g2d_view * (size_t)B);
 
     // ONE view, concatenated SH layout (gsr_preprocess_bwd_compact): the compositing kernel clears every gradient array on the side and
@@ -948,6 +957,14 @@ int backward_impl(const GsrView* views, int B, int32_t N, int32_t K,
     if (!dL_dcolor) { dL_dcolor = totals; gnull |= 1u; }
     if (!dL_ddepth) { dL_ddepth = totals; gnull |= 2u; }
     if (!dL_dalpha) { dL_dalpha = totals; gnull |= 4u; }
+    if (det) {
+        const size_t HWp = (size_t)H * W;
+        const size_t npx = HWp * (size_t)B;
+        prof_begin(stream);
+        hipLaunchKernelGGL(gsr_grad_absmax, dim3((unsigned)((npx + 255) / 256 < 1024 ? (npx + 255) / 256 : 1024)), dim3(256), 0, stream,
+                           dL_dcolor, dL_ddepth, dL_dalpha, gnull, HWp, B, vs, det_gmax);
+        LAUNCH_CHECK(view, stream, "grad_absmax");
+    }
     prof_begin(stream);
     if (M > 0) {
         const BinLayout BL = bin_layout((size_t)M, TA, shift);
@@ -966,9 +983,16 @@ int backward_impl(const GsrView* views, int B, int32_t N, int32_t K,
         const size_t dyn = ((size_t)GSR_Q2_ROW * 8) << shift;
         hipLaunchKernelGGL(gsr_render_bwd_q2, dim3(grid), dim3(256), dyn, stream, tile_off, recs, sorted_ids, W, H, vc.gx,
                            final_T, n_contrib, totals, ckpt, tile_seg, dL_dcolor, dL_ddepth, dL_dalpha, g2d, shift,
-                           plan_tile, plan_off, plan_total, vs, zr, live, gnull);
+                           plan_tile, plan_off, plan_total, vs, zr, live, gnull, det64, det_gmax);
     }
     LAUNCH_CHECK(view, stream, "render_bwd");
+    if (det) {
+        const size_t rows = (size_t)N * (size_t)B;
+        prof_begin(stream);
+        hipLaunchKernelGGL(gsr_g2d_from_fixed, dim3((unsigned)((rows + 255) / 256 < 4096 ? (rows + 255) / 256 : 4096)), dim3(256), 0, stream,
+                           N, B, recs, det64, det_gmax, counters + 4, g2d, live);
+        LAUNCH_CHECK(view, stream, "g2d_from_fixed");
+    }
 
     const int k6_grid = ov(OV_K6_GRID) < 1 ? 2048 : ov(OV_K6_GRID);   // (test hook: A/B runs)
     // K6 runs on 128-thread workgroups when it stages SH rows (25 KiB of LDS each, six per CU): a batch is a chain -- inputs, staged

@@ -1199,7 +1199,9 @@ gsr_render_fwd_fix(const uint2* __restrict__ walk_items, const unsigned long lon
     float* __restrict__ g2d, int seg_shift, const uint4* __restrict__ plan_items,                 \
     const uint32_t* __restrict__ plan_off, const unsigned long long* __restrict__ plan_total,     \
     ViewSplit vs, ZeroRegions zr, uint8_t* __restrict__ live /* [views][GSR_LIVE_BYTES(N)], cleared with g2d */,               \
-    uint32_t gnull /* bit 0 / 1 / 2: the caller passed no dL_dcolor / dL_ddepth / dL_dalpha (zeros; the pointer is a readable dummy) */
+    uint32_t gnull /* bit 0 / 1 / 2: the caller passed no dL_dcolor / dL_ddepth / dL_dalpha (zeros; the pointer is a readable dummy) */, \
+    unsigned long long* __restrict__ det64 /* GSR_VIEW_DETERMINISTIC: [views][N][GSR_Q2_ROW] 64-bit fixed-point sums (zeroed), else NULL */, \
+    const uint32_t* __restrict__ det_gmax /* ... and the bits of the largest |incoming gradient| sum of any pixel (gsr_grad_absmax) */
 
 // -----------------------------------------------------------------------------------------
 // K5b: quad lists + two passes + fixed-point accumulation.
@@ -1267,6 +1269,95 @@ __device__ __forceinline__ float from_fixed(unsigned long long v, int e) {
 // exponent with 2^result > R for the per-row scale of the moments; the SAME expression in pass 2 and in the flush
 __device__ __forceinline__ int row_radius_exp(float gx, float gy, float tcx, float tcy) {
     return __builtin_amdgcn_frexp_expf(fmaxf(fabsf(gx - tcx), fabsf(gy - tcy)) + 7.5f);
+}
+
+// ---- the deterministic backward (GSR_VIEW_DETERMINISTIC) ------------------------------------------------------------------------
+// The default flush adds every workgroup's ten per-Gaussian sums to the accumulators with FLOAT atomics: a Gaussian that lies in k
+// tiles receives k additions in whatever order the workgroups finish, and fp32 addition is not associative -- the gradients are
+// reproducible up to the last bits only. In this mode the sums travel as 64-bit FIXED-POINT integers whose
+// scale every contributor of a Gaussian derives from the same data -- integer addition is associative, so the totals (and every
+// gradient behind them) are bit-identical from run to run:
+//   e0g  from the LAUNCH's largest per-pixel gradient sum (gsr_grad_absmax, one small kernel in front) and K1's colour / depth
+//        bound, exactly as the workgroup table's e0 is derived from the tile's;
+//   eT   2^eT >= the tiles of the Gaussian's emission rectangle (at most that many workgroups add to it);
+//   eR   2^eR > the largest |dx|, |dy| between the Gaussian's centre and any pixel of that rectangle;
+// zeroth moments and colour sums at 2^(e0g - eT), first moments at 2^(e0g - eT - eR), second at 2^(e0g - eT - 2 eR).
+// gsr_g2d_from_fixed then turns the totals into the float accumulator layout K6 reads (and sets the live flags).
+__device__ __forceinline__ void det_exponents(float gx, float gy, uint32_t rectx, uint32_t recty, int& eT, int& eR) {
+    const int x0 = (int)(rectx & 0xffffu), x1 = (int)(rectx >> 16), y0 = (int)(recty & 0xffffu), y1 = (int)(recty >> 16);
+    const int nt = max(1, (x1 - x0) * (y1 - y0));
+    eT = 32 - __builtin_clz((unsigned)nt);                // 2^eT > nt
+    const float rx = fmaxf(fabsf(gx - (float)(x0 * GSR_TILE)), fabsf((float)(x1 * GSR_TILE) - gx));
+    const float ry = fmaxf(fabsf(gy - (float)(y0 * GSR_TILE)), fabsf((float)(y1 * GSR_TILE) - gy));
+    eR = __builtin_amdgcn_frexp_expf(fmaxf(rx, ry) + 1.f);
+}
+// det_gmax[0] = bits of the launch's largest per-pixel gradient sum, [1] = of the largest |background| component; cmax_k1 = K1's bound
+__device__ __forceinline__ int det_e0(const uint32_t* __restrict__ det_gmax, float cmax_k1) {
+    const uint32_t gb = det_gmax[0];
+    const float g = gb >= 0x7f800000u ? 1.f : __uint_as_float(gb);
+    const float cmax = fmaxf(fmaxf(cmax_k1, 1.f), __uint_as_float(det_gmax[1]));
+    return 60 - __builtin_amdgcn_frexp_expf(25856.f * cmax * fmaxf(g, 1e-30f));
+}
+// bits of max over the pixels of |gC0| + |gC1| + |gC2| + |gD| + |gA| (non-negative floats order like their bits; NaN / inf end up >= 0x7f800000)
+extern "C" __global__ void __launch_bounds__(256)
+gsr_grad_absmax(const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha,
+                uint32_t gnull, size_t HW, int views, ViewSplit vs, uint32_t* __restrict__ out /* [0] gradients, [1] max |background| */) {
+    if (blockIdx.x == 0 && (int)threadIdx.x < views) {
+        const float* bg = vs.bg[threadIdx.x];
+        atomicMax(out + 1, __float_as_uint(fmaxf(fabsf(bg[0]), fmaxf(fabsf(bg[1]), fabsf(bg[2])))));
+    }
+    uint32_t m = 0u;
+    const size_t total = HW * (size_t)views;
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < total; i += (size_t)gridDim.x * 256u) {
+        const size_t v = i / HW, p = i - v * HW;
+        float sgm = 0.f;
+        if (!(gnull & 1u)) sgm += fabsf(dL_dcolor[v * 3 * HW + p]) + fabsf(dL_dcolor[v * 3 * HW + HW + p]) + fabsf(dL_dcolor[v * 3 * HW + 2 * HW + p]);
+        if (!(gnull & 2u)) sgm += fabsf(dL_ddepth[i]);
+        if (!(gnull & 4u)) sgm += fabsf(dL_dalpha[i]);
+        m = max(m, __float_as_uint(sgm));
+    }
+    m = wave_max_u32(m);
+    if ((threadIdx.x & 63u) == 0u && m) atomicMax(out, m);
+}
+// the fixed-point totals -> the accumulator layout of the float flush (out[0..9] there), live flags
+extern "C" __global__ void __launch_bounds__(256)
+gsr_g2d_from_fixed(int N, int views, const SplatRec* __restrict__ recs, const unsigned long long* __restrict__ det64,
+                   const uint32_t* __restrict__ det_gmax, const unsigned long long* __restrict__ plan_total,
+                   float* __restrict__ g2d, uint8_t* __restrict__ live) {
+    const size_t total = (size_t)N * (size_t)views;
+    const uint32_t gbits = det_gmax[0];
+    const bool poisoned = gbits >= 0x7f800000u;
+    const int e0g = det_e0(det_gmax, __uint_as_float((uint32_t)plan_total[1]));
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < total; i += (size_t)gridDim.x * 256u) {
+        const unsigned long long* v = det64 + i * GSR_Q2_ROW;
+        unsigned long long w[GSR_Q2_ROW];
+        bool any = false;
+#pragma unroll
+        for (int q = 0; q < GSR_Q2_ROW; ++q) { w[q] = v[q]; any = any || (w[q] != 0ull); }
+        if (!any) continue;                               // (accumulators and flags were cleared with the rest)
+        const SplatRec r = recs[i];
+        int eT, eR;
+        det_exponents(r.x, r.y, r.rectx, r.recty, eT, eR);
+        const int e = e0g - eT;
+        const float Sx = from_fixed(w[0], e - eR), Sy = from_fixed(w[1], e - eR);
+        const float Sxx = from_fixed(w[2], e - 2 * eR), Sxy = from_fixed(w[3], e - 2 * eR), Syy = from_fixed(w[4], e - 2 * eR);
+        const float S0 = from_fixed(w[5], e);
+        float out[GSR_G2D_STRIDE];
+        out[0] = 2.f * r.qa * Sx + r.qb * Sy;
+        out[1] = 2.f * r.qc * Sy + r.qb * Sx;
+        out[2] = -0.5f * Sxx; out[3] = -Sxy; out[4] = -0.5f * Syy;
+        out[5] = r.opac != 0.f ? S0 / r.opac : 0.f;
+        out[6] = from_fixed(w[6], e); out[7] = from_fixed(w[7], e); out[8] = from_fixed(w[8], e); out[9] = from_fixed(w[9], e);
+        out[10] = out[11] = 0.f;
+        if (poisoned) {
+#pragma unroll
+            for (int q = 0; q < 10; ++q) out[q] = __uint_as_float(0x7fc00000u);
+        }
+        const size_t view = i / (size_t)N;
+        float4* o4 = reinterpret_cast<float4*>(g2d + i * GSR_G2D_STRIDE);
+        o4[0] = make_float4(out[0], out[1], out[2], out[3]); o4[1] = make_float4(out[4], out[5], out[6], out[7]); o4[2] = make_float4(out[8], out[9], 0.f, 0.f);
+        live[view * GSR_LIVE_BYTES(N) + (i - view * (size_t)N)] = (uint8_t)1;
+    }
 }
 
 __global__ void __launch_bounds__(256, 4)   // <= 128 VGPRs: four workgroups per CU (LDS: 34 KiB + 5 KiB table at 64-entry segments)
@@ -1619,6 +1710,28 @@ gsr_render_bwd_q2(GSR_BWD_PARAMS) {
                 for (int q = 0; q < 10; ++q) out[q] = __uint_as_float(0x7fc00000u);
             }
         }
+    }
+    if (det64) {                                          // (uniform) GSR_VIEW_DETERMINISTIC: integer atomics on per-Gaussian scales, see above
+        if (threadIdx.x < len && any) {
+            const unsigned long long* a = acc64 + threadIdx.x * GSR_Q2_ROW;
+            float gxr = keep_a.x, gyr = keep_a.y;
+            if (threadIdx.x >= GSR_RB) { const SplatRec* __restrict__ g = recs + gid; gxr = g->x; gyr = g->y; }
+            const uint4 tail = reinterpret_cast<const uint4*>(recs + gid)[3];       // id | rectx | recty | flags
+            int eT, eRg;
+            det_exponents(gxr, gyr, tail.y, tail.z, eT, eRg);
+            const int e = det_e0(det_gmax, __uint_as_float((uint32_t)plan_total[1])) - eT;
+            const int eR = row_radius_exp(gxr, gyr, tcx, tcy);
+            unsigned long long* dst = det64 + ((size_t)view * vs.N + gid) * GSR_Q2_ROW;
+            // the workgroup's sums as floats (its own scale), then on the Gaussian's scale: a deterministic function of this workgroup's inputs
+            atomicAdd(dst + 0, to_fixed(from_fixed(a[0], e0 - eR), e - eRg));
+            atomicAdd(dst + 1, to_fixed(from_fixed(a[1], e0 - eR), e - eRg));
+            atomicAdd(dst + 2, to_fixed(from_fixed(a[2], e0 - 2 * eR), e - 2 * eRg));
+            atomicAdd(dst + 3, to_fixed(from_fixed(a[3], e0 - 2 * eR), e - 2 * eRg));
+            atomicAdd(dst + 4, to_fixed(from_fixed(a[4], e0 - 2 * eR), e - 2 * eRg));
+#pragma unroll
+            for (int q = 5; q < GSR_Q2_ROW; ++q) atomicAdd(dst + q, to_fixed(from_fixed(a[q], e0), e) + ((poisoned && q == 5) ? 1ull : 0ull));
+        }
+        return;
     }
     // pass 2 is over (barrier above): its buffer takes the converted rows [len][12] and the Gaussian indices [len] -- a region of
     // its own, so no barrier between reading the table and writing them

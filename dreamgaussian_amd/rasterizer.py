@@ -43,6 +43,9 @@ _last_pending = None       # (GsrStats, dict) of an asynchronous forward whose c
 # shape (GSR_VIEW_ASYNC_STATS, include/gsr.h): the ~25 us of host wait per forward overlap with the caller's Python. The price is the
 # failure mode written down there (an overflow of the speculative capacity leaves NaN images and raises at the thread's NEXT forward).
 _async_forward = False
+# OPT-IN: bit-reproducible gradients (GSR_VIEW_DETERMINISTIC: the compositing backward sums in 64-bit fixed point instead of with
+# float atomics; SURVEY 5's "deterministic-mode flag")
+_deterministic = False
 # The backward normally hands the forward's GsrStats back to gsr_backward (no host round trip). Setting this
 # to False exercises the ABI's other documented mode (fwd_stats == NULL: the library reads the counters back
 # from the device, blocking) -- used by tests/test_parity_gpu.py.
@@ -53,6 +56,13 @@ def set_async_forward(on: bool) -> bool:
     """Opt into (or out of) the forward that does not wait for its instance counters (GSR_VIEW_ASYNC_STATS); returns the old setting."""
     global _async_forward
     old, _async_forward = _async_forward, bool(on)
+    return old
+
+
+def set_deterministic(on: bool) -> bool:
+    """Opt into (or out of) the bit-reproducible backward (GSR_VIEW_DETERMINISTIC, include/gsr.h); returns the old setting."""
+    global _deterministic
+    old, _deterministic = _deterministic, bool(on)
     return old
 
 
@@ -96,7 +106,8 @@ def _on_device(dev):
 
 def _view_struct(rs: GaussianRasterizationSettings, device, raw: bool = False, no_backward: bool = False):
     keep = []
-    flags = (_lib.GSR_VIEW_NO_BACKWARD if no_backward else 0) | (_lib.GSR_VIEW_ASYNC_STATS if _async_forward else 0)
+    flags = ((_lib.GSR_VIEW_NO_BACKWARD if no_backward else 0) | (_lib.GSR_VIEW_ASYNC_STATS if _async_forward else 0)
+             | (_lib.GSR_VIEW_DETERMINISTIC if _deterministic else 0))
     for x, tbit in ((rs.bg, 0), (rs.viewmatrix, _lib.GSR_VIEW_VIEWMATRIX_T), (rs.projmatrix, _lib.GSR_VIEW_PROJMATRIX_T), (rs.campos, 0)):
         ok = type(x) is torch.Tensor and x.dtype is torch.float32 and x.device == device
         if ok and x.is_contiguous():

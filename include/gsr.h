@@ -85,6 +85,10 @@ typedef struct GsrView {
 #define GSR_VIEW_NO_BACKWARD 4   /* no gsr_backward will follow this forward (inference): the backward's accumulators are neither allocated nor
                                   * cleared and the serial-walk forward keeps neither checkpoints nor quad masks (118 MB of stores and 0.4 GB of
                                   * scratch at 1M Gaussians / 800^2). GsrStats.bwd_prepared = -1; gsr_backward on such a state returns -1 */
+#define GSR_VIEW_DETERMINISTIC 16 /* gsr_backward only (ABI 6): the compositing backward adds its per-Gaussian sums in 64-bit FIXED POINT (integer atomics: the
+                                  * order of the additions no longer matters) instead of with float atomics -- gradients bit-identical from run to run, at
+                                  * the price of two small extra kernels, N x 80 bytes of `tmp` scratch and integer instead of float atomics. Same values
+                                  * as the default up to fp32 rounding of the sums (tests/test_parity_gpu.py::test_deterministic_backward_*) */
 #define GSR_VIEW_ASYNC_STATS 8   /* OPT-IN (ABI 6): a gsr_forward that could size its list scratch from earlier calls of the same shape returns as soon as
                                   * its kernels are enqueued -- the host does not wait for the instance counters (no synchronisation in
                                   * the steady state). GsrStats then comes back with pending != 0, bin_capacity / seg_shift / bwd_prepared final (all

@@ -245,6 +245,37 @@ def test_full_size_properties(gpu, N, deg, size):
         assert g0[k].abs().max() == 0, k
 
 
+@pytest.mark.parametrize("case", [("trained", 6000, 2, 200, 136), ("blob", 40_000, 3, 320, 320), ("trained", 1500, 0, 96, 96)], ids=["trained", "blob_sh3", "small"])
+def test_deterministic_backward_is_bit_reproducible(gpu, case):
+    """GSR_VIEW_DETERMINISTIC (`set_deterministic`, SURVEY 5's deterministic-mode flag): the compositing backward adds its per-Gaussian
+    sums as 64-bit fixed-point integers instead of with float atomics. Three backward passes give bit-identical gradients -- the
+    default mode's differ in their last bits (checked: otherwise this test would prove nothing) -- and the values are the default
+    mode's up to fp32 rounding of the sums, and the oracle's within the suite's tolerance."""
+    kind, N, deg, W, H = case
+    sc = O.make_scene(N, deg, 0, kind)
+    S = O.make_settings(O.orbit_pose(-10.0, 30.0, 2.0), W, H, sh_degree=deg)
+    w = weights_for(H, W)
+    _, g_def, _ = run_hip(sc, S, gpu, w)
+    old = D.set_deterministic(True)
+    try:
+        runs = [run_hip(sc, S, gpu, w)[1] for _ in range(3)]
+        _, g_alpha_only, _ = run_hip(sc, S, gpu, [0 * w[0], 0 * w[1], w[2]])
+        _, g_alpha_only2, _ = run_hip(sc, S, gpu, [0 * w[0], 0 * w[1], w[2]])
+    finally:
+        D.set_deterministic(old)
+    for k in runs[0]:
+        assert torch.equal(runs[0][k], runs[1][k]) and torch.equal(runs[0][k], runs[2][k]), k
+        assert torch.equal(g_alpha_only[k], g_alpha_only2[k]), k
+        scale = g_def[k].abs().max().item() + 1e-30
+        assert (runs[0][k] - g_def[k]).abs().max().item() <= 2e-5 * scale + 1e-9, (k, (runs[0][k] - g_def[k]).abs().max().item(), scale)
+    oo, og, aux = run_oracle(sc, S, w, torch.float64)
+    assert_grads_close(runs[0], og, aux, floors=grad_floors(sc, og), og32=util.og32_if_near_opaque(sc, S, w))
+    if N >= 6000:        # the default mode on the same inputs is NOT bit-reproducible (float atomics): some attribute differs between two runs
+        _, g_def2, _ = run_hip(sc, S, gpu, w)
+        _, g_def3, _ = run_hip(sc, S, gpu, w)
+        assert any(not torch.equal(g_def[k], g_def2[k]) or not torch.equal(g_def[k], g_def3[k]) for k in g_def)
+
+
 def test_full_size_subsample_against_oracle(gpu):
     """configs[1] geometry (800x800, SH3) on a 20k subsample so that the oracle finishes in
     seconds: exercises the full-resolution tile grid (2500 tiles)."""
