@@ -183,7 +183,7 @@ struct GeomLayout {
 };
 // B views of the same size share one scratch block: per-view arrays are [B][N] / [B][nTiles], the lists of all
 // B * nTiles tiles live in ONE array (BinLayout) addressed through tile_off.
-GeomLayout geom_layout(int N, int H, int W, int B = 1) {
+GeomLayout geom_layout(int N, int H, int W, int B = 1, bool with_acc = true /* false: a forward no backward follows (GSR_VIEW_NO_BACKWARD) */) {
     GeomLayout L;
     const int gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE;
     L.nTiles = gx * gy;
@@ -205,13 +205,15 @@ GeomLayout geom_layout(int N, int H, int W, int B = 1) {
     L.level_off = o; o += align_up((GSR_NLEV + 1) * 4);
     L.sat = o; o += align_up(BT * 4 * 8);                         // hint word per (tile, wave) of the segment forward
     L.plan_off = o; o += align_up(BT * 4);
-    // where each of K1's workgroups starts inside every tile's list ([view][workgroup][tile] u32, written by K1's histogram flush,
-    // read by the scatter) -- only with the tile counters in LDS: larger tile grids use global cursors and never touch it
-    L.wg_base = o; o += L.nTiles <= hist_lds_max_tiles() ? align_up((size_t)B * (size_t)k1_grid_for(N) * (size_t)L.nTiles * 4) : 0;
-    // LAST: the backward's screen-space gradient accumulators [B][N][12] f32 and, right behind them, the [B][N] byte flags "this Gaussian
+    // the backward's screen-space gradient accumulators [B][N][12] f32 and, right behind them, the [B][N] byte flags "this Gaussian
     // received a gradient": cleared by the FORWARD (forward_impl) so that the backward starts on its first kernel. A forward that
-    // no backward can follow (GSR_VIEW_NO_BACKWARD) allocates the block up to here only (`L.g2d` bytes).
-    L.g2d = o; o += align_up(BN * GSR_G2D_STRIDE * 4 + (size_t)B * GSR_LIVE_BYTES(N));
+    // no backward can follow (GSR_VIEW_NO_BACKWARD) leaves them out (with_acc = false).
+    L.g2d = o; o += with_acc ? align_up(BN * GSR_G2D_STRIDE * 4 + (size_t)B * GSR_LIVE_BYTES(N)) : 0;
+    // LAST (round-5 advisor: its size follows K1's grid and the LDS-histogram limit, both of which a test hook can change between a
+    // forward and its backward -- nothing the backward reads may sit behind it): where each of K1's workgroups starts inside every
+    // tile's list ([view][workgroup][tile] u32, written by K1's histogram flush, read by the scatter) -- only with the tile counters
+    // in LDS: larger tile grids use global cursors and never touch it
+    L.wg_base = o; o += L.nTiles <= hist_lds_max_tiles() ? align_up((size_t)B * (size_t)k1_grid_for(N) * (size_t)L.nTiles * 4) : 0;
     L.total = o;
     return L;
 }
@@ -402,7 +404,7 @@ int begin_impl(const GsrView* views, int B, int32_t N, int32_t K,
                const float* means3D, const float* shs, const float* colors_precomp,
                const float* opacities, const float* scales, const float* rotations,
                const float* cov3D_precomp, int32_t* radii, char* gbuf, int shift,
-               unsigned long long* host_counters, int counter_words, bool scan_in_scatter, hipStream_t stream) {
+               unsigned long long* host_counters, int counter_words, bool scan_in_scatter, bool with_acc /* geom_layout */, hipStream_t stream) {
     const GsrView* view = views;
     unsigned long long* host_counters_dev = nullptr;       // the pinned block as the device addresses it
     HIP_TRY(hipHostGetDevicePointer((void**)&host_counters_dev, host_counters, 0));
@@ -413,7 +415,7 @@ int begin_impl(const GsrView* views, int B, int32_t N, int32_t K,
     for (int v = 0; v < B; ++v) tab.v[v] = make_view(views + v);
     const ViewConst& vc = tab.v[0];
     const int H = vc.H, W = vc.W;
-    const GeomLayout GL = geom_layout(N, H, W, B);
+    const GeomLayout GL = geom_layout(N, H, W, B, with_acc);
     const int T = GL.nTiles;
 
     SplatRec* recs = (SplatRec*)(gbuf + GL.recs);
@@ -485,7 +487,7 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
     const GsrView* view = views;
     const ViewConst vc = make_view(view);
     const int H = vc.H, W = vc.W;
-    const GeomLayout GL = geom_layout(N, H, W, B);
+    const GeomLayout GL = geom_layout(N, H, W, B, prepare_bwd);
     const int T = GL.nTiles, TA = GL.allTiles;
     ViewSplit vs = make_split(views, B, N, T, H, W);
 
@@ -545,7 +547,8 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
                 if (lds_sc > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)gsr_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc));
             }
             hipLaunchKernelGGL(gsr_scatter, dim3(k1_grid_for(N) + (scan_in_scatter ? 1 : 0), B), dim3(256), lds_sc, stream, N, emit, tile_off, (const uint32_t*)(gbuf + GL.wg_base), entries,
-                               vc.gx, T, (uint32_t)M, counters, level_off, order, tile_seg, shift, items, items_cap, k1_grid_for(N), fold);
+                               vc.gx, T, (uint32_t)M, counters, level_off, order, tile_seg, shift, items, items_cap, k1_grid_for(N), fold,
+                               (const unsigned long long*)(gbuf + GL.block_stats));
         } else {
             const int grid_sc = (int)fmin((double)((N + 255) / 256), 512.0);
             hipLaunchKernelGGL(gsr_scatter_global, dim3(grid_sc, B), dim3(256), 0, stream, N, emit, tile_off, cursor, entries,
@@ -745,14 +748,15 @@ int forward_impl(const GsrView* views, int B, int32_t N, int32_t K,
     // has long passed that point: this is the check, not a wait) -- and ITS failure is reported here, before anything new is enqueued
     if (g_pending.on) { if (int rcp = complete_pending()) return rcp; }
     const ViewConst vcs = make_view(view);
-    const GeomLayout GLs = geom_layout(N, vcs.H, vcs.W, B);
+    const bool with_acc = N > 0 && !(view->flags & GSR_VIEW_NO_BACKWARD);
+    const GeomLayout GLs = geom_layout(N, vcs.H, vcs.W, B, with_acc);
     const int shift = seg_shift_for(N, GLs.nTiles);
     // The backward accumulates its screen-space gradients with atomics into [B][N][12] floats that must start from zero -- 48 MB at
     // 1M Gaussians, a 10 us fill in front of gsr_render_bwd_q2 in round 3. The forward's compositing leaves HBM idle: every workgroup
     // of its per-tile kernel (gsr_render_fwd_serial / gsr_render_fwd_combine) clears a slice of them behind its own work. (A fill on
     // a second stream was measured first: the two cross-stream waits cost 15 us of bubbles, more than the fill.)
     const bool prepare = N > 0 && !(view->flags & GSR_VIEW_NO_BACKWARD);
-    char* gbuf = (char*)geom.resize(geom.ctx, prepare ? GLs.total : GLs.g2d);      // (no backward: no accumulators at the end of the block)
+    char* gbuf = (char*)geom.resize(geom.ctx, GLs.total);                          // (no backward: the layout holds no accumulators)
     char* ibuf = (char*)img.resize(img.ctx, gsr_img_bytes(vcs.H, vcs.W) * (size_t)B);
     if (!gbuf || !ibuf) return fail(-4, "scratch allocation failed%s", "");
     // GsrView.grad_clear: the array the backward's outputs will be carved from, cleared under the serial walk when the backward would
@@ -783,7 +787,7 @@ int forward_impl(const GsrView* views, int B, int32_t N, int32_t K,
     const bool fold = spec && GLs.nTiles <= hist_lds_max_tiles() && GLs.allTiles <= 4096 && fwd_sequential_for(N, GLs.nTiles) &&
                       (ov(OV_SCAN_FOLD) == 1 || (ov(OV_SCAN_FOLD) < 0 && g_hint.M >= 2000000ull));
     if (int rc = begin_impl(views, B, N, K, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                            radii, gbuf, shift, g_pinned, 8 + 2 * B, fold, stream)) {
+                            radii, gbuf, shift, g_pinned, 8 + 2 * B, fold, with_acc, stream)) {
         (void)hipStreamSynchronize(stream);               // nothing may still write the pinned block when the next call re-arms it
         return rc;
     }

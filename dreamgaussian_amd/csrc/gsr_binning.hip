@@ -277,7 +277,8 @@ gsr_scatter(int N, const EmitRec* __restrict__ emit, const uint32_t* __restrict_
             const uint32_t* __restrict__ wg_base, unsigned long long* __restrict__ entries,
             int gx, int nTiles, uint32_t capacity, unsigned long long* __restrict__ counters,
             const uint32_t* __restrict__ level_off, const uint32_t* __restrict__ order, const uint32_t* __restrict__ tile_seg,
-            int seg_shift, uint4* __restrict__ items, uint32_t items_cap, int k1_grid, ScanFold fold) {
+            int seg_shift, uint4* __restrict__ items, uint32_t items_cap, int k1_grid, ScanFold fold,
+            const unsigned long long* __restrict__ k1_stats /* K1's block_stats [views][k1_grid][3] */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint32_t* next = reinterpret_cast<uint32_t*>(smem_raw);      // [nTiles]: the next free position of this workgroup's range in the tile's list
     __shared__ uint32_t lev[GSR_NLEV + 1];
@@ -296,6 +297,9 @@ gsr_scatter(int N, const EmitRec* __restrict__ emit, const uint32_t* __restrict_
     } else if (counters[2] > (unsigned long long)capacity) return;
     // (the scratch may have been sized BEFORE the host knew M -- gsr_forward: previous call + 25 %. M is on the device: every consumer
     // of the lists leaves at once when they do not fit, and the host repeats the tail)
+    // This workgroup's K1 twin gave up waiting for the cleared tile counters (gsr_preprocess_fwd: it reports M_ref >= 2^62 and the host
+    // returns an error): it reserved nothing, its row of wg_base is whatever the scratch held -- nothing may be written from it.
+    if (k1_stats[3 * ((size_t)blockIdx.y * k1_grid + bx)] >= (1ull << 62)) return;
     // blockIdx.y = view: its records and its tiles (tile_off holds positions in the one list array of all views)
     emit += (size_t)blockIdx.y * (size_t)N;
     const uint32_t* __restrict__ base_row = wg_base + ((size_t)blockIdx.y * k1_grid + bx) * nTiles;

@@ -601,7 +601,8 @@ template __global__ void gsr_render_fwd_serial<true>(const uint32_t*, const Spla
 //                      list then holds entries for pixels that have stopped since -- blended with done = true, i.e. not at all)
 // Same arithmetic, same macros as gsr_render_fwd_serial<true>: images, checkpoints and work list are bit-identical to its output;
 // the quad masks left for the backward may carry the stale-gate entries above (its own per-pixel tests drop them).
-// Spins are bounded: a lost hand-shake ends the walk early (wrong pixels, caught by the tests) instead of hanging the GPU.
+// Spins are bounded: a lost hand-shake (2^20 polls of a flag the partner never sets) ends the walk instead of hanging the GPU, and the
+// block's pixels are written as NaN -- visible in the image and in every loss, not a silently shorter walk.
 // =========================================================================================
 // Wave priorities inside the pair kernel (s_setprio, 0..3). The BLENDER of a block is the chain the kernel's length is made of; its
 // tester has slack (it is at most a round ahead and waits for a free buffer). Round 6, same box, 1M Gaussians / 800^2: blender 3 /
@@ -701,6 +702,7 @@ gsr_render_fwd_pair(const uint32_t* __restrict__ tile_off, const SplatRec* __res
     bool done = !inside;
     float* const sinkf = rec_base + (size_t)sink_rec * GSR_CKPT_FLOATS + (blk * 64 + lane);
     unsigned long long* const sink64 = reinterpret_cast<unsigned long long*>(rec_base + (size_t)sink_rec * GSR_CKPT_FLOATS + GSR_REC_HINT) + lane;
+    bool lost = false;                                    // (blender) the hand-shake broke: the block comes out as NaN, not as a silently shorter walk
     if (n > 0u && tester) {
         if (GSR_PAIR_PRIO_T) __builtin_amdgcn_s_setprio(GSR_PAIR_PRIO_T);
         // ---- the tester: two register sets take turns (round r tests set r & 1, requested a round ago, and requests round r + 1's
@@ -798,7 +800,8 @@ gsr_render_fwd_pair(const uint32_t* __restrict__ tile_off, const SplatRec* __res
 #pragma unroll 1
             for (int spin = 0; (code >> 8) != r + 1u && spin < GSR_PAIR_SPINS; ++spin) { __builtin_amdgcn_s_sleep(1); code = lds_flag_load(&ready[blk][buf]); }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-            if ((code >> 8) != r + 1u || (code & 0xffu) == GSR_PAIR_END) break;
+            if ((code >> 8) != r + 1u) { lost = true; break; }      // the tester never delivered this round (2^20 polls): see below
+            if ((code & 0xffu) == GSR_PAIR_END) break;
             const unsigned long long alive = __ballot(!done);
             if (alive == 0ull) {                            // every pixel has stopped: release the tester, leave
                 lds_flag_store(&freed[blk][0], GSR_PAIR_STOP, lane);
@@ -843,6 +846,7 @@ gsr_render_fwd_pair(const uint32_t* __restrict__ tile_off, const SplatRec* __res
         }
     }
     __builtin_amdgcn_s_setprio(GSR_PAIR_PRIO_TAIL);
+    if (lost) { T = C0 = C1 = C2 = D = A = __uint_as_float(0x7fc00000u); }     // (round-5 advisor: a lost hand-shake must not pass for a result)
     if (inside && !tester) {
         const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
         final_T[pix] = T;

@@ -204,8 +204,11 @@ class _RasterizeGaussians(torch.autograd.Function):
             # clear it on the side where the backward would otherwise have to (GsrView.grad_clear: large scenes, whose per-Gaussian
             # backward then writes the rows of the live Gaussians only). stats.bwd_prepared == 2 says it did; the block is handed to
             # the first backward either way (cleared or not: the streaming per-Gaussian backward writes every element)
+            # ... only where the library would use it (its rule, gsr_api.hip k6_compact_for: one view, concatenated SH layout, >= 64 MB
+            # of gradients): otherwise the block is allocated by the backward, as before round 5 -- a render whose backward never runs
+            # does not pay for it, and the loss computation does not hold it (round-5 advisor)
             grad_flat = None
-            if want_bwd and N > 0:
+            if want_bwd and N > 0 and rest is None and N * (3 * (K if shc is not None else 1) + 14) * 4 >= (64 << 20):
                 widths = _gradient_widths(K, 0 if rest is None else int(rest.shape[1]), shc is not None, col is not None,
                                           sc is not None, cov is not None)
                 grad_flat = carve_gradients(N, widths, dev)

@@ -60,7 +60,9 @@ GRAD_RTOL = 1e-4         # per attribute, relative to that attribute's max |grad
 ROW_REL_FLOOR = 1e-3
 ROW_REL_P999 = 5e-3         # small scenes (a few thousand rows: the 99.9th percentile is the second-worst row); fp32-vs-fp64 of the
                             # ORACLE ITSELF reaches 1.2e-3 there (tests/test_oracle.py): fp32 rounding, not a kernel property
-ROW_REL_P999_FULL = 1e-3    # BASELINE configs[1]-[3] at full size (>= 20k rows): observed on the MI355X <= 5.2e-4
+ROW_REL_P999_FULL = 7e-4    # BASELINE configs[1]-[3] at full size (>= 20k rows): observed on the MI355X <= 5.2e-4 (round 6: the bound follows what is
+                            # observed -- it was 1e-3; north_star's literal "1e-4 rel" holds for the MEDIAN row 5x over and for ~97-99 % of the rows, not
+                            # for the last few in a thousand: the histogram below is printed with every full-size comparison)
 ROW_REL_MEDIAN = 5e-5       # observed on the MI355X: <= 1.8e-5 (BASELINE configs[3], means2D)
 REPORT = {}              # what the last assert_* calls observed (printed by the full-size tests)
 
@@ -233,7 +235,9 @@ def assert_grads_close(hg, og, aux=None, rtol=GRAD_RTOL, floors=None, row_rel_p9
                 rel = (err[sel] / rn[sel]).sort().values
                 p999 = rel[min(rel.numel() - 1, int(0.999 * rel.numel()))].item()
                 med = rel[rel.numel() // 2].item()
-                REPORT[f"rowrel_{k}"] = dict(rows=int(sel.sum()), median=med, p999=p999, max=rel[-1].item())
+                # how the rows above the floor are distributed against north_star's literal 1e-4 (fractions of rows at or below each bound)
+                hist = {f"le_{b:g}": round(float((rel <= b).double().mean()), 5) for b in (1e-5, 3e-5, 1e-4, 3e-4, 1e-3)}
+                REPORT[f"rowrel_{k}"] = dict(rows=int(sel.sum()), median=med, p999=p999, max=rel[-1].item(), **hist)
                 assert p999 <= row_rel_p999 and med <= ROW_REL_MEDIAN, \
                     f"d{k}: row-relative error median {med:.2e} / p99.9 {p999:.2e} over {int(sel.sum())} rows"
 

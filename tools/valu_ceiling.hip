@@ -64,14 +64,24 @@ __device__ __forceinline__ void fill_stage(float4* sa, float4* sb, float4* sc, i
 // ---------------------------------------------------------------------------------------------------------------
 // backward: pass 1 + pass 2 of gsr_render_bwd_q2 for `rounds` rounds of `nq` entries per quad list (nq a multiple of 8)
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256, 4)
-bwd_mix(float* __restrict__ out, int rounds, int nq) {
-    __shared__ float4 stage[4][3][GSR_RB];
+// OCC = waves per SIMD the kernel is compiled for. OCC > 4 (round 6, the review's experiment (a): what would >= 5 waves per SIMD buy?):
+// the per-pixel gradients of pass 2 (`g2`, 32 registers) are read from LDS at their uses instead of held, and -- because the real
+// kernel's LDS (9.6 KiB per wave: staged records, quad lists, the (m, w) exchange, the table) caps a CU at 16 waves whatever the
+// registers allow -- the staging and exchange buffers are SHARED by wave pairs here: the results are wrong by construction, the
+// instruction stream and the LDS traffic are the kernel's. Only the timing is used.
+template <int OCC>
+__global__ void __launch_bounds__(256, OCC)
+bwd_mix_t(float* __restrict__ out, int rounds, int nq) {
+    constexpr int NB = OCC > 4 ? 2 : 4;                   // buffer sets per workgroup
+    constexpr bool G2_LDS = OCC > 4;
+    __shared__ float4 stage[NB][3][GSR_RB];
     __shared__ __attribute__((aligned(8))) uint8_t qlist[4][4][GSR_QL_PITCH];
-    __shared__ __attribute__((aligned(16))) float mw[4][4][GSR_Q2_BATCH * GSR_Q2_KSTRIDE];
+    __shared__ __attribute__((aligned(16))) float mw[NB][4][GSR_Q2_BATCH * GSR_Q2_KSTRIDE];
     __shared__ __attribute__((aligned(16))) unsigned long long acc64[GSR_Q2_ROW * 64];
+    __shared__ float4 gtab[G2_LDS ? 64 : 1];           // (one wave's worth, shared: timing only)
     extern __shared__ __attribute__((aligned(16))) unsigned char pad_[];      // occupancy control only
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave_true = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = wave_true % NB;
     const int lane = threadIdx.x & 63;
     const int row = lane >> 4, l15 = lane & 15;
     const int bx = (wave & 1) * 8, by = (wave >> 1) * 8;
@@ -83,9 +93,10 @@ bwd_mix(float* __restrict__ out, int rounds, int nq) {
     float4* __restrict__ sc = stage[wave][2];
     fill_stage(sa, sb, sc, lane, (float)bx, (float)by);
     for (int q = threadIdx.x; q < GSR_Q2_ROW * 64; q += 256) acc64[q] = 0ull;
-    for (int q = lane; q < 4 * GSR_QL_PITCH; q += 64) qlist[wave][q / GSR_QL_PITCH][q % GSR_QL_PITCH] = (uint8_t)((q * 7 + 3 * (q / GSR_QL_PITCH)) & 63);
+    for (int q = lane; q < 4 * GSR_QL_PITCH; q += 64) qlist[wave_true][q / GSR_QL_PITCH][q % GSR_QL_PITCH] = (uint8_t)((q * 7 + 3 * (q / GSR_QL_PITCH)) & 63);
+    if (G2_LDS && threadIdx.x < 64) gtab[threadIdx.x] = make_float4(out[256 + (threadIdx.x & 31)] + 0.3f, out[257] + 0.5f, out[258] + 0.7f, out[259] + 0.2f + 0.001f * lane);
     __syncthreads();
-    const uint8_t* __restrict__ ql = qlist[wave][row];
+    const uint8_t* __restrict__ ql = qlist[wave_true][row];
     // per-pixel values the real kernel loads: kept opaque to the compiler (the host zeroes `out`; + constants)
     const float z = out[threadIdx.x];
     const float gC0 = z + 0.3f + 0.001f * lane, gC1 = z + 0.5f, gC2 = z + 0.7f - 0.001f * lane, gD = z + 0.2f, gA = z + 0.1f;
@@ -97,9 +108,12 @@ bwd_mix(float* __restrict__ out, int rounds, int nq) {
     const int k2 = l15 & 7, h2 = l15 >> 3;
     const float* __restrict__ mw2 = &mw[wave][row][k2 * GSR_Q2_KSTRIDE + h2 * GSR_Q2_HSTRIDE];
     const float qxf = (float)qx, qyf = (float)(qy + 2 * h2);
-    float4 g2[8];
+    float4 g2[G2_LDS ? 1 : 8];
+    if (!G2_LDS) {
 #pragma unroll
-    for (int i2 = 0; i2 < 8; ++i2) g2[i2] = make_float4(out[256 + 4 * i2] + 0.3f + 0.01f * i2, out[257 + 4 * i2] + 0.5f, out[258 + 4 * i2] + 0.7f, out[259 + 4 * i2] + 0.2f + 0.001f * lane);
+        for (int i2 = 0; i2 < (G2_LDS ? 1 : 8); ++i2) g2[i2] = make_float4(out[256 + 4 * i2] + 0.3f + 0.01f * i2, out[257 + 4 * i2] + 0.5f, out[258 + 4 * i2] + 0.7f, out[259 + 4 * i2] + 0.2f + 0.001f * lane);
+    }
+    const float4* __restrict__ g2l = gtab + (G2_LDS ? row * 16 + h2 * 8 : 0);
     float T = 1.f, Cgf = 0.f;
 
 #define GSR_Q2_ENTRY(ea, eb, ec, kpos, valid, kslot)                                             \
@@ -157,7 +171,7 @@ bwd_mix(float* __restrict__ out, int rounds, int nq) {
 #pragma unroll
                     for (int c2 = 0; c2 < 4; c2 += 2) {
                         const float4 v = *reinterpret_cast<const float4*>(mw2 + (r2 * 4 + c2) * 2);
-                        const float4 g0 = g2[r2 * 4 + c2], g1 = g2[r2 * 4 + c2 + 1];
+                        const float4 g0 = G2_LDS ? g2l[r2 * 4 + c2] : g2[G2_LDS ? 0 : r2 * 4 + c2], g1 = G2_LDS ? g2l[r2 * 4 + c2 + 1] : g2[G2_LDS ? 0 : r2 * 4 + c2 + 1];
                         const float dx0 = dxb - (float)c2, dx1 = dxb - (float)(c2 + 1);
                         const float t0 = v.x * dx0, t1 = v.z * dx1;
                         R0 += v.x; R0 += v.z;
@@ -307,7 +321,11 @@ int main(int argc, char** argv) {
     float* out; CHECK(hipMalloc(&out, 256 * 8 * 256 * 4));
     const size_t lds_bwd = 4 * 3 * 64 * 16 + 4 * 4 * 80 + 4 * 4 * 8 * 40 * 4 + 10 * 64 * 8;
     const size_t lds_fwd = 4 * 3 * 66 * 16 + 4 * 4 * 80;
-    for (int occ = 1; occ <= 4; ++occ) if (run("bwd_mix", bwd_mix, lds_bwd, occ, rounds, nq, out)) return 1;
+    for (int occ = 1; occ <= 4; ++occ) if (run("bwd_mix", bwd_mix_t<4>, lds_bwd, occ, rounds, nq, out)) return 1;
+    // experiment (a): the same loops compiled for 5 / 6 waves per SIMD (<= 102 / <= 84 VGPRs, g2 from LDS, shared buffers: timing only)
+    const size_t lds_bwd2 = 2 * 3 * 64 * 16 + 4 * 4 * 80 + 2 * 4 * 8 * 40 * 4 + 10 * 64 * 8 + 64 * 16;
+    for (int occ = 4; occ <= 5; ++occ) if (run("bwd_mix_occ5", bwd_mix_t<5>, lds_bwd2, occ, rounds, nq, out)) return 1;
+    for (int occ = 4; occ <= 6; ++occ) if (run("bwd_mix_occ6", bwd_mix_t<6>, lds_bwd2, occ, rounds, nq, out)) return 1;
     for (int occ = 1; occ <= 4; ++occ) if (run("fwd_mix", fwd_mix, lds_fwd, occ, rounds, nq, out)) return 1;
     for (int occ = 1; occ <= 4; ++occ) if (run("fma_ref", fma_ref, 0, occ, rounds * 8, nq, out)) return 1;
     // the forward has 128 VGPRs at most too, but LDS would let 8 workgroups share a CU: the mix at 8 waves per SIMD if registers allowed
