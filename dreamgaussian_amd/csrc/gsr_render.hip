@@ -619,6 +619,9 @@ template __global__ void gsr_render_fwd_serial<true>(const uint32_t*, const Spla
 #ifndef GSR_PAIR_PRIO_ADAPT
 #define GSR_PAIR_PRIO_ADAPT 0     // experiment: a tester that finds its buffer free at once (its blender is waiting for IT) takes the blender's level for the round
 #endif
+#ifndef GSR_PAIR_WAIT_LOW
+#define GSR_PAIR_WAIT_LOW 0       // experiment: a blender that has to wait for its tester waits at priority 0
+#endif
 #ifndef GSR_PAIR_PRIO_TAIL
 #define GSR_PAIR_PRIO_TAIL 0      // priority of the blender behind its walk (outputs, work items, the slices of zeros)
 #endif
@@ -797,8 +800,17 @@ gsr_render_fwd_pair(const uint32_t* __restrict__ tile_off, const SplatRec* __res
             const int buf = (int)(r & 1u);
             if (GSR_PAIR_PRIO_DEPTH) { if (r == (uint32_t)GSR_PAIR_PRIO_DEPTH) __builtin_amdgcn_s_setprio(2); if (r == 2u * (uint32_t)GSR_PAIR_PRIO_DEPTH) __builtin_amdgcn_s_setprio(3); }
             uint32_t code = lds_flag_load(&ready[blk][buf]);
+#if GSR_PAIR_WAIT_LOW
+            if ((code >> 8) != r + 1u) {                    // the tester is late: it shares this SIMD -- wait BELOW it, not above
+                __builtin_amdgcn_s_setprio(0);
+#pragma unroll 1
+                for (int spin = 0; (code >> 8) != r + 1u && spin < GSR_PAIR_SPINS; ++spin) { __builtin_amdgcn_s_sleep(1); code = lds_flag_load(&ready[blk][buf]); }
+                __builtin_amdgcn_s_setprio(GSR_PAIR_PRIO_B);
+            }
+#else
 #pragma unroll 1
             for (int spin = 0; (code >> 8) != r + 1u && spin < GSR_PAIR_SPINS; ++spin) { __builtin_amdgcn_s_sleep(1); code = lds_flag_load(&ready[blk][buf]); }
+#endif
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
             if ((code >> 8) != r + 1u) { lost = true; break; }      // the tester never delivered this round (2^20 polls): see below
             if ((code & 0xffu) == GSR_PAIR_END) break;

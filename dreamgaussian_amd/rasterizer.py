@@ -19,7 +19,7 @@ from typing import NamedTuple, Optional
 import torch
 from torch import nn
 
-from . import _lib
+from . import _lib, _testing
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -208,7 +208,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             # of gradients): otherwise the block is allocated by the backward, as before round 5 -- a render whose backward never runs
             # does not pay for it, and the loss computation does not hold it (round-5 advisor)
             grad_flat = None
-            if want_bwd and N > 0 and rest is None and N * (3 * (K if shc is not None else 1) + 14) * 4 >= (64 << 20):
+            if want_bwd and N > 0 and rest is None and (N * (3 * (K if shc is not None else 1) + 14) * 4 >= (64 << 20)
+                                                         or _testing._current.get("k6_compact") == 1):      # (test hook: the small scenes of the suite)
                 widths = _gradient_widths(K, 0 if rest is None else int(rest.shape[1]), shc is not None, col is not None,
                                           sc is not None, cov is not None)
                 grad_flat = carve_gradients(N, widths, dev)

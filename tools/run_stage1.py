@@ -172,8 +172,10 @@ def check_against_oracle(sc, sizes=((256, 0.0, 0.0), (512, -15.0, 130.0)), label
     return rep
 
 
-def run(ref, iters, input_path, profiled, optin=False, keep=None, zorder=False):
+def run(ref, iters, input_path, profiled, optin=False, keep=None, zorder=False, async_forward=False):
     from dreamgaussian_amd import _lib
+    import dreamgaussian_amd as D
+    D.set_async_forward(async_forward)               # GSR_VIEW_ASYNC_STATS: gsr_forward does not wait for its instance counters (opt-in)
     for m in ("main", "gs_renderer", "sh_utils", "cam_utils", "grid_put"):
         sys.modules.pop(m, None)
     import main as ref_main                          # the reference trainer, unmodified
@@ -203,6 +205,8 @@ def run(ref, iters, input_path, profiled, optin=False, keep=None, zorder=False):
     gui.renderer.gaussians.prune(min_opacity=0.01, extent=1, max_screen_size=1)      # main.py:895
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
+    D.last_stats()                                   # (collects a pending asynchronous forward's counts -- and would raise had one overflowed)
+    D.set_async_forward(False)
     kern = {}
     if profiled:
         _lib.profile_enable(False)
@@ -242,6 +246,8 @@ def main():
                     "(the 512^2 orbit view costs the CPU oracle four times as long: the GPU suite's test uses this)")
     ap.add_argument("--optin", action="store_true", help="one more run with FusedAdam, the fused densification statistics and the "
                                                          "one-gather prune patched onto the reference's GaussianModel")
+    ap.add_argument("--async-forward", action="store_true", help="two more runs (plain and opt-in) with dreamgaussian_amd.set_async_forward(True): "
+                                                                 "gsr_forward returns without waiting for its instance counters (GSR_VIEW_ASYNC_STATS)")
     a = ap.parse_args()
     ref = a.ref or next((d for d in (os.path.join(ROOT, "_ref_stage"), "/root/reference") if os.path.isdir(d)), None)
     if ref is None:
@@ -282,6 +288,12 @@ def main():
         out["optin_zorder_run"]["what"] = ("the opt-in run with prune_points(..., zorder=True): the rows leave every densification interval "
                                            "along a Z-order curve (at ~10k Gaussians the binning kernels are not where the time is: a check "
                                            "that it costs nothing here; where it pays: bench.py --order morton at 250k-1M)")
+    if a.async_forward:
+        out["async_run"] = run(ref, a.iters, input_path, profiled=False, async_forward=True)
+        out["async_run"]["what"] = "the plain run (reference trainer unmodified) with set_async_forward(True): no host wait per forward in the steady state"
+        if a.optin:
+            out["optin_async_run"] = run(ref, a.iters, input_path, profiled=False, optin=True, async_forward=True)
+            out["optin_async_run"]["what"] = "the opt-in run with set_async_forward(True)"
     os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
     json.dump(out, open(a.out, "w"), indent=1)
     print(json.dumps(out, indent=1))
