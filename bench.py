@@ -357,6 +357,9 @@ def main():
                     help="what the timed step does about DreamGaussian's parameter activations (gs_renderer.py:134-142): "
                          "none = the rasterizer alone on activated inputs (the headline metric); torch = sigmoid/exp/normalize "
                          "as torch ops + their autograd, as Renderer.render does; fused = rasterize_gaussians_raw")
+    ap.add_argument("--async-forward", action="store_true",
+                    help="dreamgaussian_amd.set_async_forward(True): gsr_forward returns without waiting for its instance counters (GSR_VIEW_ASYNC_STATS, "
+                         "opt-in; recorded in the line's config -- a line with it is not the headline)")
     ap.add_argument("--hook", action="append", default=[], metavar="NAME=VALUE",
                     help="A/B measurements only: a test hook of the library (dreamgaussian_amd._testing), e.g. fwd_lds_kb=44; "
                          "recorded in the line's config (a line with hooks is not the headline)")
@@ -389,6 +392,8 @@ def main():
 
     import dreamgaussian_amd as D
     from dreamgaussian_amd import _lib, views
+    if a.async_forward:
+        D.set_async_forward(True)
     if a.hook:
         from dreamgaussian_amd import _testing
         for h in a.hook:
@@ -621,7 +626,7 @@ def main():
                        "views_per_step": world * a.views, "order": a.order, "activations": a.activations, "views_mode": ("single" if a.views == 1 else ("serial loop" if a.views_serial else "rasterize_views/chain")), "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU",
                        "N": wl["N"], "K": K, "V": st.get("V"), "M": st.get("M_ref"), "M_emitted": st.get("M"),
                        "max_tile_list": st.get("max_tile"), "seg_shift": st.get("seg_shift"),
-                       **({"hooks": list(a.hook)} if a.hook else {})},
+                       **({"hooks": list(a.hook)} if a.hook else {}), **({"async_forward": True} if a.async_forward else {})},
             "roofline": roof, "path_roofline": path_roof, "cpu_baseline": cpu,
             "kernels_ms_per_step": {k: round(v[0] / a.steps, 4) for k, v in sorted(kern.items())},
             "kernels_ms_per_step_raw": {k: round(v, 4) for k, v in sorted(kern_raw.items())} if kern else {},

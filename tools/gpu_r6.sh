@@ -30,6 +30,16 @@ order)
       echo "== bench $wl --order $o"; timeout 300 python bench.py --workload ${wl%%:*} --kind $kind --order $o --cpu-budget 0 --steps 60 --warmup 10 2>> gpurun_out/bench_order.err | tee -a gpurun_out/bench_order.jsonl | line
     done
   done;;
+floor5k)
+  # 5k / 256^2: ten launches of the bench line, blocking and with the forward that does not wait for its counters; the host phases
+  python tools/host_overhead.py 2>&1 | grep -a "ms/step\|floor" | tee gpurun_out/host_floor_5k.txt
+  for mode in "" "--async-forward"; do
+    echo "== 5k-256-sh0 $mode" | tee -a gpurun_out/host_floor_5k.txt
+    for i in 1 2 3 4 5 6 7 8 9 10; do python bench.py --workload 5k-256-sh0 --cpu-budget 0 --no-roofline --steps 200 --warmup 20 $mode 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('5k-256-sh0 ms_per_step', d['ms_per_step'])"; done | tee -a gpurun_out/host_floor_5k.txt
+  done
+  python tools/host_phases.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/host_phases_5k.txt;;
+place)
+  GSR_LIB=$R/_exp/libgsr_place.so python tools/placement_report.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/placement_1M.txt | head -40;;
 reduce)
   # the gradient exchange of the "local" SDS step through a ONE-rank RCCL group: dense all-reduce / sharded Adam / live rows, at
   # BASELINE configs[3] and at 1M / SH 3 (62 MB of gradients)

@@ -32,6 +32,19 @@ k = k.replace('''    // ---- how deep the backward has to walk this tile's list,
     }
     // ---- how deep the backward has to walk this tile's list, and its (tile, segment) work items''', 1)
 s = s[:a] + k + s[b:]
+# ---- the pair forward (round 6): one row per BLENDER wave (the block's chain), same table
+a = s.index('gsr_render_fwd_pair(const uint32_t* __restrict__ tile_off')
+b = s.index('// The exact walk of list positions [lo, hi) of a tile')
+k = s[a:b]
+k = k.replace('''    const int tg = (int)order[blockIdx.x];                // heaviest tiles first''', '''    const unsigned long long dbg_t0 = wall_clock64();
+    const int tg = (int)order[blockIdx.x];                // heaviest tiles first''', 1)
+assert 'dbg_t0 = wall_clock64' in k
+k = k.replace('''    // ---- how deep the backward has to walk this tile's list, and its (tile, segment) work items''', '''    if (!tester && lane == 0 && blockIdx.x * 4 + blk < GSR_DBG_ROWS) {
+        unsigned long long* d = g_dbg_fwd + (size_t)(blockIdx.x * 4 + blk) * 4;
+        d[0] = dbg_t0; d[1] = wall_clock64(); d[2] = dbg_where(); d[3] = (unsigned long long)n | ((unsigned long long)wave_max_u32(inside ? last : 0u) << 32);
+    }
+    // ---- how deep the backward has to walk this tile's list, and its (tile, segment) work items''', 1)
+s = s[:a] + k + s[b:]
 # ---- backward: one row per workgroup (item)
 s = s.replace('''    clear_rows();                                         // (in front of the set-up loads: 2.5 us better than behind the flush, same box)
     if (blockIdx.x >= nitems) return;''', '''    const unsigned long long dbg_t0 = wall_clock64();
