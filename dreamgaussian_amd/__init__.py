@@ -12,7 +12,7 @@ indexings and `torch.cat`s).
 """
 from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer,
                          rasterize_gaussians, rasterize_gaussians_raw, rasterize_gaussians_split, last_stats,
-                         set_async_forward, set_deterministic)
+                         set_async_forward, set_deterministic, use_cpp_binding, binding_loaded, peek_stats)
 from .knn import distCUDA2
 from .batched import rasterize_views
 from .fields import extract_fields
@@ -21,5 +21,5 @@ from .densify import (add_densification_stats, compact_mask, gather_rows, prune_
 from .optim import FusedAdam
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_gaussians_raw", "rasterize_gaussians_split",
-           "last_stats", "set_async_forward", "set_deterministic", "distCUDA2", "rasterize_views", "extract_fields", "add_densification_stats", "compact_mask", "gather_rows", "prune_points",
+           "last_stats", "peek_stats", "set_async_forward", "set_deterministic", "use_cpp_binding", "binding_loaded", "distCUDA2", "rasterize_views", "extract_fields", "add_densification_stats", "compact_mask", "gather_rows", "prune_points",
            "densification_postfix", "densify_and_clone", "densify_and_split", "morton_order", "reorder_gaussians", "FusedAdam"]

@@ -75,6 +75,49 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+# ---- the torch binding (csrc/gsr_torch.cpp -> _gsr_torch.so): a pybind11 / C++ autograd module compiled by g++ against torch's
+# headers (no device code: it only calls the C ABI). Optional at run time -- rasterizer.py falls back to its ctypes path without it.
+BIND_SRC = os.path.join(CSRC, "gsr_torch.cpp")
+BIND_LIB = os.path.join(HERE, "_gsr_torch.so")
+BIND_STAMP = os.path.join(HERE, ".gsr_torch.stamp")
+
+
+def _bind_cmd():
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
+    inc = ce.include_paths() + [sysconfig.get_paths()["include"], "/opt/rocm/include"]
+    return (["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DTORCH_EXTENSION_NAME=_gsr_torch",
+             "-DTORCH_API_INCLUDE_EXTENSION_H", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-Wno-deprecated-declarations",
+             BIND_SRC, "-o", BIND_LIB] + [f"-I{i}" for i in inc] + [f"-L{p}" for p in ce.library_paths()]
+            + ["-lc10", "-ltorch", "-ltorch_cpu", "-ltorch_python", "-lc10_hip", "-ltorch_hip", "-ldl"])
+
+
+def _bind_digest() -> str:
+    import torch
+    h = hashlib.sha256()
+    h.update(torch.__version__.encode())
+    for f in (BIND_SRC, os.path.join(os.path.dirname(HERE), "include", "gsr.h")):
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def build_binding(force: bool = False, verbose: bool = True) -> str:
+    dig = _bind_digest()
+    if not force and os.path.exists(BIND_LIB) and os.path.exists(BIND_STAMP):
+        with open(BIND_STAMP) as fh:
+            if fh.read().strip() == dig:
+                return BIND_LIB
+    cmd = _bind_cmd()
+    if verbose:
+        print("[dreamgaussian_amd.build]", " ".join(cmd[:14]), "...", flush=True)
+    subprocess.run(cmd, check=True)
+    with open(BIND_STAMP, "w") as fh:
+        fh.write(dig)
+    return BIND_LIB
+
+
 def is_current() -> bool:
     if not (os.path.exists(LIB) and os.path.exists(STAMP)):
         return False
@@ -85,3 +128,5 @@ def is_current() -> bool:
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
     print(LIB)
+    build_binding(force="--force" in sys.argv)
+    print(BIND_LIB)

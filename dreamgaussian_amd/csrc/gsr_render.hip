@@ -607,8 +607,11 @@ template __global__ void gsr_render_fwd_serial<true>(const uint32_t*, const Spla
 // Wave priorities inside the pair kernel (s_setprio, 0..3). The BLENDER of a block is the chain the kernel's length is made of; its
 // tester has slack (it is at most a round ahead and waits for a free buffer). Round 6, same box, 1M Gaussians / 800^2: blender 3 /
 // tester 0 takes the forward compositing from 0.1464 to 0.1310 ms -- the blenders issue whenever they can, the testers of all blocks
-// fill the slots the blenders leave --, tester 1 (above the finished blocks' output / zero stores, which run at 0) to 0.1277; blender 2 = blender 3;
-// keeping 3 through the tail 0.1331; levels that rise with the depth walked 0.134-0.138; four workgroups per CU (<= 64 VGPRs) 0.155. (Priorities among the waves of the SERIAL walk, where every wave is a chain, did nothing in
+// fill the slots the blenders leave --, tester 1 (above the finished blocks' output / zero stores, which run at 0) to 0.1277. Measured
+// and NOT kept (profiles/r06_ab_pair_priorities.txt): blender 2 = blender 3; tester 2 = tester 1; the blender's level kept through its tail
+// 0.1331; levels that rise with the rounds walked 0.134-0.138, or once a blender has composited 300 .. 1 100 staged entries 0.127-0.129;
+// a tester that takes the blender's level while the blender waits for it 0.126-0.128; a blender that waits at level 0 0.125-0.126 (and
+// 0.089 -> 0.096 at 250k / 512^2); four workgroups per CU (<= 64 VGPRs) 0.155. (Priorities among the waves of the SERIAL walk, where every wave is a chain, did nothing in
 // round 4: 0.1536 / 0.1536.)
 #ifndef GSR_PAIR_PRIO_B
 #define GSR_PAIR_PRIO_B 3
@@ -616,20 +619,8 @@ template __global__ void gsr_render_fwd_serial<true>(const uint32_t*, const Spla
 #ifndef GSR_PAIR_PRIO_T
 #define GSR_PAIR_PRIO_T 1
 #endif
-#ifndef GSR_PAIR_PRIO_ADAPT
-#define GSR_PAIR_PRIO_ADAPT 0     // experiment: a tester that finds its buffer free at once (its blender is waiting for IT) takes the blender's level for the round
-#endif
-#ifndef GSR_PAIR_WAIT_LOW
-#define GSR_PAIR_WAIT_LOW 0       // experiment: a blender that has to wait for its tester waits at priority 0
-#endif
 #ifndef GSR_PAIR_PRIO_TAIL
 #define GSR_PAIR_PRIO_TAIL 0      // priority of the blender behind its walk (outputs, work items, the slices of zeros)
-#endif
-#ifndef GSR_PAIR_PRIO_DEPTH
-#define GSR_PAIR_PRIO_DEPTH 0     // experiment: n > 0 = both waves of a block rise one level every n rounds (blender from 1, tester from 0)
-#endif
-#ifndef GSR_PAIR_WAVES_PER_EU
-#define GSR_PAIR_WAVES_PER_EU 6
 #endif
 #define GSR_PAIR_END 0xffu
 #define GSR_PAIR_STOP 0xffffffffu
@@ -642,7 +633,7 @@ __device__ __forceinline__ void lds_flag_store(uint32_t* p, uint32_t v, int lane
     if (lane == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-__global__ void __launch_bounds__(512, GSR_PAIR_WAVES_PER_EU)      // 6: <= 80 VGPRs, three workgroups of eight waves per CU
+__global__ void __launch_bounds__(512, 6)      // <= 80 VGPRs: three workgroups of eight waves per CU
 gsr_render_fwd_pair(const uint32_t* __restrict__ tile_off, const SplatRec* __restrict__ recs,
                     const uint32_t* __restrict__ ids, int W, int H, int gx,
                     float* __restrict__ out_color, float* __restrict__ out_depth,
@@ -730,7 +721,6 @@ gsr_render_fwd_pair(const uint32_t* __restrict__ tile_off, const SplatRec* __res
         auto test_round = [&](const uint32_t r, float4 ra, float4 rb, float4 rc, float4& da, float4& db, float4& dc) -> bool {
             const uint32_t rel = r * GSR_RB;
             const int buf = (int)(r & 1u);
-            if (GSR_PAIR_PRIO_DEPTH) { if (r == (uint32_t)GSR_PAIR_PRIO_DEPTH) __builtin_amdgcn_s_setprio(1); if (r == 2u * (uint32_t)GSR_PAIR_PRIO_DEPTH) __builtin_amdgcn_s_setprio(2); }
             if (rel >= n) {                                 // behind the end of the list
                 if (r >= 2u && !wait_free(&freed[blk][buf], r - 1u)) return false;
                 lds_flag_store(&ready[blk][buf], ((r + 1u) << 8) | GSR_PAIR_END, lane);
@@ -759,9 +749,6 @@ gsr_render_fwd_pair(const uint32_t* __restrict__ tile_off, const SplatRec* __res
                 *((lane < 4 && keep_state) ? mp + lane : sink64) = lane == 0 ? m0 : (lane == 1 ? m1 : (lane == 2 ? m2 : m3));
             }
             // the buffer is free once the blender has left round r - 2
-            if (GSR_PAIR_PRIO_ADAPT && r >= 2u) {
-                if (lds_flag_load(&freed[blk][buf]) == r - 1u) __builtin_amdgcn_s_setprio(GSR_PAIR_PRIO_B); else __builtin_amdgcn_s_setprio(GSR_PAIR_PRIO_T);
-            }
             if (r >= 2u) { if (!wait_free(&freed[blk][buf], r - 1u)) return false; }
             else if (lds_flag_load(&freed[blk][buf]) == GSR_PAIR_STOP) return false;
             alive = __hip_atomic_load(&alive_pub[blk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // gate of the NEXT round's quads (a superset of the pixels alive then)
@@ -793,24 +780,14 @@ gsr_render_fwd_pair(const uint32_t* __restrict__ tile_off, const SplatRec* __res
         }
     } else if (n > 0u) {
         // ---- the blender
-        __builtin_amdgcn_s_setprio(GSR_PAIR_PRIO_DEPTH ? 1 : GSR_PAIR_PRIO_B);
+        __builtin_amdgcn_s_setprio(GSR_PAIR_PRIO_B);
 #pragma unroll 1
         for (uint32_t r = 0;; ++r) {
             const uint32_t rel = r * GSR_RB;
             const int buf = (int)(r & 1u);
-            if (GSR_PAIR_PRIO_DEPTH) { if (r == (uint32_t)GSR_PAIR_PRIO_DEPTH) __builtin_amdgcn_s_setprio(2); if (r == 2u * (uint32_t)GSR_PAIR_PRIO_DEPTH) __builtin_amdgcn_s_setprio(3); }
             uint32_t code = lds_flag_load(&ready[blk][buf]);
-#if GSR_PAIR_WAIT_LOW
-            if ((code >> 8) != r + 1u) {                    // the tester is late: it shares this SIMD -- wait BELOW it, not above
-                __builtin_amdgcn_s_setprio(0);
-#pragma unroll 1
-                for (int spin = 0; (code >> 8) != r + 1u && spin < GSR_PAIR_SPINS; ++spin) { __builtin_amdgcn_s_sleep(1); code = lds_flag_load(&ready[blk][buf]); }
-                __builtin_amdgcn_s_setprio(GSR_PAIR_PRIO_B);
-            }
-#else
 #pragma unroll 1
             for (int spin = 0; (code >> 8) != r + 1u && spin < GSR_PAIR_SPINS; ++spin) { __builtin_amdgcn_s_sleep(1); code = lds_flag_load(&ready[blk][buf]); }
-#endif
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
             if ((code >> 8) != r + 1u) { lost = true; break; }      // the tester never delivered this round (2^20 polls): see below
             if ((code & 0xffu) == GSR_PAIR_END) break;

@@ -52,11 +52,83 @@ _deterministic = False
 _pass_fwd_stats = True
 
 
+# The torch binding in C++ (csrc/gsr_torch.cpp -> _gsr_torch.so, dreamgaussian_amd/build.py): the same host logic as the
+# autograd.Function below -- checks, allocations, view struct, gradient carving, the two C-ABI calls -- without the Python in between
+# (and without the three scratch callbacks that re-enter it): at DreamGaussian's own sizes that Python is most of a step. Used by the
+# three entry points when the module has been built; `use_cpp_binding(False)` (or a missing module) selects the ctypes path.
+_binding = None
+_binding_state = 0          # 0 = not tried, 1 = loaded, -1 = unavailable
+_use_binding = True
+_last_via_binding = False
+
+
+def use_cpp_binding(on: bool) -> bool:
+    """Route the rasterizer's entry points through the C++ binding (default when it has been built) or through the ctypes path;
+    returns the old setting."""
+    global _use_binding
+    old, _use_binding = _use_binding, bool(on)
+    return old
+
+
+def _get_binding():
+    global _binding, _binding_state
+    if _binding_state == 0:
+        _binding_state = -1
+        import importlib.util
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_gsr_torch.so")
+        if os.path.exists(path):
+            try:
+                _lib.load()                                   # (loads libgsr.so and checks its ABI version first)
+                spec = importlib.util.spec_from_file_location("dreamgaussian_amd._gsr_torch", path)
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+                if mod.abi_version() == _lib.GSR_ABI_VERSION:
+                    mod.init(_lib.LIB_PATH)
+                    _binding, _binding_state = mod, 1
+            except Exception as e:                            # a stale or unloadable module: the ctypes path is complete on its own
+                import warnings
+                warnings.warn(f"dreamgaussian_amd: the C++ torch binding could not be loaded ({e}); using the ctypes path")
+    return _binding if _binding_state == 1 else None
+
+
+def binding_loaded() -> bool:
+    return _get_binding() is not None
+
+
+def _via_binding(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs, raw, sh_rest):
+    """The call through _gsr_torch.rasterize, or None when the C++ path does not apply (module absent or switched off, settings that are
+    not tensors, the tests' fwd_stats = NULL mode)."""
+    global _last_via_binding, _last_pending
+    if not (_use_binding and _pass_fwd_stats):
+        return None
+    b = _get_binding()
+    if b is None or not all(type(x) is torch.Tensor for x in (rs.bg, rs.viewmatrix, rs.projmatrix, rs.campos)):
+        return None
+    extra = (_lib.GSR_VIEW_ASYNC_STATS if _async_forward else 0) | (_lib.GSR_VIEW_DETERMINISTIC if _deterministic else 0)
+    out = b.rasterize(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, sh_rest,
+                      rs.bg, rs.viewmatrix, rs.projmatrix, rs.campos, int(rs.image_height), int(rs.image_width), float(rs.tanfovx),
+                      float(rs.tanfovy), float(rs.scale_modifier), int(rs.sh_degree), bool(rs.prefiltered), bool(rs.debug), bool(raw),
+                      extra, _testing._current.get("k6_compact") == 1)
+    _last_via_binding, _last_pending = True, None
+    return tuple(out)
+
+
 def set_async_forward(on: bool) -> bool:
     """Opt into (or out of) the forward that does not wait for its instance counters (GSR_VIEW_ASYNC_STATS); returns the old setting."""
     global _async_forward
     old, _async_forward = _async_forward, bool(on)
     return old
+
+
+def peek_stats(complete: bool = False) -> dict:
+    """The statistics of the calling thread's most recent forward as they stand (an asynchronous forward's counts are -1 and
+    `pending` != 0 until `last_stats()` -- or `complete=True` here -- has collected them)."""
+    if _last_via_binding:
+        v = _binding.last_stats(bool(complete))
+        return dict(M=v[0], M_ref=v[1], V=v[2], max_tile=v[3], seg_shift=v[4], bwd_prepared=v[5], speculated=v[6], pending=v[7],
+                    N=v[8], H=v[9], W=v[10], K=v[11])
+    return last_stats() if complete else dict(_last_stats)
 
 
 def set_deterministic(on: bool) -> bool:
@@ -70,6 +142,8 @@ def last_stats() -> dict:
     """Scene statistics of the most recent forward (V, M of SURVEY 8(d)). After an asynchronous forward this collects its counts
     (blocking until they have arrived; call it from the thread that rendered)."""
     global _last_pending
+    if _last_via_binding:
+        return peek_stats(complete=True)
     if _last_pending is not None:
         stats, _last_pending = _last_pending, None
         rc = _lib.load().gsr_forward_complete(C.byref(stats))
@@ -222,7 +296,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                                  geom.alloc, binb.alloc, img.alloc, C.byref(stats), stream)
         geom_t, bin_t, img_t = geom.release(), binb.release(), img.release()
         _lib.check(rc, "gsr_forward")
-        global _last_pending
+        global _last_pending, _last_via_binding
+        _last_via_binding = False
         _last_pending = stats if stats.pending else None   # (an asynchronous forward: the counts are -1 until last_stats() collects them)
         _last_stats.update(M=stats.num_instances, M_ref=stats.num_instances_ref,
                            V=stats.num_visible, max_tile=stats.max_tile_count, N=N, H=H, W=W, K=K,
@@ -317,6 +392,9 @@ class _RasterizeGaussians(torch.autograd.Function):
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                         cov3Ds_precomp, raster_settings):
+    out = _via_binding(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings, False, None)
+    if out is not None:
+        return out
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales,
                                      rotations, cov3Ds_precomp, raster_settings, False, None, torch.is_grad_enabled())
 
@@ -327,6 +405,9 @@ def rasterize_gaussians_raw(means3D, means2D, sh, opacity_raw, scaling_raw, rota
     (gs_renderer.py:134-142, 196-216) and their backward inside the per-Gaussian kernels -- five
     elementwise launches and their five backward launches per render disappear. Same outputs as
     `rasterize_gaussians(means3D, means2D, sh, None, sigmoid(o), exp(s), normalize(q), None, settings)`."""
+    out = _via_binding(means3D, means2D, sh, None, opacity_raw, scaling_raw, rotation_raw, None, raster_settings, True, None)
+    if out is not None:
+        return out
     return _RasterizeGaussians.apply(means3D, means2D, sh, None, opacity_raw, scaling_raw, rotation_raw,
                                      None, raster_settings, True, None, torch.is_grad_enabled())
 
@@ -337,6 +418,9 @@ def rasterize_gaussians_split(means3D, means2D, features_dc, features_rest, opac
     tensors DreamGaussian keeps (`_features_dc` [N,1,3], `_features_rest` [N,K-1,3]) read where they are -- no
     `torch.cat` copy per render (gs_renderer.py:209-212), gradients written straight into two tensors of the same
     shapes. Same outputs as `rasterize_gaussians_raw(means3D, means2D, cat((features_dc, features_rest), 1), ...)`."""
+    out = _via_binding(means3D, means2D, features_dc, None, opacity_raw, scaling_raw, rotation_raw, None, raster_settings, True, features_rest)
+    if out is not None:
+        return out
     return _RasterizeGaussians.apply(means3D, means2D, features_dc, None, opacity_raw, scaling_raw, rotation_raw,
                                      None, raster_settings, True, features_rest, torch.is_grad_enabled())
 

@@ -18,6 +18,7 @@ def pytest_configure(config):
     # on import: it fails loudly when libgsr.so is absent.
     from dreamgaussian_amd import build as _build
     _build.build(verbose=False)
+    _build.build_binding(verbose=False)      # the C++ torch binding (g++, ~45 s the first time)
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` on the GPU box)")
 
 

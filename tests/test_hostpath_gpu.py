@@ -110,7 +110,8 @@ def test_async_forward_matches_the_blocking_one(gpu):
         for p, (o_ref, g_ref, st_ref) in zip(poses, ref):
             S = O.make_settings(p, W, H, sh_degree=1)
             o, g = _render(sc, S, gpu, w)
-            assert R._last_stats["pending"] != 0 and R._last_stats["M"] == -1      # returned before the counters were collected
+            pk = R.peek_stats()
+            assert pk["pending"] != 0 and pk["M"] == -1                              # returned before the counters were collected
             st = D.last_stats()
             assert st["pending"] == 0 and st["speculated"] == 1
             assert (st["M"], st["M_ref"], st["V"], st["max_tile"]) == (st_ref["M"], st_ref["M_ref"], st_ref["V"], st_ref["max_tile"])

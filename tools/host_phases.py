@@ -51,9 +51,32 @@ def run(n, sync_each=False):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n * 1e3
 
-for label, kw in (("free running", {}), ("synchronize after every step", dict(sync_each=True))):
-    ms = run(400, **kw)
-    print(f"== {label}: {ms:.3f} ms/step")
-    for k, v in sorted(acc.items()):
-        v = sorted(v)
-        print(f"   {k:28s} median {st.median(v):7.1f} us  p10 {v[len(v)//10]:7.1f}  p90 {v[9*len(v)//10]:7.1f}")
+def host_only(n):
+    """host time of one fwd+bwd ENQUEUE (the call returns before the GPU has run it): forward call, backward call"""
+    for _ in range(30): step()
+    torch.cuda.synchronize()
+    tf, tb = [], []
+    for _ in range(n):
+        t0 = time.perf_counter_ns()
+        c, r, d, a = rast(means3D=t["means3D"], means2D=m2d, shs=t["shs"], colors_precomp=None, opacities=t["opacities"],
+                          scales=t["scales"], rotations=t["rotations"], cov3D_precomp=None)
+        t1 = time.perf_counter_ns()
+        torch.autograd.backward([c, d, a], g)
+        t2 = time.perf_counter_ns()
+        tf.append((t1 - t0) / 1e3); tb.append((t2 - t1) / 1e3)
+        if len(tf) % 8 == 0: torch.cuda.synchronize()       # (keep the queue short: the host must not be throttled by a full one)
+    return st.median(tf), st.median(tb)
+
+# round 6: the two bindings side by side (the C++ autograd function of csrc/gsr_torch.cpp is the default when built)
+for name, on in (("C++ binding (_gsr_torch.so)", True), ("ctypes / Python autograd.Function", False)):
+    if on and not D.binding_loaded():
+        print("== C++ binding: not built"); continue
+    D.use_cpp_binding(on)
+    f_us, b_us = host_only(400)
+    ms = run(400)
+    print(f"== {name}: {ms:.3f} ms/step free running; host per call: forward {f_us:.1f} us, backward {b_us:.1f} us")
+    if not on:
+        for k, v in sorted(acc.items()):
+            v = sorted(v)
+            print(f"   {k:28s} median {st.median(v):7.1f} us  p10 {v[len(v)//10]:7.1f}  p90 {v[9*len(v)//10]:7.1f}")
+D.use_cpp_binding(True)
