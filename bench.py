@@ -357,6 +357,9 @@ def main():
                     help="what the timed step does about DreamGaussian's parameter activations (gs_renderer.py:134-142): "
                          "none = the rasterizer alone on activated inputs (the headline metric); torch = sigmoid/exp/normalize "
                          "as torch ops + their autograd, as Renderer.render does; fused = rasterize_gaussians_raw")
+    ap.add_argument("--binding", default="auto", choices=["auto", "cpp", "ctypes"],
+                    help="which torch binding drives the C ABI: the C++ autograd function of csrc/gsr_torch.cpp (auto: when it has been built) or the "
+                         "ctypes / Python autograd.Function of rasterizer.py; recorded in the line's config")
     ap.add_argument("--async-forward", action="store_true",
                     help="dreamgaussian_amd.set_async_forward(True): gsr_forward returns without waiting for its instance counters (GSR_VIEW_ASYNC_STATS, "
                          "opt-in; recorded in the line's config -- a line with it is not the headline)")
@@ -392,6 +395,10 @@ def main():
 
     import dreamgaussian_amd as D
     from dreamgaussian_amd import _lib, views
+    if a.binding == "ctypes":
+        D.use_cpp_binding(False)
+    elif a.binding == "cpp" and not D.binding_loaded():
+        raise SystemExit("--binding cpp: dreamgaussian_amd/_gsr_torch.so has not been built (python -m dreamgaussian_amd.build)")
     if a.async_forward:
         D.set_async_forward(True)
     if a.hook:
@@ -626,7 +633,8 @@ def main():
                        "views_per_step": world * a.views, "order": a.order, "activations": a.activations, "views_mode": ("single" if a.views == 1 else ("serial loop" if a.views_serial else "rasterize_views/chain")), "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU",
                        "N": wl["N"], "K": K, "V": st.get("V"), "M": st.get("M_ref"), "M_emitted": st.get("M"),
                        "max_tile_list": st.get("max_tile"), "seg_shift": st.get("seg_shift"),
-                       **({"hooks": list(a.hook)} if a.hook else {}), **({"async_forward": True} if a.async_forward else {})},
+                       **({"hooks": list(a.hook)} if a.hook else {}), **({"async_forward": True} if a.async_forward else {}),
+                       "binding": "cpp" if (a.binding != "ctypes" and D.binding_loaded()) else "ctypes"},
             "roofline": roof, "path_roofline": path_roof, "cpu_baseline": cpu,
             "kernels_ms_per_step": {k: round(v[0] / a.steps, 4) for k, v in sorted(kern.items())},
             "kernels_ms_per_step_raw": {k: round(v, 4) for k, v in sorted(kern_raw.items())} if kern else {},

@@ -145,3 +145,18 @@ def test_morton_order_is_the_z_curve_sort():
     cs = [code(v) for v in q]
     assert p == sorted(range(500), key=lambda i: (cs[i], i))
     assert p.index(3) + 1 == p.index(17)
+
+
+def test_torch_binding_builds_loads_and_matches_the_header():
+    """dreamgaussian_amd/_gsr_torch.so (csrc/gsr_torch.cpp: the C++ autograd binding over the C ABI) builds with g++ against torch's headers
+    (no GPU needed), loads, binds to the in-tree libgsr.so and was compiled against the header's ABI version. It holds no device code
+    and computes nothing: CPU tensors raise through it exactly as through the ctypes path."""
+    from dreamgaussian_amd import _lib, build as b, rasterizer as R
+    assert os.path.exists(b.build_binding(verbose=False))
+    assert R.binding_loaded() and R._binding.abi_version() == _lib.GSR_ABI_VERSION
+    src = open(os.path.join(ROOT, "dreamgaussian_amd", "csrc", "gsr_torch.cpp")).read()
+    assert "oracle" not in src and "__global__" not in src and "hipLaunchKernel" not in src
+    m, o, sh, s, q = torch.zeros(4, 3), torch.ones(4, 1), torch.zeros(4, 1, 3), torch.ones(4, 3), torch.ones(4, 4)
+    with pytest.raises(RuntimeError, match="no CPU fallback|There is no CPU"):
+        R._binding.rasterize(m, m, sh, None, o, s, q, None, None, torch.zeros(3), torch.eye(4), torch.eye(4), torch.zeros(3), 16, 16, 1.0, 1.0, 1.0, 0,
+                             False, False, False, 0, False)

@@ -25,12 +25,12 @@ def _both(fn):
     return out["cpp"], out["ctypes"]
 
 
-def _close(ga, gb, tol=1e-5):
+def _close(ga, gb, tol=1e-5, floors=None):
     for k in ga:
         if ga[k] is None or gb[k] is None:
             assert ga[k] is None and gb[k] is None, k
             continue
-        scale = gb[k].abs().max().item() + 1e-30
+        scale = max(gb[k].abs().max().item(), (floors or {}).get(k, 0.0)) + 1e-30     # (an isotropic blob's drotations is cancellation noise: its floor)
         assert ga[k].shape == gb[k].shape and (ga[k] - gb[k]).abs().max().item() <= tol * scale + 1e-12, k
 
 
@@ -57,7 +57,7 @@ def test_both_bindings_give_the_same_result(gpu, case):
     (oa, ga, sa), (ob, gb, sb) = _both(lambda: util.run_hip(sc, S, gpu, w))
     for a, b in zip(oa, ob):
         assert torch.equal(a, b)
-    _close(ga, gb)
+    _close(ga, gb, floors=util.grad_floors(sc, gb))
     for k in ("M", "M_ref", "V", "max_tile", "N", "H", "W", "K", "seg_shift"):
         assert sa[k] == sb[k], k
 
@@ -125,7 +125,7 @@ def test_edges_through_both_bindings(gpu):
         oe = rast(means3D=e["means3D"], means2D=torch.zeros(0, 3, device=gpu, requires_grad=True), shs=e["shs"], opacities=e["opacities"],
                   scales=e["scales"], rotations=e["rotations"])
         oe[0].sum().backward()
-        res["empty"] = (oe[0].detach().clone(), tuple(e["shs"].grad.shape))
+        res["empty"] = (oe[0].detach().clone(), tuple(e["means3D"].grad.shape), e["shs"].grad is None)     # (an empty tensor counts as absent: no gradient for it)
         # (5) CPU tensors raise
         with pytest.raises(RuntimeError, match="no CPU fallback|There is no CPU"):
             rast(**{k: v.detach().cpu() for k, v in kw.items()})
@@ -135,4 +135,4 @@ def test_edges_through_both_bindings(gpu):
     for x, y in zip(a["img"], b["img"]):
         assert torch.equal(x, y)
     _close(a["col"], b["col"])
-    assert torch.equal(a["empty"][0], b["empty"][0]) and a["empty"][1] == b["empty"][1] == (0, 4, 3)
+    assert torch.equal(a["empty"][0], b["empty"][0]) and a["empty"][1:] == b["empty"][1:] == ((0, 3), True)
