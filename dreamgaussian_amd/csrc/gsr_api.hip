@@ -379,7 +379,7 @@ extern "C" int gsr_profile_read(int cap, const char** names, float* total_ms, in
     }
     return n;
 }
-extern "C" const char* gsr_version(void) { return "gsr 0.4 (gfx950, wave64, 16x16 bins / 8x8 wave blocks, depth-segmented forward)"; }
+extern "C" const char* gsr_version(void) { return "gsr 0.5 (gfx950, wave64, 16x16 bins / 8x8 wave blocks, depth-segmented forward, ABI 6)"; }
 extern "C" int gsr_abi_version(void) { return GSR_ABI_VERSION; }
 extern "C" int gsr_testing_override(const char* name, int32_t value) {
     if (!name) return fail(-1, "override name is NULL%s", "");
