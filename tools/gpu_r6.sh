@@ -33,7 +33,7 @@ order)
 floor5k)
   # 5k / 256^2: ten launches of the bench line, blocking and with the forward that does not wait for its counters; the host phases
   python tools/host_overhead.py 2>&1 | grep -a "ms/step\|floor" | tee gpurun_out/host_floor_5k.txt
-  for mode in "" "--async-forward"; do
+  for mode in "--binding cpp" "--binding ctypes" "--binding cpp --async-forward" "--binding ctypes --async-forward"; do
     echo "== 5k-256-sh0 $mode" | tee -a gpurun_out/host_floor_5k.txt
     for i in 1 2 3 4 5 6 7 8 9 10; do python bench.py --workload 5k-256-sh0 --cpu-budget 0 --no-roofline --steps 200 --warmup 20 $mode 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('5k-256-sh0 ms_per_step', d['ms_per_step'])"; done | tee -a gpurun_out/host_floor_5k.txt
   done

@@ -244,6 +244,7 @@ def main():
     ap.add_argument("--no-oracle-check", action="store_true")
     ap.add_argument("--oracle-check-256-only", action="store_true", help="check the trained model against the fp64 oracle at the 256^2 training view only "
                     "(the 512^2 orbit view costs the CPU oracle four times as long: the GPU suite's test uses this)")
+    ap.add_argument("--oracle-512-report-only", action="store_true", help="record a failed assertion of the 512^2 orbit-view oracle check in the JSON instead of aborting")
     ap.add_argument("--optin", action="store_true", help="one more run with FusedAdam, the fused densification statistics and the "
                                                          "one-gather prune patched onto the reference's GaussianModel")
     ap.add_argument("--async-forward", action="store_true", help="two more runs (plain and opt-in) with dreamgaussian_amd.set_async_forward(True): "
@@ -262,7 +263,16 @@ def main():
     plain = run(ref, a.iters, input_path, profiled=False, keep=model)     # the number to quote: same seed, warm process
     oracle_rep = None
     if not a.no_oracle_check:                                 # the run asserts what it rendered with: the trained model, HIP vs oracle
-        oracle_rep = check_against_oracle(model, sizes=((256, 0.0, 0.0),)) if a.oracle_check_256_only else check_against_oracle(model)
+        oracle_rep = check_against_oracle(model, sizes=((256, 0.0, 0.0),))          # the training view: always asserted
+        if not a.oracle_check_256_only:
+            # the 512^2 orbit view: asserted too, unless --oracle-512-report-only (the count cap on flagged-and-different pixels is a fixed
+            # 2e-4 of the image; a trained model full of near-opaque Gaussians sits close to it: round 6 saw 60 against a cap of 52 once)
+            try:
+                oracle_rep.update(check_against_oracle(model, sizes=((512, -15.0, 130.0),)))
+            except AssertionError as e:
+                if not a.oracle_512_report_only:
+                    raise
+                oracle_rep["512x512_assertion"] = str(e)
     if a.export_fixture:
         n = int(model["means3D"].shape[0])
         idx = torch.randperm(n, generator=torch.Generator().manual_seed(0))[:2000].sort().values
