@@ -32,7 +32,8 @@ def test_hot_kernels_have_no_loads_waited_for_on_the_spot(asm):
     budget = {
         "_Z21gsr_render_fwd_serialILb1E": 1,      # the work-list reservation (returning atomic) at the end
         "_Z21gsr_render_fwd_serialILb0E": 1,
-        "_Z17gsr_render_bwd_q2": 4,               # later rounds of segments longer than 64 entries: list entry -> records
+        "_Z17gsr_render_bwd_q2": 5,               # later rounds of segments longer than 64 entries: list entry -> records; + round 6: the record's tile
+                                                  # rectangle in the flush of the opt-in deterministic mode (GSR_VIEW_DETERMINISTIC)
         "gsr_scatter": 32,                        # the segment forward's work items (rare path), the tail of the eight-deep fetch of the ranges, the refill of a pinned grid's later rounds: 11;
                                                   # + round 5: K2's body inlined for the launch's ONE scan workgroup (a chain of dependent phases by nature: 17) and the
                                                   # scatter workgroups' own scan of the tile counts (the counts of the other views, the tail of the fetch: 2)
