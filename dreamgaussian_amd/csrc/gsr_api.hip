@@ -154,9 +154,9 @@ int once_per_device(F fn) {
 // A/B measurement through an explicit call. Nothing here is read from the process environment: two of them (forward mode, segment
 // length) decide where the per-pixel sums are cut, i.e. the rounding of the results, and that must not depend on who started the
 // process. -1 = the library decides.
-enum { OV_FWD_MODE, OV_SEG_SHIFT, OV_FWD_LISTS, OV_FWD_HINTS, OV_SPECULATE, OV_HIST_MAX, OV_K1_GRID, OV_FWD_GRID, OV_K6_GRID, OV_FWD_LDS_KB, OV_BWD_GRID, OV_K6_COMPACT, OV_SCAN_FOLD, OV_GRAD_CLEAR, OV_COUNT };
-const char* const kOvNames[OV_COUNT] = {"fwd_mode", "seg_shift", "fwd_lists", "fwd_hints", "speculate", "hist_max", "k1_grid", "fwd_grid", "k6_grid", "fwd_lds_kb", "bwd_grid", "k6_compact", "scan_fold", "grad_clear"};
-std::atomic<int> g_ov[OV_COUNT] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
+enum { OV_FWD_MODE, OV_SEG_SHIFT, OV_FWD_LISTS, OV_FWD_HINTS, OV_SPECULATE, OV_HIST_MAX, OV_K1_GRID, OV_FWD_GRID, OV_K6_GRID, OV_FWD_LDS_KB, OV_BWD_GRID, OV_K6_COMPACT, OV_SCAN_FOLD, OV_GRAD_CLEAR, OV_K1_GROUP, OV_COUNT };
+const char* const kOvNames[OV_COUNT] = {"fwd_mode", "seg_shift", "fwd_lists", "fwd_hints", "speculate", "hist_max", "k1_grid", "fwd_grid", "k6_grid", "fwd_lds_kb", "bwd_grid", "k6_compact", "scan_fold", "grad_clear", "k1_group"};
+std::atomic<int> g_ov[OV_COUNT] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
 inline int ov(int k) { return g_ov[k].load(std::memory_order_relaxed); }
 
 // K1's grid (a persistent grid: every workgroup walks the same number of 256-Gaussian batches; test hook "k1_grid" pins it). The
@@ -170,6 +170,16 @@ int k1_grid_for(int N) {
     return (batches + rounds - 1) / rounds;
 }
 
+// How many consecutive K1 workgroups share one reserved range per tile list = how many 256-thread slices a workgroup of gsr_scatter has
+// (1 or 4). Four from 256 K1 workgroups on (65k Gaussians): a group's run in a list is then a whole cache line written through one
+// L2, and a tile counter sees a quarter of the reserving atomics (gsr_preprocess_fwd's flush; profiles/r06_group_reservation.txt:
+// K1 -7 us and the scatter -14 us at 1M Gaussians, K1 -10 us at 250k). Test hook "k1_group" pins it (1 / 4).
+int k1_group_for(int N) {
+    const int pin = ov(OV_K1_GROUP);
+    if (pin == 1 || pin == 4) return pin;
+    return k1_grid_for(N) >= 256 ? 4 : 1;
+}
+
 // Largest tile grid whose per-tile counters a workgroup of K1 / the scatter keeps in LDS (64 KiB)
 static int hist_lds_max_tiles() {
     const int t = ov(OV_HIST_MAX);
@@ -177,7 +187,7 @@ static int hist_lds_max_tiles() {
 }
 
 struct GeomLayout {
-    size_t recs, emit, flags8, block_stats, tile_count, cursor, counters, tile_off, tile_seg, order, order_span, level_off, sat, plan_off, g2d, wg_base, total;
+    size_t recs, emit, flags8, block_stats, tile_count, cursor, counters, arrive, tile_off, tile_seg, order, order_span, level_off, sat, plan_off, g2d, wg_base, total;
     int nTiles;        // per view
     int allTiles;      // views * nTiles: the per-tile arrays hold every view's tiles, view-major
 };
@@ -198,6 +208,7 @@ GeomLayout geom_layout(int N, int H, int W, int B = 1, bool with_acc = true /* f
     L.tile_count = o; o += align_up(BT * 4);
     L.cursor = o; o += align_up(BT * 4);
     L.counters = o; o += align_up((size_t)kCounterSlots * 8);          // totals, (M_ref, V) per view, walk items, quad-mask word, K1's tag
+    L.arrive = o; o += align_up((size_t)B * 2048 * 4);                 // K1's flush: workgroups of a group that have stored their histogram (cleared with the counters)
     L.tile_off = o; o += align_up((BT + 1) * 4);
     L.tile_seg = o; o += align_up((BT + 1) * 4);
     L.order = o; o += align_up(BT * 4);
@@ -211,12 +222,19 @@ GeomLayout geom_layout(int N, int H, int W, int B = 1, bool with_acc = true /* f
     L.g2d = o; o += with_acc ? align_up(BN * GSR_G2D_STRIDE * 4 + (size_t)B * GSR_LIVE_BYTES(N)) : 0;
     // LAST (round-5 advisor: its size follows K1's grid and the LDS-histogram limit, both of which a test hook can change between a
     // forward and its backward -- nothing the backward reads may sit behind it): where each of K1's workgroups starts inside every
-    // tile's list ([view][workgroup][tile] u32, written by K1's histogram flush, read by the scatter) -- only with the tile counters
-    // in LDS: larger tile grids use global cursors and never touch it
-    L.wg_base = o; o += L.nTiles <= hist_lds_max_tiles() ? align_up((size_t)B * (size_t)k1_grid_for(N) * (size_t)L.nTiles * 4) : 0;
+    // tile's list ([view][workgroup][tile] u32 histogram rows of K1's workgroups, then [view][group][tile] u32 range starts: written
+    // by K1's histogram flush, the second read by the scatter) -- only with the tile counters in LDS: larger tile grids use global
+    // cursors and never touch it
+    L.wg_base = o;
+    if (L.nTiles <= hist_lds_max_tiles()) {
+        const int grid = k1_grid_for(N), G = k1_group_for(N);
+        o += align_up((size_t)B * (size_t)grid * (size_t)((L.nTiles + 3) & ~3) * 4) + align_up((size_t)B * (size_t)((grid + G - 1) / G) * (size_t)L.nTiles * 4);
+    }
     L.total = o;
     return L;
 }
+// where the [view][group][tile] range starts sit behind the histogram rows (geom_layout)
+inline size_t group_base_off(const GeomLayout& L, int N, int B) { return L.wg_base + align_up((size_t)B * (size_t)k1_grid_for(N) * (size_t)((L.nTiles + 3) & ~3) * 4); }
 struct BinLayout { size_t entries, ids, ckpt, plan_tile, plan_cap, items, item_recs, walk_items, total; };
 BinLayout bin_layout(size_t M, int nTiles, int shift, bool records = true /* false: a serial-walk forward no backward follows keeps no segment records */) {
     BinLayout L;
@@ -450,7 +468,8 @@ int begin_impl(const GsrView* views, int B, int32_t N, int32_t K,
         prof_begin(stream); hipLaunchKernelGGL(k1, dim3(grid_pre, B), dim3(256), lds, stream, tab, N, K, means3D, shs, view->shs_rest,
                            colors_precomp, opacities, scales, rotations, cov3D_precomp, recs, emit, radii,
                            tile_count, (unsigned long long*)(gbuf + GL.block_stats), hist_in_lds, (uint8_t*)(gbuf + GL.flags8),
-                           (uint32_t*)(gbuf + GL.tile_count), zero_words, flag_word, epoch, (uint32_t*)(gbuf + GL.wg_base));
+                           (uint32_t*)(gbuf + GL.tile_count), zero_words, flag_word, epoch, (uint32_t*)(gbuf + GL.wg_base),
+                           (uint32_t*)(gbuf + group_base_off(GL, N, B)), k1_group_for(N), (uint32_t*)(gbuf + GL.arrive));
         LAUNCH_CHECK(view, stream, "preprocess_fwd");
     }
     if (scan_in_scatter) return 0;                         // (finish_impl: a workgroup of gsr_scatter runs K2 beside the scatter)
@@ -523,8 +542,6 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
 
     if (M > 0) {
         const size_t lds = hist_in_lds ? (size_t)T * 4 : 0;
-        if (lds > 48 * 1024)
-            HIP_TRY(hipFuncSetAttribute((const void*)gsr_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const uint32_t* level_off = (const uint32_t*)(gbuf + GL.level_off);
         uint4* items = (uint4*)(bbuf + BL.item_recs);
         const uint32_t items_cap = sequential ? 0u : (uint32_t)BL.items;   // the serial walk takes its tiles from `order`: no work items
@@ -544,9 +561,11 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
                 const size_t scan_base = (sizeof(TileScanLds) + 15) & ~(size_t)15;
                 if (scan_base + ((size_t)TA + 1) * 4 <= 24 * 1024) fold.lds_words = TA + 1;      // (every workgroup of the launch is given the same dynamic LDS: keep it small)
                 if (lds_sc < scan_base + (size_t)fold.lds_words * 4) lds_sc = scan_base + (size_t)fold.lds_words * 4;
-                if (lds_sc > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)gsr_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc));
             }
-            hipLaunchKernelGGL(gsr_scatter, dim3(k1_grid_for(N) + (scan_in_scatter ? 1 : 0), B), dim3(256), lds_sc, stream, N, emit, tile_off, (const uint32_t*)(gbuf + GL.wg_base), entries,
+            const int G = k1_group_for(N), groups = (k1_grid_for(N) + G - 1) / G;
+            auto sc = G == 4 ? gsr_scatter<4> : gsr_scatter<1>;
+            if (lds_sc > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)sc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc));
+            hipLaunchKernelGGL(sc, dim3(groups + (scan_in_scatter ? 1 : 0), B), dim3(256 * G), lds_sc, stream, N, emit, tile_off, (const uint32_t*)(gbuf + group_base_off(GL, N, B)), entries,
                                vc.gx, T, (uint32_t)M, counters, level_off, order, tile_seg, shift, items, items_cap, k1_grid_for(N), fold,
                                (const unsigned long long*)(gbuf + GL.block_stats));
         } else {

@@ -235,10 +235,10 @@ gsr_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ ti
 __device__ __forceinline__ void write_forward_items(const uint32_t* __restrict__ level_off, const uint32_t* __restrict__ order,
                                                     const uint32_t* __restrict__ tile_off, const uint32_t* __restrict__ tile_seg,
                                                     int seg_shift, uint4* __restrict__ items, uint32_t items_cap, uint32_t* lev /* LDS [GSR_NLEV + 1] */) {
-    for (int i = threadIdx.x; i <= GSR_NLEV; i += 256) lev[i] = level_off[i];
+    for (int i = threadIdx.x; i <= GSR_NLEV; i += (int)blockDim.x) lev[i] = level_off[i];
     lds_barrier();
     const uint32_t total = min(lev[GSR_NLEV], items_cap);
-    const uint32_t nthreads = gridDim.x * gridDim.y * 256u, gid = (blockIdx.y * gridDim.x + blockIdx.x) * 256u + threadIdx.x;
+    const uint32_t nthreads = gridDim.x * gridDim.y * blockDim.x, gid = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
     for (uint32_t k = gid; k < total; k += nthreads) {
         uint32_t lo = 0, hi = GSR_NLEV;               // lev[lo] <= k < lev[hi]
         while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (lev[mid] <= k) lo = mid; else hi = mid; }
@@ -260,51 +260,61 @@ struct ScanFold {
     int lds_words;                           // words of dynamic LDS behind the TileScanLds block (all tiles' counts fit: K2 keeps them there)
 };
 
-// LDS-histogram mode (tile grids of up to 16 384 tiles): K1's twin. Same grid, same Gaussians per workgroup (batches bx,
-// bx + k1_grid, ... of 256): K1's histogram flush has reserved, per tile, the range of this workgroup's entries
-// (wg_base); the positions inside it are handed out from LDS. ONE pass, no global atomics.
+// LDS-histogram mode (tile grids of up to 16 384 tiles): K1's twin. A workgroup here is S x 256 threads and emits the Gaussians of a
+// GROUP of S consecutive K1 workgroups (K1 workgroup w walks batches w, w + k1_grid, ... of 256; slice q = threadIdx.x / 256 of block
+// g stands for K1 workgroup g * S + q): K1's histogram flush has reserved, per tile, ONE range for the group's entries (group_base);
+// the positions inside it are handed out from LDS. ONE pass, no global atomics. S = 4 at the headline size: what a workgroup writes
+// into a tile's list is a run of ~16 keys = a whole 128-byte line through ONE L2 (gsr_preprocess_fwd's flush has the measurement
+// this answers).
 //
 // K2 FOLDED IN (fold.on, round 5; the speculative forward of views whose compositing takes its tiles from `order`): the scatter needs
 // of K2 only where every tile's list starts -- an exclusive scan of the tile counts K1 left, which every workgroup here takes for
 // itself in LDS (2 500 counts: ~1 us, the counts are L2 hits) -- and the rest of K2 (segment bases, K1's statistics, the tiles
 // ordered by length for the sort and the compositing, the counters for the host) is needed by the kernels BEHIND the scatter. So
-// workgroup x = 0 of view 0 runs K2's body (256 threads instead of 1 024: it has the scatter's 35 us to hide in) and the scatter
-// workgroups are x = 1 .. k1_grid: one launch and 15-18 us of a single-workgroup kernel fewer per forward.
+// workgroup x = 0 of view 0 runs K2's body (it has the scatter's 35 us to hide in) and the scatter workgroups are x = 1 .. groups:
+// one launch and 15-18 us of a single-workgroup kernel fewer per forward.
 // dynamic LDS: max(nTiles uint32, sizeof(TileScanLds) + (views * nTiles + 1) uint32 when that fits 64 KiB).
 #define GSR_SC_R 4      // emission records a thread requests at once (K1's default grid: four batches per workgroup)
-extern "C" __global__ void __launch_bounds__(256)
+template <int S>
+__global__ void __launch_bounds__(256 * S)
 gsr_scatter(int N, const EmitRec* __restrict__ emit, const uint32_t* __restrict__ tile_off,
-            const uint32_t* __restrict__ wg_base, unsigned long long* __restrict__ entries,
+            const uint32_t* __restrict__ group_base, unsigned long long* __restrict__ entries,
             int gx, int nTiles, uint32_t capacity, unsigned long long* __restrict__ counters,
             const uint32_t* __restrict__ level_off, const uint32_t* __restrict__ order, const uint32_t* __restrict__ tile_seg,
             int seg_shift, uint4* __restrict__ items, uint32_t items_cap, int k1_grid, ScanFold fold,
             const unsigned long long* __restrict__ k1_stats /* K1's block_stats [views][k1_grid][3] */) {
+    constexpr int NT = 256 * S;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    uint32_t* next = reinterpret_cast<uint32_t*>(smem_raw);      // [nTiles]: the next free position of this workgroup's range in the tile's list
+    uint32_t* next = reinterpret_cast<uint32_t*>(smem_raw);      // [nTiles]: the next free position of this group's range in the tile's list
     __shared__ uint32_t lev[GSR_NLEV + 1];
-    __shared__ uint32_t red[8];
+    __shared__ uint32_t red[2 * (NT / 64)];
     int bx = (int)blockIdx.x;
     if (fold.on) {
         if (bx == 0) {
             if (blockIdx.y == 0)
-                tile_scan_body<256>(*reinterpret_cast<TileScanLds*>(smem_raw),
-                                    fold.lds_words > nTiles * (int)gridDim.y ? reinterpret_cast<uint32_t*>(smem_raw + ((sizeof(TileScanLds) + 15) & ~(size_t)15)) : nullptr, fold.tile_count, fold.tile_off_w, nTiles * (int)gridDim.y, counters,
-                                    fold.tile_seg_w, seg_shift, fold.block_stats, fold.nblocks, (int)gridDim.y, fold.order_w, fold.order_span,
-                                    fold.level_off_w, fold.host_out, fold.host_words, fold.host_flag);
+                tile_scan_body<NT>(*reinterpret_cast<TileScanLds*>(smem_raw),
+                                   fold.lds_words > nTiles * (int)gridDim.y ? reinterpret_cast<uint32_t*>(smem_raw + ((sizeof(TileScanLds) + 15) & ~(size_t)15)) : nullptr, fold.tile_count, fold.tile_off_w, nTiles * (int)gridDim.y, counters,
+                                   fold.tile_seg_w, seg_shift, fold.block_stats, fold.nblocks, (int)gridDim.y, fold.order_w, fold.order_span,
+                                   fold.level_off_w, fold.host_out, fold.host_words, fold.host_flag);
             return;
         }
         --bx;
     } else if (counters[2] > (unsigned long long)capacity) return;
     // (the scratch may have been sized BEFORE the host knew M -- gsr_forward: previous call + 25 %. M is on the device: every consumer
     // of the lists leaves at once when they do not fit, and the host repeats the tail)
-    // This workgroup's K1 twin gave up waiting for the cleared tile counters (gsr_preprocess_fwd: it reports M_ref >= 2^62 and the host
-    // returns an error): it reserved nothing, its row of wg_base is whatever the scratch held -- nothing may be written from it.
-    if (k1_stats[3 * ((size_t)blockIdx.y * k1_grid + bx)] >= (1ull << 62)) return;
+    // A K1 workgroup of this group gave up waiting for the cleared tile counters (gsr_preprocess_fwd: it reports M_ref >= 2^62 and the
+    // host returns an error): the group reserved nothing, its row of group_base is whatever the scratch held -- nothing may be
+    // written from it.
+    const int ngroups = (k1_grid + S - 1) / S;
+#pragma unroll
+    for (int q = 0; q < S; ++q)
+        if (bx * S + q < k1_grid && k1_stats[3 * ((size_t)blockIdx.y * k1_grid + bx * S + q)] >= (1ull << 62)) return;
     // blockIdx.y = view: its records and its tiles (tile_off holds positions in the one list array of all views)
     emit += (size_t)blockIdx.y * (size_t)N;
-    const uint32_t* __restrict__ base_row = wg_base + ((size_t)blockIdx.y * k1_grid + bx) * nTiles;
+    const uint32_t* __restrict__ base_row = group_base + ((size_t)blockIdx.y * ngroups + bx) * nTiles;
     const int stride = k1_grid * 256;
-    const int first = bx * 256 + threadIdx.x;
+    const int wg = bx * S + ((int)threadIdx.x >> 8);               // the K1 workgroup this slice stands for
+    const int first = wg < k1_grid ? wg * 256 + ((int)threadIdx.x & 255) : N;      // (the last group may be short: its spare slices emit nothing)
     // a thread's first records travel while the ranges are loaded
     uint4 em[GSR_SC_R];
 #pragma unroll
@@ -314,32 +324,34 @@ gsr_scatter(int N, const EmitRec* __restrict__ emit, const uint32_t* __restrict_
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const int before = (int)blockIdx.y * nTiles, all = (int)gridDim.y * nTiles;
         uint32_t s_before = 0, s_after = 0;
-        for (int t = threadIdx.x; t < all; t += 256) {
+        for (int t = threadIdx.x; t < all; t += NT) {
             if (t >= before && t < before + nTiles) continue;
             const uint32_t c = fold.tile_count[t];
             if (t < before) s_before += c; else s_after += c;
         }
-        for (int t = threadIdx.x; t < nTiles; t += 256) next[t] = fold.tile_count[before + t];
+        for (int t = threadIdx.x; t < nTiles; t += NT) next[t] = fold.tile_count[before + t];
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) { s_before += __shfl_xor(s_before, off, 64); s_after += __shfl_xor(s_after, off, 64); }
-        if (lane == 0) { red[wave] = s_before; red[4 + wave] = s_after; }
+        if (lane == 0) { red[wave] = s_before; red[NT / 64 + wave] = s_after; }
         __syncthreads();
-        const uint32_t own = block_excl_scan_lds<256>(next, nTiles, lev);     // (lev: free here -- no items in this mode; 4 words used)
-        const uint32_t lists_before = red[0] + red[1] + red[2] + red[3];
-        const unsigned long long M_all = (unsigned long long)lists_before + own + red[4] + red[5] + red[6] + red[7];
+        const uint32_t own = block_excl_scan_lds<NT>(next, nTiles, lev);     // (lev: free here -- no items in this mode; NT / 64 words used)
+        uint32_t lists_before = 0, lists_after = 0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) { lists_before += red[w]; lists_after += red[NT / 64 + w]; }
+        const unsigned long long M_all = (unsigned long long)lists_before + own + lists_after;
         if (M_all > (unsigned long long)capacity) return;                        // (the scan workgroup tells the host; the tail is repeated)
         if (bx == 0 && blockIdx.y == 0 && threadIdx.x == 0) counters[6] = capacity;
-        for (int t = threadIdx.x; t < nTiles; t += 256) next[t] += lists_before + base_row[t];
+        for (int t = threadIdx.x; t < nTiles; t += NT) next[t] += lists_before + base_row[t];
     } else {
         if (bx == 0 && blockIdx.y == 0 && threadIdx.x == 0) counters[6] = capacity;    // for a backward called without GsrStats
         if (items_cap) write_forward_items(level_off, order, tile_off, tile_seg, seg_shift, items, items_cap, lev);
         tile_off += (size_t)blockIdx.y * nTiles;
-        for (int t0 = threadIdx.x; t0 < nTiles; t0 += 256 * 4) {      // (eight loads in flight per thread; entries of tiles nobody here emits into: never used)
+        for (int t0 = threadIdx.x; t0 < nTiles; t0 += NT * 4) {      // (eight loads in flight per thread; entries of tiles nobody here emits into: never used)
             uint32_t a[4], b[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const int t = min(t0 + 256 * u, nTiles - 1); a[u] = tile_off[t]; b[u] = base_row[t]; }
+            for (int u = 0; u < 4; ++u) { const int t = min(t0 + NT * u, nTiles - 1); a[u] = tile_off[t]; b[u] = base_row[t]; }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) if (t0 + 256 * u < nTiles) next[t0 + 256 * u] = a[u] + b[u];
+            for (int u = 0; u < 4; ++u) if (t0 + NT * u < nTiles) next[t0 + NT * u] = a[u] + b[u];
         }
     }
     lds_barrier();
@@ -366,6 +378,8 @@ gsr_scatter(int N, const EmitRec* __restrict__ emit, const uint32_t* __restrict_
         }
     }
 }
+template __global__ void gsr_scatter<1>(int, const EmitRec*, const uint32_t*, const uint32_t*, unsigned long long*, int, int, uint32_t, unsigned long long*, const uint32_t*, const uint32_t*, const uint32_t*, int, uint4*, uint32_t, int, ScanFold, const unsigned long long*);
+template __global__ void gsr_scatter<4>(int, const EmitRec*, const uint32_t*, const uint32_t*, unsigned long long*, int, int, uint32_t, unsigned long long*, const uint32_t*, const uint32_t*, const uint32_t*, int, uint4*, uint32_t, int, ScanFold, const unsigned long long*);
 
 // Tile grids beyond the LDS histogram (more than 16 384 tiles): one pass, a global cursor per tile.
 extern "C" __global__ void __launch_bounds__(256)

@@ -268,7 +268,10 @@ gsr_preprocess_fwd(ViewTab views /* camera of this workgroup: views.v[blockIdx.y
                    uint8_t* __restrict__ flags8 /* colour-clamp bits for K6: 1 B instead of a 64-B record line */,
                    uint32_t* __restrict__ zero_base /* tile_count | cursor | counters of ALL views: zeroed here, by workgroup (0, 0) */,
                    uint32_t zero_words, uint32_t flag_word /* (even) index in zero_base of the 64-bit "zeroed" flag */, unsigned long long epoch,
-                   uint32_t* __restrict__ wg_base /* [views][grid][nTiles]: where this workgroup's entries start inside each tile's list (LDS-histogram mode) */) {
+                   uint32_t* __restrict__ wg_hist /* [views][grid][nTiles]: this workgroup's tile histogram, for the group-mate that reserves (LDS-histogram mode, groups of more than one) */,
+                   uint32_t* __restrict__ group_base /* [views][groups][nTiles]: where the entries of a GROUP of `group` consecutive workgroups start inside each tile's list */,
+                   int group /* workgroups per group: 1, or what one workgroup of gsr_scatter covers (its block = 256 x group threads) */,
+                   uint32_t* __restrict__ arrive /* [views][2048] inside the zeroed words: how many workgroups of a group have stored their histogram */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_pp[];
     const ViewConst vc = views.v[blockIdx.y];
     // The per-tile counts, the scatter's cursors and the counters start from zero: workgroup (0, 0) -- the first the dispatcher
@@ -628,21 +631,73 @@ gsr_preprocess_fwd(ViewTab views /* camera of this workgroup: views.v[blockIdx.y
             if (threadIdx.x == 0) block_stats[3 * blockIdx.x] = 1ull << 62;
             return;
         }
-        // every workgroup starts its flush at a different tile: no burst of atomics on one address
-        // The flush RESERVES: the value the atomic returns is the number of entries other workgroups have claimed in that tile's list so
-        // far = where this workgroup's entries start. It goes to wg_base; gsr_scatter, on the same grid with the same Gaussians, hands
-        // positions out from there -- no counting pass and no reservation atomics of its own (round 3: one returning atomic per
-        // (workgroup round, tile) in the scatter ON TOP of the ones here).
-        uint32_t* __restrict__ base_row = wg_base + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * nTiles;
-        const int t0 = (int)((blockIdx.x * 67u) % (unsigned)nTiles);
+        // The flush RESERVES: the value the atomic returns is the number of entries others have claimed in that tile's list so far = where
+        // the own entries start; gsr_scatter hands positions out from there -- no counting pass and no reservation atomics of its own.
+        //
+        // GROUPS (round 6). What is reserved is ONE range per tile for `group` consecutive workgroups (the Gaussians ONE workgroup of
+        // gsr_scatter emits: its block is 256 x group threads with one LDS cursor per tile). A range per K1 workgroup meant runs of ~4
+        // keys (32 B) per (workgroup, tile) at 1M Gaussians; the 128-byte line around a run is shared with three other workgroups'
+        // runs which, nine times out of ten, live in ANOTHER XCD's L2 -- every L2 wrote its quarter of the line back on its own
+        // and the scatter's HBM writes were 3.2 x its keys (profiles/r05_*_pmc.txt). A group's run is ~16 keys = a whole line written
+        // by one workgroup through one L2. The workgroups of a group do not wait for each other: each stores its histogram row
+        // (write-through stores), then counts itself in; the one that finds the others already counted reads their rows back
+        // (loads that are not served from its own XCD's L2), adds its own and reserves for all. Four times fewer returning atomics
+        // per tile counter than one reservation per workgroup.
+        const int G = group;
+        const int grp = (int)blockIdx.x / G, gfirst = grp * G;
+        const int gsize = min(G, (int)gridDim.x - gfirst);
+        const int ngroups = ((int)gridDim.x + G - 1) / G;
+        const int pitch = (nTiles + 3) & ~3;                              // words between histogram rows (16-byte stores)
+        if (gsize > 1) {
+            // The hand-off (MI355X guide, inter-workgroup visibility R1): WRITE-THROUGH (sc1) row stores, every storing wave drains its
+            // stores, barrier, ONE lane counts the workgroup in with a relaxed agent-scope atomic; the reader uses sc1 loads. No
+            // release fence: with it (buffer_wbl2: the XCD's L2 writes back every dirty record line first) K1 was 0.104 ms instead
+            // of 0.069 (profiles/r06_group_reservation.txt).
+            __shared__ uint32_t last_s;
+            uint4* __restrict__ my_row = reinterpret_cast<uint4*>(wg_hist + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * pitch);
+            for (int t4 = threadIdx.x; t4 < pitch / 4; t4 += 256) {       // (hist is a multiple of 16 bytes long: the words past nTiles are never read back)
+                typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 v = reinterpret_cast<const u32x4*>(hist)[t4];
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(my_row + t4), "v"(v) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0)
+                last_s = __hip_atomic_fetch_add(arrive + (size_t)blockIdx.y * 2048 + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)(gsize - 1) ? 1u : 0u;
+            __syncthreads();
+            if (!last_s) return;
+        }
+        const uint32_t* __restrict__ rows = wg_hist + ((size_t)blockIdx.y * gridDim.x + gfirst) * pitch;
+        const int own = (int)blockIdx.x - gfirst;
+        uint32_t* __restrict__ base_row = group_base + ((size_t)blockIdx.y * ngroups + grp) * nTiles;
+        // every group starts its flush at a different tile: no burst of atomics on one address
+        const int t0 = (int)(((unsigned)grp * 67u) % (unsigned)nTiles);
         for (int i0 = threadIdx.x; i0 < nTiles; i0 += 256 * 4) {          // four returning atomics in flight per thread
-            int tt[4]; uint32_t cc[4], got[4];
+            int tt[4]; uint32_t cc[4], got[4], oth[4][3];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int i = min(i0 + 256 * u, nTiles - 1);
                 int t = t0 + i; if (t >= nTiles) t -= nTiles;
                 tt[u] = t;
-                cc[u] = i0 + 256 * u < nTiles ? hist[t] : 0u;
+                // the group-mates' counts: agent-scope loads written out by hand (sc1: not served from this XCD's L2) -- the compiler
+                // waits for an atomic load where it issues it, and these are twelve independent requests. Branch-free: a mate the
+                // (short, last) group does not have is read from the own row and dropped.
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int q = k + (k >= own ? 1 : 0);
+                    const uint32_t* p = rows + (size_t)(q < gsize ? q : own) * pitch + t;
+                    asm volatile("global_load_dword %0, %1, off sc1" : "=v"(oth[u][k]) : "v"(p) : "memory");
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(oth[0][0]), "+v"(oth[0][1]), "+v"(oth[0][2]), "+v"(oth[1][0]), "+v"(oth[1][1]), "+v"(oth[1][2]),
+                           "+v"(oth[2][0]), "+v"(oth[2][1]), "+v"(oth[2][2]), "+v"(oth[3][0]), "+v"(oth[3][1]), "+v"(oth[3][2]) :: "memory");
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                uint32_t c = hist[tt[u]];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) c += k + (k >= own ? 1 : 0) < gsize ? oth[u][k] : 0u;
+                cc[u] = i0 + 256 * u < nTiles ? c : 0u;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) { got[u] = 0u; if (cc[u]) got[u] = atomicAdd(&tile_count[tt[u]], cc[u]); }

@@ -34,11 +34,13 @@ def test_hot_kernels_have_no_loads_waited_for_on_the_spot(asm):
         "_Z21gsr_render_fwd_serialILb0E": 1,
         "_Z17gsr_render_bwd_q2": 5,               # later rounds of segments longer than 64 entries: list entry -> records; + round 6: the record's tile
                                                   # rectangle in the flush of the opt-in deterministic mode (GSR_VIEW_DETERMINISTIC)
-        "gsr_scatter": 32,                        # the segment forward's work items (rare path), the tail of the eight-deep fetch of the ranges, the refill of a pinned grid's later rounds: 11;
+        "_Z11gsr_scatterILi": 32,                        # the segment forward's work items (rare path), the tail of the eight-deep fetch of the ranges, the refill of a pinned grid's later rounds: 11;
                                                   # + round 5: K2's body inlined for the launch's ONE scan workgroup (a chain of dependent phases by nature: 17) and the
                                                   # scatter workgroups' own scan of the tile counts (the counts of the other views, the tail of the fetch: 2)
-        "_Z18gsr_preprocess_fwdILb0E": 10,        # camera staging, cov3D_precomp / colors_precomp / degree-0 paths, the two polls of the "counters cleared" tag,
-        "_Z18gsr_preprocess_fwdILb1E": 10,        # the last of the flush's four reserving atomics (their results are what is stored)
+        "_Z18gsr_preprocess_fwdILb0E": 14,        # camera staging, cov3D_precomp / colors_precomp / degree-0 paths, the two polls of the "counters cleared" tag,
+        "_Z18gsr_preprocess_fwdILb1E": 14,        # the last of the flush's four reserving atomics (their results are what is stored); + round 6: the tail of
+                                                  # the twelve-deep fetch of the group-mates' histogram rows (the last three of twelve loads issued together) and the
+                                                  # workgroup's arrival ticket (one returning atomic by one lane)
         "_Z18gsr_preprocess_bwdILb0ELb0E": 14,    # camera staging, the accumulate read-modify-write of views after the first, the
         "_Z18gsr_preprocess_bwdILb1ELb0E": 15,    # row-predicated element loads of the split / odd-row-length staging paths
     }

@@ -697,6 +697,49 @@ def test_scatter_with_several_rounds_per_workgroup(gpu, hooks, N, size):
     assert_grads_close(hg, og, aux, floors=grad_floors(sc, og))
 
 
+@pytest.mark.parametrize("N,size,grid", [(9_000, 160, 0), (9_000, 160, 7), (9_000, 160, 5), (60_000, 256, 0), (300_000, 400, 0)])
+def test_group_reservation_of_the_tile_lists(gpu, hooks, N, size, grid):
+    """Round 6: K1's histogram flush reserves ONE range per tile list for a GROUP of four consecutive workgroups (each stores its
+    histogram row, the last one to arrive adds them up and reserves) and a workgroup of gsr_scatter is four 256-thread slices with
+    one LDS cursor per tile (test hook k1_group pins 1 / 4; the default is 4 from 512 K1 workgroups on). Same lists either way: the
+    images are identical bit for bit (the sort orders a list by (depth, index)), the counters equal, and the oracle agrees -- at the
+    default grid, at grids that leave the last group one / three workgroups short, with the scan folded into the scatter's launch,
+    and (300k: 1 172 batches, two rounds of 586 workgroups) at a size where the grouping is the default."""
+    if grid:
+        hooks.set("k1_grid", grid)
+    sc = O.make_scene(N, 1, 5, "trained")
+    S = O.make_settings(O.orbit_pose(-8.0, 40.0, 2.0), size, size, sh_degree=1)
+    w = weights_for(size, size)
+    outs = {}
+    for G in (1, 4):
+        hooks.set("k1_group", G)
+        for fold in (0, 1):
+            hooks.set("scan_fold", fold)
+            for _ in range(2):                                      # (the second call speculates: the folded scan needs that)
+                ho, hg, st = run_hip(sc, S, gpu, w)
+            outs[(G, fold)] = (ho, hg, st)
+    base = outs[(1, 0)]
+    for key, (ho, hg, st) in outs.items():
+        for i in range(4):
+            assert torch.equal(ho[i], base[0][i]), (key, i)
+        assert st["M"] == base[2]["M"] and st["V"] == base[2]["V"] and st["max_tile"] == base[2]["max_tile"], key
+    # the hand-off between the workgroups of a group is a race the hardware decides anew in every launch: forty more forwards (who
+    # arrives last, on which XCD, changes from launch to launch), every image word compared
+    hooks.set("k1_group", 4)
+    for rep in range(40):
+        hooks.set("scan_fold", rep & 1)
+        ho, hg, st = run_hip(sc, S, gpu, w if rep % 8 == 0 else None)
+        for i in range(4):
+            assert torch.equal(ho[i], base[0][i]), (rep, i)
+        assert st["M"] == base[2]["M"], rep
+    if N <= 60_000:
+        oo, og, aux = run_oracle(sc, S, w, torch.float64)
+        ho, hg, st = outs[(4, 1)]
+        util.assert_counts_explained(st, aux)
+        assert_forward_close(ho, oo, aux)
+        assert_grads_close(hg, og, aux, floors=grad_floors(sc, og))
+
+
 def test_debug_flag_synchronises_and_reports_the_failing_kernel(gpu):
     """`GaussianRasterizationSettings.debug=True` (the reference passes its `opt.debug` through, gs_renderer.py:757): every launch is
     followed by a stream synchronise + error check (gsr_api.hip launch_status), so a failing kernel is named in the exception

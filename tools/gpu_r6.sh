@@ -47,6 +47,16 @@ reduce)
   for wl in 250k-512-sh0 1M-800-sh3; do for m in "--reduce dense" "--reduce dense --sds-adam" "--reduce sharded" "--reduce live" "--reduce live --sds-adam"; do
     echo "== sds local $wl $m"; timeout 300 python bench.py --step sds --sds-mode local --sds-workload $wl $m --force-collectives --cpu-budget 0 --steps 40 --warmup 10 2>>gpurun_out/sds_reduce.err | grep -a "^{" | tee -a gpurun_out/sds_reduce.jsonl | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], 'ms', d['config'].get('reduce'), d['config'].get('live_rows'))"
   done; done;;
+group)
+  # K1's group reservation + the four-slice scatter: the tests, then a same-process-order A/B of the hook (k1_group = 1 / 4)
+  timeout 900 python -m pytest tests/test_parity_gpu.py -m gpu -q -x -p no:cacheprovider --tb=short -rf -k "group_reservation or scatter_with_several or speculative or multi_view or views" > gpurun_out/pytest_group.log 2>&1
+  grep -a "passed\|failed\|FAILED\|Error\|assert" gpurun_out/pytest_group.log | cut -c1-300 | tail -20
+  for rep in 1 2; do for wl in ${GROUP_WL:-1M-800-sh3 1M-800-sh3:trained 250k-512-sh0 100k-800-sh3}; do
+    kind=blob; [ "${wl#*:}" != "$wl" ] && kind=${wl#*:}
+    for g in 1 4; do
+      echo "== k1_group=$g $wl"; timeout 300 python bench.py --workload ${wl%%:*} --kind $kind --hook k1_group=$g --cpu-budget 0 --steps 60 --warmup 10 2>>gpurun_out/group_err.log | tee -a gpurun_out/group_ab.jsonl | line
+    done
+  done; done;;
 *) bash tools/gpu_r5.sh $sec;;
 esac
 done
