@@ -154,9 +154,9 @@ int once_per_device(F fn) {
 // A/B measurement through an explicit call. Nothing here is read from the process environment: two of them (forward mode, segment
 // length) decide where the per-pixel sums are cut, i.e. the rounding of the results, and that must not depend on who started the
 // process. -1 = the library decides.
-enum { OV_FWD_MODE, OV_SEG_SHIFT, OV_FWD_LISTS, OV_FWD_HINTS, OV_SPECULATE, OV_HIST_MAX, OV_K1_GRID, OV_FWD_GRID, OV_K6_GRID, OV_FWD_LDS_KB, OV_BWD_GRID, OV_K6_COMPACT, OV_SCAN_FOLD, OV_GRAD_CLEAR, OV_K1_GROUP, OV_COUNT };
-const char* const kOvNames[OV_COUNT] = {"fwd_mode", "seg_shift", "fwd_lists", "fwd_hints", "speculate", "hist_max", "k1_grid", "fwd_grid", "k6_grid", "fwd_lds_kb", "bwd_grid", "k6_compact", "scan_fold", "grad_clear", "k1_group"};
-std::atomic<int> g_ov[OV_COUNT] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
+enum { OV_FWD_MODE, OV_SEG_SHIFT, OV_FWD_LISTS, OV_FWD_HINTS, OV_SPECULATE, OV_HIST_MAX, OV_K1_GRID, OV_FWD_GRID, OV_K6_GRID, OV_FWD_LDS_KB, OV_BWD_GRID, OV_K6_COMPACT, OV_SCAN_FOLD, OV_GRAD_CLEAR, OV_K1_GROUP, OV_SORT_GRID, OV_COUNT };
+const char* const kOvNames[OV_COUNT] = {"fwd_mode", "seg_shift", "fwd_lists", "fwd_hints", "speculate", "hist_max", "k1_grid", "fwd_grid", "k6_grid", "fwd_lds_kb", "bwd_grid", "k6_compact", "scan_fold", "grad_clear", "k1_group", "sort_grid"};
+std::atomic<int> g_ov[OV_COUNT] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
 inline int ov(int k) { return g_ov[k].load(std::memory_order_relaxed); }
 
 // K1's grid (a persistent grid: every workgroup walks the same number of 256-Gaussian batches; test hook "k1_grid" pins it). The
@@ -576,10 +576,10 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
         LAUNCH_CHECK(view, stream, "scatter");
         // per-tile sort, size classes by list length
         constexpr size_t lds_s = 2048 * 8 + (512 + 1 + 512 + 40) * 4;
-        constexpr size_t lds_m = 8192 * 8 + (2048 + 1 + 2048 + 40) * 4;
+        constexpr size_t lds_m = 8192 * 8 + (1920 + 1 + 1920 + 40) * 4;     // 81 060 B: TWO workgroups per CU (2 048 buckets: 82 084 B, 328 B too many for the second)
         constexpr size_t lds_l = 16384 * 8 + (2048 + 1 + 2048 + 40) * 4;
         if (int rc = once_per_device([]() -> hipError_t {   // > 64 KiB of dynamic LDS is an opt-in per device
-                hipError_t e = hipFuncSetAttribute((const void*)gsr_tile_sort_bucket<8192, 1024, 2048>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m);
+                hipError_t e = hipFuncSetAttribute((const void*)gsr_tile_sort_bucket<8192, 1024, 1920>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m);
                 if (e != hipSuccess) return e;
                 return hipFuncSetAttribute((const void*)gsr_tile_sort_bucket<16384, 1024, 2048>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l);
             })) return rc;
@@ -587,19 +587,22 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
         // list up to 8 192 (a short list then runs on its first waves): the two launches were latency chains of their own, one
         // behind the other -- 12 + 32 us at 1M Gaussians against 32 for the merged one (44 -> 33 us with the third class).
         if (maxc <= 2048) {
-            prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<2048, 256, 512>), dim3(TA), dim3(256), lds_s, stream, tile_off, entries, sorted_ids, 0u, 2048u, counters, (uint32_t)M, (const uint2*)(gbuf + GL.order_span));
+            prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<2048, 256, 512>), dim3(TA), dim3(256), lds_s, stream, tile_off, entries, sorted_ids, 0u, 2048u, counters, (uint32_t)M, (const uint2*)(gbuf + GL.order_span), (uint32_t)TA);
             LAUNCH_CHECK(view, stream, "tile_sort_small");
         } else {
-            prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<8192, 1024, 2048>), dim3(TA), dim3(1024), lds_m, stream, tile_off, entries, sorted_ids, 0u, 8192u, counters, (uint32_t)M, (const uint2*)(gbuf + GL.order_span));
+            prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<8192, 1024, 1920>), dim3(TA), dim3(1024), lds_m, stream, tile_off, entries, sorted_ids, 0u, 8192u, counters, (uint32_t)M, (const uint2*)(gbuf + GL.order_span), (uint32_t)TA);
             LAUNCH_CHECK(view, stream, "tile_sort_medium");
         }
-        // The tiles come longest list first (order_span), so the lists of more than L entries sit at the first <= M / (L + 1) positions:
-        // the launch of the 16 384 class is that small (M here is the capacity the lists were laid out for: more instances than that and every kernel
-        // leaves; the speculative forward launches the 16 384 class whenever the
-        // previous frame's longest list x 1.25 exceeds 8 192 -- 2 500 workgroups of 128 KiB that all leave at once cost 5-7 us at 1M).
-        const unsigned grid_l = (unsigned)((unsigned long long)TA < M / 8193ull + 1ull ? (unsigned long long)TA : M / 8193ull + 1ull);
+        // The tiles come longest list first (order_span), so the lists of more than L entries sit at the first <= M / (L + 1) positions
+        // (M here is the capacity the lists were laid out for: more instances than that and every kernel leaves). The 16 384 class
+        // holds ONE workgroup per CU (128 KiB of LDS) and the speculative forward launches it whenever the previous frame's longest
+        // list x 1.25 exceeds 8 192, i.e. mostly for nothing: its grid is at most one workgroup per CU, each walks the positions
+        // blockIdx.x, + grid, ... until the lists get too short for the class.
+        const unsigned long long bound_l = (unsigned long long)TA < M / 8193ull + 1ull ? (unsigned long long)TA : M / 8193ull + 1ull;
+        const unsigned long long cap_l = ov(OV_SORT_GRID) > 0 ? (unsigned long long)ov(OV_SORT_GRID) : 256ull;      // (test hook "sort_grid": the walk with fewer workgroups than long lists)
+        const unsigned grid_l = (unsigned)(bound_l < cap_l ? bound_l : cap_l);
         if (maxc > 8192) {
-            prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<16384, 1024, 2048>), dim3(grid_l), dim3(1024), lds_l, stream, tile_off, entries, sorted_ids, 8192u, 16384u, counters, (uint32_t)M, (const uint2*)(gbuf + GL.order_span));
+            prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<16384, 1024, 2048>), dim3(grid_l), dim3(1024), lds_l, stream, tile_off, entries, sorted_ids, 8192u, 16384u, counters, (uint32_t)M, (const uint2*)(gbuf + GL.order_span), (uint32_t)TA);
             LAUNCH_CHECK(view, stream, "tile_sort_large");
         }
         if (maxc > 16384) {

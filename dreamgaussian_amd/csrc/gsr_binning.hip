@@ -479,22 +479,8 @@ __device__ __forceinline__ void block_excl_scan_u32(uint32_t* a, int n, uint32_t
 }
 
 template <int CAP, int NT, int NBMAX>
-__global__ void __launch_bounds__(NT)
-gsr_tile_sort_bucket(const uint32_t* __restrict__ tile_off, const unsigned long long* __restrict__ entries,
-                     uint32_t* __restrict__ out_ids, uint32_t lo_excl, uint32_t hi_incl,
-                     const unsigned long long* __restrict__ counters, uint32_t capacity,
-                     const uint2* __restrict__ order_span /* (list start, length) of the tiles, longest lists first (gsr_tile_scan) */) {
-    if (counters[2] > (unsigned long long)capacity) return;            // lists do not fit the scratch (see gsr_scatter)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem_raw);
-    uint32_t* off = reinterpret_cast<uint32_t*>(smem_raw + (size_t)CAP * 8);
-    uint32_t* cur = off + (NBMAX + 1);
-    uint32_t* red = cur + NBMAX;                       // [0..15] wave partials, [32] min, [33] max, [34] max bucket
-    // longest lists first: a tile is a latency chain of its own (eight barriers), and with two 80 KiB workgroups per CU the
-    // launch is two rounds deep -- the long chains start in the first, the short ones fill in behind them
-    const uint2 span = order_span[blockIdx.x];
-    const uint32_t s = span.x, n = span.y;
-    if (n <= lo_excl || n > hi_incl) return;
+__device__ __forceinline__ void sort_one_tile(unsigned long long* keys, uint32_t* off, uint32_t* cur, uint32_t* red,
+                                              const unsigned long long* __restrict__ entries, uint32_t* __restrict__ out_ids, uint32_t s, uint32_t n) {
     const unsigned long long* __restrict__ src = entries + s;
     const int lane = threadIdx.x & 63;
     constexpr int PER = CAP / NT;                      // entries per thread: ONE pass over HBM, the keys stay in registers
@@ -581,6 +567,40 @@ gsr_tile_sort_bucket(const uint32_t* __restrict__ tile_off, const unsigned long 
     for (uint32_t i = threadIdx.x; i < n; i += NT) out_ids[s + i] = (uint32_t)keys[i];
 }
 
+template <int CAP, int NT, int NBMAX>
+__global__ void __launch_bounds__(NT, CAP == 8192 ? 2 : 1)     // the 8 192 class: two 1 024-thread workgroups per CU (<= 64 VGPRs, 2 x 81 060 B of LDS)
+gsr_tile_sort_bucket(const uint32_t* __restrict__ tile_off, const unsigned long long* __restrict__ entries,
+                     uint32_t* __restrict__ out_ids, uint32_t lo_excl, uint32_t hi_incl,
+                     const unsigned long long* __restrict__ counters, uint32_t capacity,
+                     const uint2* __restrict__ order_span /* (list start, length) of the tiles, longest lists first (gsr_tile_scan) */,
+                     uint32_t ntiles /* entries of order_span */) {
+    if (counters[2] > (unsigned long long)capacity) return;            // lists do not fit the scratch (see gsr_scatter)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem_raw);
+    uint32_t* off = reinterpret_cast<uint32_t*>(smem_raw + (size_t)CAP * 8);
+    uint32_t* cur = off + (NBMAX + 1);
+    uint32_t* red = cur + NBMAX;                       // [0..15] wave partials, [32] min, [33] max, [34] max bucket
+    // longest lists first: a tile is a latency chain of its own (eight barriers), and with two 80 KiB workgroups per CU the
+    // launch is two rounds deep -- the long chains start in the first, the short ones fill in behind them.
+    // The grid may be smaller than the number of tiles (the 16 384 class: <= one workgroup per CU, launched on a PREDICTION that a
+    // list longer than 8 192 exists -- 380 workgroups of 128 KiB that all leave at once were 4.9 us of every step at 1M Gaussians):
+    // a workgroup walks positions blockIdx.x, + gridDim.x, ... and stops at the first list too short for its class (the order is
+    // by ceil(n / 2^seg_shift) descending and 8 192 is a multiple of every 2^seg_shift: no longer list follows a shorter class).
+    if constexpr (CAP > 8192) {
+        for (uint32_t pos = blockIdx.x; pos < ntiles; pos += gridDim.x) {
+            const uint2 span = order_span[pos];
+            const uint32_t s = span.x, n = span.y;
+            if (n <= lo_excl) return;
+            if (n <= hi_incl) sort_one_tile<CAP, NT, NBMAX>(keys, off, cur, red, entries, out_ids, s, n);
+            if (pos + gridDim.x < ntiles) __syncthreads();             // (block-uniform) the LDS arrays are reused
+        }
+    } else {                                                           // one tile per workgroup (the loop costs the compiler 18 VGPRs)
+        const uint2 span = order_span[blockIdx.x];
+        if (span.y <= lo_excl || span.y > hi_incl) return;
+        sort_one_tile<CAP, NT, NBMAX>(keys, off, cur, red, entries, out_ids, span.x, span.y);
+    }
+}
+
 // lists longer than the largest LDS class: network in place in HBM, then the same outputs
 extern "C" __global__ void __launch_bounds__(1024)
 gsr_tile_sort_global_ids(const uint32_t* __restrict__ tile_off, unsigned long long* __restrict__ entries,
@@ -594,6 +614,6 @@ gsr_tile_sort_global_ids(const uint32_t* __restrict__ tile_off, unsigned long lo
     for (uint32_t i = threadIdx.x; i < n; i += 1024) out_ids[s + i] = (uint32_t)entries[s + i];
 }
 
-template __global__ void gsr_tile_sort_bucket<2048, 256, 512>(const uint32_t*, const unsigned long long*, uint32_t*, uint32_t, uint32_t, const unsigned long long*, uint32_t, const uint2*);
-template __global__ void gsr_tile_sort_bucket<8192, 1024, 2048>(const uint32_t*, const unsigned long long*, uint32_t*, uint32_t, uint32_t, const unsigned long long*, uint32_t, const uint2*);
-template __global__ void gsr_tile_sort_bucket<16384, 1024, 2048>(const uint32_t*, const unsigned long long*, uint32_t*, uint32_t, uint32_t, const unsigned long long*, uint32_t, const uint2*);
+template __global__ void gsr_tile_sort_bucket<2048, 256, 512>(const uint32_t*, const unsigned long long*, uint32_t*, uint32_t, uint32_t, const unsigned long long*, uint32_t, const uint2*, uint32_t);
+template __global__ void gsr_tile_sort_bucket<8192, 1024, 1920>(const uint32_t*, const unsigned long long*, uint32_t*, uint32_t, uint32_t, const unsigned long long*, uint32_t, const uint2*, uint32_t);
+template __global__ void gsr_tile_sort_bucket<16384, 1024, 2048>(const uint32_t*, const unsigned long long*, uint32_t*, uint32_t, uint32_t, const unsigned long long*, uint32_t, const uint2*, uint32_t);

@@ -140,7 +140,7 @@ def _cluster_scene(N, spread, offset, ties, seed=0):
                          [(6000, 0.2, 0.0, True, 2048, 8192), (12000, 0.15, 0.229, False, 8192, 16384),
                           (12000, 0.15, 0.229, True, 8192, 16384), (20000, 0.15, 0.229, True, 16384, 10 ** 9)],
                          ids=["medium_ties", "large_bucket", "large_ties", "global_ties"])
-def test_depth_ties_and_heavy_tile(gpu, N, spread, offset, ties, lo, hi):
+def test_depth_ties_and_heavy_tile(gpu, hooks, N, spread, offset, ties, lo, hi):
     """Many coincident-depth Gaussians in one tile (stable tie order) and tile lists in every size class
     of the sort, including the > 16384-entry fallback that sorts in HBM."""
     W = H = 64
@@ -152,6 +152,17 @@ def test_depth_ties_and_heavy_tile(gpu, N, spread, offset, ties, lo, hi):
     oo, og, aux = run_oracle(sc, S, w, torch.float64)
     assert_forward_close(ho, oo, aux)
     assert_grads_close(hg, og, aux, floors=grad_floors(sc, og))
+    if lo == 8192:
+        # the 16 384 class on ONE workgroup (test hook sort_grid): it walks every list of the class, one after the other -- same bits
+        # (with the cluster spread over four tiles: several lists in the class)
+        sc4 = _cluster_scene(20000, spread, 0.0, ties)
+        base4, _, st4 = run_hip(sc4, S, gpu, w)
+        assert 8192 < st4["max_tile"] <= 16384, st4
+        hooks.set("sort_grid", 1)
+        for _ in range(2):
+            h1, _, st1 = run_hip(sc4, S, gpu, w)
+            for i in range(4):
+                assert torch.equal(h1[i], base4[i]), i
 
 
 def test_backward_without_forward_stats(gpu, monkeypatch):

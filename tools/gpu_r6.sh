@@ -49,7 +49,7 @@ reduce)
   done; done;;
 group)
   # K1's group reservation + the four-slice scatter: the tests, then a same-process-order A/B of the hook (k1_group = 1 / 4)
-  timeout 900 python -m pytest tests/test_parity_gpu.py -m gpu -q -x -p no:cacheprovider --tb=short -rf -k "group_reservation or scatter_with_several or speculative or multi_view or views" > gpurun_out/pytest_group.log 2>&1
+  timeout 900 python -m pytest tests/test_parity_gpu.py -m gpu -q -x -p no:cacheprovider --tb=short -rf -k "${GROUP_K:-group_reservation or scatter_with_several or speculative or heavy_tile}" > gpurun_out/pytest_group.log 2>&1
   grep -a "passed\|failed\|FAILED\|Error\|assert" gpurun_out/pytest_group.log | cut -c1-300 | tail -20
   for rep in 1 2; do for wl in ${GROUP_WL:-1M-800-sh3 1M-800-sh3:trained 250k-512-sh0 100k-800-sh3}; do
     kind=blob; [ "${wl#*:}" != "$wl" ] && kind=${wl#*:}
