@@ -12,7 +12,7 @@ import contextlib
 
 from . import _lib
 
-NAMES = ("fwd_mode", "seg_shift", "fwd_lists", "fwd_hints", "speculate", "hist_max", "k1_grid", "fwd_grid", "k6_grid", "fwd_lds_kb", "bwd_grid", "k6_compact", "scan_fold", "grad_clear", "k1_group", "sort_grid")
+NAMES = ("fwd_mode", "seg_shift", "fwd_lists", "fwd_hints", "speculate", "hist_max", "k1_grid", "fwd_grid", "k6_grid", "fwd_lds_kb", "bwd_grid", "k6_compact", "scan_fold", "grad_clear", "k1_group", "sort_kernel")
 _WORDS = {"fwd_mode": {"seq": 1, "seg": 2, "pair": 3}, "fwd_lists": {"block": 1, "q": 2, "quad": 2}, "fwd_hints": {"off": 1, "skipall": 2}}
 _current = {}
 

@@ -154,8 +154,8 @@ int once_per_device(F fn) {
 // A/B measurement through an explicit call. Nothing here is read from the process environment: two of them (forward mode, segment
 // length) decide where the per-pixel sums are cut, i.e. the rounding of the results, and that must not depend on who started the
 // process. -1 = the library decides.
-enum { OV_FWD_MODE, OV_SEG_SHIFT, OV_FWD_LISTS, OV_FWD_HINTS, OV_SPECULATE, OV_HIST_MAX, OV_K1_GRID, OV_FWD_GRID, OV_K6_GRID, OV_FWD_LDS_KB, OV_BWD_GRID, OV_K6_COMPACT, OV_SCAN_FOLD, OV_GRAD_CLEAR, OV_K1_GROUP, OV_SORT_GRID, OV_COUNT };
-const char* const kOvNames[OV_COUNT] = {"fwd_mode", "seg_shift", "fwd_lists", "fwd_hints", "speculate", "hist_max", "k1_grid", "fwd_grid", "k6_grid", "fwd_lds_kb", "bwd_grid", "k6_compact", "scan_fold", "grad_clear", "k1_group", "sort_grid"};
+enum { OV_FWD_MODE, OV_SEG_SHIFT, OV_FWD_LISTS, OV_FWD_HINTS, OV_SPECULATE, OV_HIST_MAX, OV_K1_GRID, OV_FWD_GRID, OV_K6_GRID, OV_FWD_LDS_KB, OV_BWD_GRID, OV_K6_COMPACT, OV_SCAN_FOLD, OV_GRAD_CLEAR, OV_K1_GROUP, OV_SORT_KERNEL, OV_COUNT };
+const char* const kOvNames[OV_COUNT] = {"fwd_mode", "seg_shift", "fwd_lists", "fwd_hints", "speculate", "hist_max", "k1_grid", "fwd_grid", "k6_grid", "fwd_lds_kb", "bwd_grid", "k6_compact", "scan_fold", "grad_clear", "k1_group", "sort_kernel"};
 std::atomic<int> g_ov[OV_COUNT] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
 inline int ov(int k) { return g_ov[k].load(std::memory_order_relaxed); }
 
@@ -485,7 +485,10 @@ int begin_impl(const GsrView* views, int B, int32_t N, int32_t K,
     return 0;
 }
 
-int sort_class(unsigned long long maxc) { return maxc <= 2048 ? 0 : (maxc <= 8192 ? 1 : (maxc <= 16384 ? 2 : 3)); }
+// The per-tile sort takes a list of any length in either of its two kernels (a list beyond the LDS buffer is streamed through it): the
+// predicted longest list only picks the faster kernel, it can no longer be WRONG (rounds 2-5: a frame whose longest list outgrew the
+// predicted class repeated binning, sort and compositing).
+int sort_class(unsigned long long) { return 0; }
 
 // Whether the per-Gaussian backward of this problem visits the live Gaussians only (gsr_preprocess_bwd_compact, backward_impl) -- and
 // with it whether somebody has to clear the gradient arrays on the side. Known from the problem's shape: the forward asks too.
@@ -524,7 +527,7 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
     const int hist_in_lds = T <= hist_lds_max_tiles();
     const unsigned long long M = cap;
     if (M >= 0xfffffff0ull) return fail(-5, "too many tile instances (%s%lld)", "", (long long)M);
-    const uint32_t maxc_cap = maxc >= 0xffffffffull ? 0xffffffffu : (uint32_t)maxc;
+    const uint32_t maxc_cap = 0xffffffffu;              // (the sort takes lists of any length: the compositing kernels no longer leave on a longer one than predicted)
 
     const bool sequential = fwd_sequential_for(N, T);
     // GSR_VIEW_NO_BACKWARD + the serial walk: no checkpoints, no quad masks, no records in the scratch (the segmented mode composites
@@ -574,40 +577,22 @@ int finish_impl(const GsrView* views, int B, int32_t N, float* out_color, float*
                                vc.gx, T, (uint32_t)M, counters, level_off, order, tile_seg, shift, items, items_cap);
         }
         LAUNCH_CHECK(view, stream, "scatter");
-        // per-tile sort, size classes by list length
+        // per-tile sort: ONE launch. Lists of up to 2 048 entries sort on 256 threads; when longer ones exist the 1 024-thread kernel takes
+        // every list (a short one runs on its first waves; one beyond its 8 192-key LDS buffer streams its keys through it in portions:
+        // gsr_binning.hip sort_long_tile). Rounds 1-5 had size classes in launches of their own: latency chains one behind the other --
+        // 12 + 32 us at 1M Gaussians against 32 for the merged one -- and a 16 384 class that was launched whenever the previous
+        // frame's longest list x 1.25 exceeded 8 192: 4.9 us of every step at the headline scene for a launch that found nothing.
         constexpr size_t lds_s = 2048 * 8 + (512 + 1 + 512 + 40) * 4;
         constexpr size_t lds_m = 8192 * 8 + (1920 + 1 + 1920 + 40) * 4;     // 81 060 B: TWO workgroups per CU (2 048 buckets: 82 084 B, 328 B too many for the second)
-        constexpr size_t lds_l = 16384 * 8 + (2048 + 1 + 2048 + 40) * 4;
         if (int rc = once_per_device([]() -> hipError_t {   // > 64 KiB of dynamic LDS is an opt-in per device
-                hipError_t e = hipFuncSetAttribute((const void*)gsr_tile_sort_bucket<8192, 1024, 1920>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m);
-                if (e != hipSuccess) return e;
-                return hipFuncSetAttribute((const void*)gsr_tile_sort_bucket<16384, 1024, 2048>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l);
+                return hipFuncSetAttribute((const void*)gsr_tile_sort_bucket<8192, 1024, 1920>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m);
             })) return rc;
-        // Lists of up to 2 048 entries sort on 256 threads; when longer ones exist ONE launch of the 1 024-thread kernel takes every
-        // list up to 8 192 (a short list then runs on its first waves): the two launches were latency chains of their own, one
-        // behind the other -- 12 + 32 us at 1M Gaussians against 32 for the merged one (44 -> 33 us with the third class).
-        if (maxc <= 2048) {
-            prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<2048, 256, 512>), dim3(TA), dim3(256), lds_s, stream, tile_off, entries, sorted_ids, 0u, 2048u, counters, (uint32_t)M, (const uint2*)(gbuf + GL.order_span), (uint32_t)TA);
+        if (ov(OV_SORT_KERNEL) == 1 || (ov(OV_SORT_KERNEL) != 2 && maxc <= 2048)) {       // (test hook "sort_kernel": 1 / 2 = the 256- / 1 024-thread kernel whatever the lists)
+            prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<2048, 256, 512>), dim3(TA), dim3(256), lds_s, stream, tile_off, entries, sorted_ids, 0u, 0xffffffffu, counters, (uint32_t)M, (const uint2*)(gbuf + GL.order_span), (uint32_t)TA);
             LAUNCH_CHECK(view, stream, "tile_sort_small");
         } else {
-            prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<8192, 1024, 1920>), dim3(TA), dim3(1024), lds_m, stream, tile_off, entries, sorted_ids, 0u, 8192u, counters, (uint32_t)M, (const uint2*)(gbuf + GL.order_span), (uint32_t)TA);
-            LAUNCH_CHECK(view, stream, "tile_sort_medium");
-        }
-        // The tiles come longest list first (order_span), so the lists of more than L entries sit at the first <= M / (L + 1) positions
-        // (M here is the capacity the lists were laid out for: more instances than that and every kernel leaves). The 16 384 class
-        // holds ONE workgroup per CU (128 KiB of LDS) and the speculative forward launches it whenever the previous frame's longest
-        // list x 1.25 exceeds 8 192, i.e. mostly for nothing: its grid is at most one workgroup per CU, each walks the positions
-        // blockIdx.x, + grid, ... until the lists get too short for the class.
-        const unsigned long long bound_l = (unsigned long long)TA < M / 8193ull + 1ull ? (unsigned long long)TA : M / 8193ull + 1ull;
-        const unsigned long long cap_l = ov(OV_SORT_GRID) > 0 ? (unsigned long long)ov(OV_SORT_GRID) : 256ull;      // (test hook "sort_grid": the walk with fewer workgroups than long lists)
-        const unsigned grid_l = (unsigned)(bound_l < cap_l ? bound_l : cap_l);
-        if (maxc > 8192) {
-            prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<16384, 1024, 2048>), dim3(grid_l), dim3(1024), lds_l, stream, tile_off, entries, sorted_ids, 8192u, 16384u, counters, (uint32_t)M, (const uint2*)(gbuf + GL.order_span), (uint32_t)TA);
-            LAUNCH_CHECK(view, stream, "tile_sort_large");
-        }
-        if (maxc > 16384) {
-            prof_begin(stream); hipLaunchKernelGGL(gsr_tile_sort_global_ids, dim3(TA), dim3(1024), 0, stream, tile_off, entries, sorted_ids, 16384u, counters, (uint32_t)M);
-            LAUNCH_CHECK(view, stream, "tile_sort_global");
+            prof_begin(stream); hipLaunchKernelGGL((gsr_tile_sort_bucket<8192, 1024, 1920>), dim3(TA), dim3(1024), lds_m, stream, tile_off, entries, sorted_ids, 0u, 0xffffffffu, counters, (uint32_t)M, (const uint2*)(gbuf + GL.order_span), (uint32_t)TA);
+            LAUNCH_CHECK(view, stream, "tile_sort");
         }
     }
     // Quad lists pay when splats are small against an 8x8 block (few of its 64 lanes blend a given Gaussian): the scene
@@ -825,7 +810,7 @@ int forward_impl(const GsrView* views, int B, int32_t N, int32_t K,
     if (spec) {
         cap = async ? g_hint.M_hi + g_hint.M_hi / 2 + 4096 : g_hint.M + g_hint.M / 4 + 4096;
         const unsigned long long c = async ? g_hint.maxc_hi + g_hint.maxc_hi / 2 + 64 : g_hint.maxc + g_hint.maxc / 4 + 64;
-        capc = c <= 2048 ? 2048 : (c <= 8192 ? 8192 : (c <= 16384 ? 16384 : ~0ull));
+        capc = c <= 2048 ? 2048 : ~0ull;                      // (which of the two sort kernels; the compositing kernels take lists of any length)
         rc = finish_impl(views, B, N, out_color, out_depth, out_alpha, gbuf, ibuf, bin, shift, g_hint.per_view, cap, capc, prepare, fold, 8 + 2 * B, stream, side, async);
         if (rc && fold) {                                 // K2 never ran: nothing will ever arrive in the pinned block
             (void)hipStreamSynchronize(stream);

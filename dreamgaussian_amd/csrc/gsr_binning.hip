@@ -9,7 +9,7 @@
 // tile segments through an LDS-privatised cursor reservation (one returning global atomic per
 // (workgroup,tile) instead of one per instance); K4 sorts each segment inside LDS (counting pass
 // into ~n/4 depth buckets + rank inside each bucket on the 64-bit key; rank sort for lists of <= 256;
-// bitonic network as the skew fallback; up to 16384 entries = 128 KiB of the CU's 160 KiB) and writes the tile's sorted
+// bitonic network as the skew fallback; a list longer than the 8 192-key buffer is streamed through it in depth-ordered portions) and writes the tile's sorted
 // list of Gaussian INDICES; the compositing kernels gather the 64-byte records themselves.
 #include "gsr_device.h"
 
@@ -567,10 +567,80 @@ __device__ __forceinline__ void sort_one_tile(unsigned long long* keys, uint32_t
     for (uint32_t i = threadIdx.x; i < n; i += NT) out_ids[s + i] = (uint32_t)keys[i];
 }
 
+// A list LONGER than the class's LDS buffer (round 6; was: a 16 384-entry class of its own -- one workgroup per CU, launched on a
+// prediction and mostly for nothing, 4.9 us of every step at 1M Gaussians, 27 us BEHIND the main launch where such lists exist -- and
+// beyond that a bitonic network in HBM). Same bucket sort, with the keys streamed from the list (an L2-resident re-read) instead of
+// held in registers: minimum / maximum, histogram over n / 4 depth buckets (<= NBMAX), scan; then the buckets go through LDS in
+// depth-ordered PORTIONS of at most CAP keys -- stream the list, keep the portion's keys, rank inside the bucket, store the indices.
+// Any length; two or three portions for the lists the 16 384 class took. Skewed depths (a bucket of more than kLongBucketLimit keys):
+// the network, in place in the list (global memory, the workgroup's own L1: the barriers between its passes order it).
+constexpr uint32_t kLongBucketLimit = 512;       // (a portion must hold a whole bucket: <= the smallest CAP; the rank loop is as long as the bucket)
+template <int CAP, int NT, int NBMAX>
+__device__ __forceinline__ void sort_long_tile(unsigned long long* keys, uint32_t* off, uint32_t* cur, uint32_t* red,
+                                               unsigned long long* __restrict__ list /* entries + s: may be sorted in place */,
+                                               uint32_t* __restrict__ out /* out_ids + s */, uint32_t n) {
+    const int lane = threadIdx.x & 63;
+    uint32_t mn = 0xffffffffu, mx = 0u;
+    for (uint32_t i = threadIdx.x; i < n; i += NT) { const uint32_t d = (uint32_t)(list[i] >> 32); mn = min(mn, d); mx = max(mx, d); }
+    mx = wave_max_u32(mx);
+    mn = ~wave_max_u32(~mn);
+    if (threadIdx.x == 0) { red[32] = 0xffffffffu; red[33] = 0u; red[34] = 0u; }
+    __syncthreads();
+    if (lane == 0) { atomicMin(&red[32], mn); atomicMax(&red[33], mx); }
+    __syncthreads();
+    const float fmin = __uint_as_float(red[32]), fmax = __uint_as_float(red[33]);
+    const int NB = min(NBMAX, (int)(n >> 2));
+    const float range = fmax - fmin;
+    const float scale = range > 0.f ? (float)NB / range : 0.f;
+    auto bucket_of = [&](unsigned long long k) -> int { return min((int)((__uint_as_float((uint32_t)(k >> 32)) - fmin) * scale), NB - 1); };
+    for (int b = threadIdx.x; b <= NB; b += NT) off[b] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += NT) atomicAdd(&off[bucket_of(list[i])], 1u);
+    __syncthreads();
+    uint32_t m = 0;
+    for (int b = threadIdx.x; b < NB; b += NT) m = max(m, off[b]);
+    m = wave_max_u32(m);
+    if (lane == 0) atomicMax(&red[34], m);
+    __syncthreads();
+    if (red[34] > kLongBucketLimit) {                     // (block-uniform)
+        bitonic_sort(list, n, NT);
+        for (uint32_t i = threadIdx.x; i < n; i += NT) out[i] = (uint32_t)list[i];
+        return;
+    }
+    __syncthreads();                                      // (red[34] has been read by everyone: the scan reuses red)
+    block_excl_scan_u32<NT>(off, NB + 1, red);            // off[b] = where bucket b starts in the sorted list, off[NB] = n
+    int lo = 0;
+    while (lo < NB) {                                     // (block-uniform) buckets [lo, hi): the most that fit CAP keys
+        const uint32_t base = off[lo];
+        int a = lo + 1, z = NB;                           // the largest hi in [lo + 1, NB] with off[hi] - base <= CAP (a bucket holds <= kLongBucketLimit <= CAP keys)
+        while (a < z) { const int mid = (a + z + 1) >> 1; if (off[mid] - base <= (uint32_t)CAP) a = mid; else z = mid - 1; }
+        const int hi = a;
+        const uint32_t cnt = off[hi] - base;
+        for (int b = lo + (int)threadIdx.x; b < hi; b += NT) cur[b] = 0u;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += NT) {
+            const unsigned long long k = list[i];
+            const int b = bucket_of(k);
+            if (b >= lo && b < hi) keys[off[b] - base + atomicAdd(&cur[b], 1u)] = k;
+        }
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < cnt; j += NT) {
+            const unsigned long long k = keys[j];
+            const int b = bucket_of(k);
+            const uint32_t l0 = off[b] - base, l1 = off[b + 1] - base;
+            uint32_t rank = 0;
+            for (uint32_t q = l0; q < l1; ++q) rank += keys[q] < k ? 1u : 0u;
+            out[base + l0 + rank] = (uint32_t)k;
+        }
+        __syncthreads();
+        lo = hi;
+    }
+}
+
 template <int CAP, int NT, int NBMAX>
 __global__ void __launch_bounds__(NT, CAP == 8192 ? 2 : 1)     // the 8 192 class: two 1 024-thread workgroups per CU (<= 64 VGPRs, 2 x 81 060 B of LDS)
-gsr_tile_sort_bucket(const uint32_t* __restrict__ tile_off, const unsigned long long* __restrict__ entries,
-                     uint32_t* __restrict__ out_ids, uint32_t lo_excl, uint32_t hi_incl,
+gsr_tile_sort_bucket(const uint32_t* __restrict__ tile_off, unsigned long long* __restrict__ entries,
+                     uint32_t* __restrict__ out_ids, uint32_t lo_excl, uint32_t hi_incl /* (unused bound of the classes of rounds 1-5: every list longer than lo_excl is sorted) */,
                      const unsigned long long* __restrict__ counters, uint32_t capacity,
                      const uint2* __restrict__ order_span /* (list start, length) of the tiles, longest lists first (gsr_tile_scan) */,
                      uint32_t ntiles /* entries of order_span */) {
@@ -581,39 +651,12 @@ gsr_tile_sort_bucket(const uint32_t* __restrict__ tile_off, const unsigned long 
     uint32_t* cur = off + (NBMAX + 1);
     uint32_t* red = cur + NBMAX;                       // [0..15] wave partials, [32] min, [33] max, [34] max bucket
     // longest lists first: a tile is a latency chain of its own (eight barriers), and with two 80 KiB workgroups per CU the
-    // launch is two rounds deep -- the long chains start in the first, the short ones fill in behind them.
-    // The grid may be smaller than the number of tiles (the 16 384 class: <= one workgroup per CU, launched on a PREDICTION that a
-    // list longer than 8 192 exists -- 380 workgroups of 128 KiB that all leave at once were 4.9 us of every step at 1M Gaussians):
-    // a workgroup walks positions blockIdx.x, + gridDim.x, ... and stops at the first list too short for its class (the order is
-    // by ceil(n / 2^seg_shift) descending and 8 192 is a multiple of every 2^seg_shift: no longer list follows a shorter class).
-    if constexpr (CAP > 8192) {
-        for (uint32_t pos = blockIdx.x; pos < ntiles; pos += gridDim.x) {
-            const uint2 span = order_span[pos];
-            const uint32_t s = span.x, n = span.y;
-            if (n <= lo_excl) return;
-            if (n <= hi_incl) sort_one_tile<CAP, NT, NBMAX>(keys, off, cur, red, entries, out_ids, s, n);
-            if (pos + gridDim.x < ntiles) __syncthreads();             // (block-uniform) the LDS arrays are reused
-        }
-    } else {                                                           // one tile per workgroup (the loop costs the compiler 18 VGPRs)
-        const uint2 span = order_span[blockIdx.x];
-        if (span.y <= lo_excl || span.y > hi_incl) return;
-        sort_one_tile<CAP, NT, NBMAX>(keys, off, cur, red, entries, out_ids, span.x, span.y);
-    }
+    // launch is two rounds deep -- the long chains start in the first, the short ones fill in behind them
+    const uint2 span = order_span[blockIdx.x];
+    if (span.y <= lo_excl) return;
+    if (span.y <= (uint32_t)CAP) sort_one_tile<CAP, NT, NBMAX>(keys, off, cur, red, entries, out_ids, span.x, span.y);
+    else sort_long_tile<CAP, NT, NBMAX>(keys, off, cur, red, entries + span.x, out_ids + span.x, span.y);
 }
 
-// lists longer than the largest LDS class: network in place in HBM, then the same outputs
-extern "C" __global__ void __launch_bounds__(1024)
-gsr_tile_sort_global_ids(const uint32_t* __restrict__ tile_off, unsigned long long* __restrict__ entries,
-                         uint32_t* __restrict__ out_ids, uint32_t lo_excl,
-                         const unsigned long long* __restrict__ counters, uint32_t capacity) {
-    if (counters[2] > (unsigned long long)capacity) return;
-    const uint32_t s = tile_off[blockIdx.x];
-    const uint32_t n = tile_off[blockIdx.x + 1] - s;
-    if (n <= lo_excl) return;
-    bitonic_sort(entries + s, n, 1024);
-    for (uint32_t i = threadIdx.x; i < n; i += 1024) out_ids[s + i] = (uint32_t)entries[s + i];
-}
-
-template __global__ void gsr_tile_sort_bucket<2048, 256, 512>(const uint32_t*, const unsigned long long*, uint32_t*, uint32_t, uint32_t, const unsigned long long*, uint32_t, const uint2*, uint32_t);
-template __global__ void gsr_tile_sort_bucket<8192, 1024, 1920>(const uint32_t*, const unsigned long long*, uint32_t*, uint32_t, uint32_t, const unsigned long long*, uint32_t, const uint2*, uint32_t);
-template __global__ void gsr_tile_sort_bucket<16384, 1024, 2048>(const uint32_t*, const unsigned long long*, uint32_t*, uint32_t, uint32_t, const unsigned long long*, uint32_t, const uint2*, uint32_t);
+template __global__ void gsr_tile_sort_bucket<2048, 256, 512>(const uint32_t*, unsigned long long*, uint32_t*, uint32_t, uint32_t, const unsigned long long*, uint32_t, const uint2*, uint32_t);
+template __global__ void gsr_tile_sort_bucket<8192, 1024, 1920>(const uint32_t*, unsigned long long*, uint32_t*, uint32_t, uint32_t, const unsigned long long*, uint32_t, const uint2*, uint32_t);

@@ -134,15 +134,18 @@ def _cluster_scene(N, spread, offset, ties, seed=0):
                 rotations=torch.nn.functional.normalize(torch.randn(N, 4, generator=g), dim=1))
 
 
-# list-length classes of the per-tile sort (csrc/gsr_api.hip: <=2048 small, <=8192 medium, <=16384 large LDS
-# classes, beyond that the in-place HBM network) -- every class is driven through the oracle comparison
+# list lengths of the per-tile sort (csrc/gsr_binning.hip: a 256-thread kernel with a 2 048-key LDS buffer, a 1 024-thread one with
+# 8 192; longer lists are streamed through the buffer in portions, skewed depths fall back to the network) -- every path is driven
+# through the oracle comparison
 @pytest.mark.parametrize("N,spread,offset,ties,lo,hi",
                          [(6000, 0.2, 0.0, True, 2048, 8192), (12000, 0.15, 0.229, False, 8192, 16384),
-                          (12000, 0.15, 0.229, True, 8192, 16384), (20000, 0.15, 0.229, True, 16384, 10 ** 9)],
-                         ids=["medium_ties", "large_bucket", "large_ties", "global_ties"])
+                          (12000, 0.15, 0.229, True, 8192, 16384), (20000, 0.15, 0.229, True, 16384, 10 ** 9),
+                          (20000, 0.15, 0.229, False, 16384, 10 ** 9)],
+                         ids=["medium_ties", "large_bucket", "large_ties", "global_ties", "huge_bucket"])
 def test_depth_ties_and_heavy_tile(gpu, hooks, N, spread, offset, ties, lo, hi):
-    """Many coincident-depth Gaussians in one tile (stable tie order) and tile lists in every size class
-    of the sort, including the > 16384-entry fallback that sorts in HBM."""
+    """Many coincident-depth Gaussians in one tile (stable tie order) and tile lists of every length the sort treats differently:
+    inside the LDS buffer, two or three portions of it, many portions, and -- thousands of exact ties in one bucket -- the network
+    in the list's own memory."""
     W = H = 64
     sc = _cluster_scene(N, spread, offset, ties)
     S = O.make_settings(O.orbit_pose(0, 0, 2.0), W, H, sh_degree=0)
@@ -152,17 +155,15 @@ def test_depth_ties_and_heavy_tile(gpu, hooks, N, spread, offset, ties, lo, hi):
     oo, og, aux = run_oracle(sc, S, w, torch.float64)
     assert_forward_close(ho, oo, aux)
     assert_grads_close(hg, og, aux, floors=grad_floors(sc, og))
-    if lo == 8192:
-        # the 16 384 class on ONE workgroup (test hook sort_grid): it walks every list of the class, one after the other -- same bits
-        # (with the cluster spread over four tiles: several lists in the class)
-        sc4 = _cluster_scene(20000, spread, 0.0, ties)
-        base4, _, st4 = run_hip(sc4, S, gpu, w)
-        assert 8192 < st4["max_tile"] <= 16384, st4
-        hooks.set("sort_grid", 1)
+    # a list longer than a kernel's LDS buffer is streamed through it in depth-ordered portions (sort_long_tile): the same scene through
+    # the 256-thread kernel (buffer 2 048: up to ten portions here; test hook sort_kernel) and through the 1 024-thread one -- same bits
+    base = ho
+    for kern in (1, 2):
+        hooks.set("sort_kernel", kern)
         for _ in range(2):
-            h1, _, st1 = run_hip(sc4, S, gpu, w)
+            h1, _, _ = run_hip(sc, S, gpu, w)
             for i in range(4):
-                assert torch.equal(h1[i], base4[i]), i
+                assert torch.equal(h1[i], base[i]), (kern, i)
 
 
 def test_backward_without_forward_stats(gpu, monkeypatch):
