@@ -122,7 +122,7 @@ typedef struct GsrStats {
                                  * 0 (the first one has accumulated into them); 0 also without GsrStats. 2: as 1, and the forward has also cleared
                                  * GsrView.grad_clear (the array the backward's outputs are carved from; same one-shot rule). -1: the
                                  * forward ran with GSR_VIEW_NO_BACKWARD and left no state for a backward */
-    int64_t speculated;         /* 1: the list scratch and the sort classes came from the thread's earlier calls of the same (N, H, W, views) -- an
+    int64_t speculated;         /* 1: the list scratch and the choice of sort kernel came from the thread's earlier calls of the same (N, H, W, views) -- an
                                  * 8-entry table, least recently used shape replaced -- and binning / sort / compositing ran without waiting for the host;
                                  * 0: first call of the shape, a prediction that turned out too small (tail repeated), or "speculate" = 0 */
     int64_t pending;            /* != 0: an asynchronous forward (GSR_VIEW_ASYNC_STATS) whose counts have not been collected: gsr_forward_complete */
@@ -172,8 +172,8 @@ int gsr_testing_override(const char* name, int32_t value);
  *   stats            [host] optional
  * The host returns once the instance counters of THIS call have arrived (GsrStats is exact), but nothing on the GPU waits for
  * the host: the list scratch is sized from the previous call of the thread on the same (N, H, W) (+25 %), binning / sort /
- * compositing are enqueued before the wait, and a prediction that turns out too small (instances, or the longest list against
- * the sort kernels that were launched) is detected on the device by every kernel that touches the lists and the tail repeated
+ * compositing are enqueued before the wait, and a prediction that turns out too small (more instances than the scratch was laid
+ * out for; the per-tile sort takes lists of any length) is detected on the device by every kernel that touches the lists and the tail repeated
  * (first call of a shape, or test hook "speculate" = 0: counters first, then the tail, like the reference ext's blocking read of num_rendered).
  * The result does not depend on the prediction: the depth-segment length (GsrStats.seg_shift) follows N and the image size only.
  * Returns 0, or a negative code with gsr_last_error() set. N==0 renders the background. */
